@@ -1,0 +1,92 @@
+"""ctypes binding of libatlas_hip.so (the C-ABI declared in include/atlas_hip.h).
+
+No fallback: `lib()` raises if the library was not built (`python -m atlas_amd.build`).
+torch must be imported before the library is loaded so that the HIP runtime torch ships
+(SONAME libamdhip64.so.7) is the one already resident; the extension then binds to it and
+shares torch's streams and device pointers.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_SO = os.path.join(HERE, "lib", "libatlas_hip.so")
+
+ABI_VERSION = 1
+DT_F16, DT_F32, DT_BF16 = 0, 1, 2
+STATUS_HEADER = 8
+ST_FLAGS, ST_PMAX_BITS, ST_N_FALLBACK, ST_N_CANDIDATES, ST_N_RESCORED, ST_MAXERR_BITS = 0, 1, 2, 3, 4, 5
+F_PMAX_VIOLATION, F_FALLBACK, F_EPS_VIOLATION = 1, 2, 4
+E_BADARG, E_WORKSPACE, E_UNSUPPORTED = -1, -2, -3
+D_FAST, K_FAST_MAX, K_EXACT_MAX = 768, 256, 2048
+
+SYMBOLS = [
+    "atlas_abi_version", "atlas_build_info",
+    "atlas_scan_topk_workspace_bytes", "atlas_scan_topk",
+    "atlas_exact_topk_workspace_bytes", "atlas_exact_topk",
+    "atlas_pack_candidates", "atlas_merge_packed",
+    "atlas_pool_write", "atlas_slab_pmax",
+]
+
+
+class AtlasHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(HIP_SO):
+        raise AtlasHipError(
+            f"{HIP_SO} is missing: the HIP extension is not built (run `python -m atlas_amd.build`). "
+            "atlas_amd has no CPU fallback."
+        )
+    import torch  # noqa: F401  (loads torch's HIP runtime first; see module docstring)
+
+    L = ctypes.CDLL(HIP_SO)
+    vp, i64, i32, f32, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+    L.atlas_abi_version.restype = i32
+    L.atlas_abi_version.argtypes = []
+    L.atlas_build_info.restype = ctypes.c_char_p
+    L.atlas_build_info.argtypes = []
+    L.atlas_scan_topk_workspace_bytes.restype = sz
+    L.atlas_scan_topk_workspace_bytes.argtypes = [i64, i32, i32, i32]
+    L.atlas_scan_topk.restype = i32
+    L.atlas_scan_topk.argtypes = [vp, i32, vp, i64, i32, i32, i32, f32, vp, vp, vp, vp, sz, vp]
+    L.atlas_exact_topk_workspace_bytes.restype = sz
+    L.atlas_exact_topk_workspace_bytes.argtypes = [i64, i32, i32, i32]
+    L.atlas_exact_topk.restype = i32
+    L.atlas_exact_topk.argtypes = [vp, i32, vp, i64, i32, i32, i32, vp, vp, vp, sz, vp]
+    L.atlas_pack_candidates.restype = i32
+    L.atlas_pack_candidates.argtypes = [vp, vp, i64, i64, i64, vp, vp]
+    L.atlas_merge_packed.restype = i32
+    L.atlas_merge_packed.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.atlas_pool_write.restype = i32
+    L.atlas_pool_write.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, vp]
+    L.atlas_slab_pmax.restype = i32
+    L.atlas_slab_pmax.argtypes = [vp, i64, i32, vp, vp]
+    if L.atlas_abi_version() != ABI_VERSION:
+        raise AtlasHipError(f"ABI mismatch: library {L.atlas_abi_version()} vs binding {ABI_VERSION}")
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        names = {E_BADARG: "ATLAS_E_BADARG", E_WORKSPACE: "ATLAS_E_WORKSPACE", E_UNSUPPORTED: "ATLAS_E_UNSUPPORTED"}
+        raise AtlasHipError(f"{what} failed: {names.get(rc, 'hipError_t ' + str(rc))}")
+
+
+def torch_dtype_code(dtype):
+    import torch
+
+    if dtype == torch.float16:
+        return DT_F16
+    if dtype == torch.float32:
+        return DT_F32
+    if dtype == torch.bfloat16:
+        return DT_BF16
+    return None

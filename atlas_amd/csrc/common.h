@@ -1,0 +1,135 @@
+// common.h — arithmetic helpers shared by every kernel of the retrieval path.
+//
+// Everything here is `ATLAS_HD` (host+device) on purpose: tests/test_host_helpers.py
+// compiles this header with g++ into a tiny host library and checks each helper against
+// the independent restatement in oracle/oracle.c — the device arithmetic that decides
+// scores, keys and pruning margins is therefore testable without a GPU.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define ATLAS_HD __host__ __device__ __forceinline__
+#else
+#define ATLAS_HD static inline
+#endif
+
+namespace atlas {
+
+// ---- bit casts ---------------------------------------------------------------------
+ATLAS_HD uint32_t f32_bits(float f) { union { float f; uint32_t u; } x; x.f = f; return x.u; }
+ATLAS_HD float bits_f32(uint32_t u) { union { float f; uint32_t u; } x; x.u = u; return x.f; }
+ATLAS_HD uint64_t f64_bits(double f) { union { double f; uint64_t u; } x; x.f = f; return x.u; }
+ATLAS_HD double bits_f64(uint64_t u) { union { double f; uint64_t u; } x; x.u = u; return x.f; }
+
+// ---- fp16 <-> wider, bit-level, round-to-nearest-even, subnormals kept ----------------
+// (src/index.py:117 `.half()` on queries and the single fp16 rounding of each score)
+ATLAS_HD double f16_bits_to_f64(uint16_t h) {
+    const uint32_t s = h >> 15, e = (h >> 10) & 31, m = h & 1023;
+    double v;
+    if (e == 0) v = (double)m * 5.9604644775390625e-08;                 // m * 2^-24
+    else if (e == 31) v = m ? bits_f64(0x7ff8000000000000ull) : bits_f64(0x7ff0000000000000ull);
+    else v = bits_f64(((uint64_t)(e - 15 + 1023) << 52) | ((uint64_t)m << 42));
+    return s ? -v : v;
+}
+ATLAS_HD float f16_bits_to_f32(uint16_t h) { return (float)f16_bits_to_f64(h); }  // exact
+
+// double -> fp16 bits, one rounding (RNE), no intermediate float (avoids double rounding)
+ATLAS_HD uint16_t f64_to_f16_bits(double x) {
+    const uint64_t u = f64_bits(x);
+    const uint16_t sign = (uint16_t)((u >> 48) & 0x8000);
+    const uint64_t a = u & 0x7fffffffffffffffull;
+    if (a > 0x7ff0000000000000ull) return (uint16_t)(sign | 0x7e00);          // NaN
+    const int e = (int)(a >> 52) - 1023;                                      // unbiased
+    if (e >= 16) return (uint16_t)(sign | 0x7c00);                            // >= 2^16 -> inf
+    if (e < -25) return sign;                                                 // < 2^-25 -> 0
+    uint64_t m = (a & 0x000fffffffffffffull) | 0x0010000000000000ull;         // 53-bit
+    // target: value = mant * 2^(q) with q = max(e,-14) - 10 ; shift = 52 - 10 + (sub ? -14-e : 0)
+    int shift = 42 + (e < -14 ? (-14 - e) : 0);
+    uint64_t keep = m >> shift;
+    const uint64_t rem = m & ((1ull << shift) - 1), half = 1ull << (shift - 1);
+    if (rem > half || (rem == half && (keep & 1))) keep++;
+    uint32_t out;
+    if (e < -14) out = (uint32_t)keep;                    // subnormal (may carry into normal)
+    else out = (uint32_t)(((uint32_t)(e + 15 - 1) << 10) + keep);   // keep has hidden bit
+    if (out >= 0x7c00) out = 0x7c00;                                        // rounded up to inf
+    return (uint16_t)(sign | out);
+}
+ATLAS_HD uint16_t f32_to_f16_bits(float x) { return f64_to_f16_bits((double)x); }  // exact widen
+ATLAS_HD uint16_t bf16_bits_to_f16_bits(uint16_t b) {
+    return f32_to_f16_bits(bits_f32((uint32_t)b << 16));
+}
+
+// ---- order-preserving integer keys ---------------------------------------------------
+// fp16 bits -> 16-bit key, larger key <=> larger value; -0 == +0 (a tie, broken by row)
+ATLAS_HD uint16_t f16_order_key(uint16_t h) {
+    if ((h & 0x7fff) == 0) h = 0;
+    return (h & 0x8000) ? (uint16_t)~h : (uint16_t)(h | 0x8000);
+}
+ATLAS_HD uint16_t f16_from_order_key(uint16_t k) {
+    return (k & 0x8000) ? (uint16_t)(k & 0x7fff) : (uint16_t)~k;
+}
+// fp32 -> 32-bit key, larger key <=> larger value (used for the approximate MFMA scores)
+ATLAS_HD uint32_t f32_order_key(float f) {
+    const uint32_t u = f32_bits(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+ATLAS_HD float f32_from_order_key(uint32_t k) {
+    return bits_f32((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+// canonical 64-bit candidate key inside one shard: (score desc, row asc) == key desc
+ATLAS_HD uint64_t local_key(uint16_t h, uint32_t row) {
+    return ((uint64_t)f16_order_key(h) << 32) | (uint64_t)(0xffffffffu - row);
+}
+// cross-shard packed candidate (atlas_hip.h): 16-bit score key, 47-bit inverted global id
+#define ATLAS_GID_BITS 47
+#define ATLAS_GID_MASK ((1ull << ATLAS_GID_BITS) - 1)
+ATLAS_HD uint64_t pack_candidate(uint16_t h, uint64_t gid) {
+    return ((uint64_t)f16_order_key(h) << ATLAS_GID_BITS) | (ATLAS_GID_MASK - (gid & ATLAS_GID_MASK));
+}
+
+// ---- canonical exact score -------------------------------------------------------------
+// 8 interleaved double chains (chain j takes elements j, j+8, ...), combined by a fixed
+// tree. fp16*fp16 is exact in double, so `c + q*p` rounds once whether or not the compiler
+// contracts it to an fma: the result depends only on this order. oracle/oracle.c restates it.
+struct Chains8 { double c[8]; };
+ATLAS_HD void chains_init(Chains8& s) { for (int j = 0; j < 8; ++j) s.c[j] = 0.0; }
+ATLAS_HD double chains_finish(const Chains8& s) {
+    return ((s.c[0] + s.c[1]) + (s.c[2] + s.c[3])) + ((s.c[4] + s.c[5]) + (s.c[6] + s.c[7]));
+}
+ATLAS_HD double exact_dot_f16(const uint16_t* q, const uint16_t* p, int d) {
+    Chains8 s; chains_init(s);
+    int i = 0;
+    for (; i + 8 <= d; i += 8)
+        for (int j = 0; j < 8; ++j) s.c[j] += f16_bits_to_f64(q[i + j]) * f16_bits_to_f64(p[i + j]);
+    for (int j = 0; i + j < d; ++j) s.c[j] += f16_bits_to_f64(q[i + j]) * f16_bits_to_f64(p[i + j]);
+    return chains_finish(s);
+}
+
+// ---- certified pruning margin ---------------------------------------------------------
+// The MFMA scan produces s~ with |s~ - s| <= eps (eps = GAMMA*|q|*pmax).
+// Let T be the k-th largest s~ over any set of rows already seen. Then k rows have exact
+// score >= T-eps, so the final k-th best fp16 score is >= RNE16(T-eps) >= T - eps - u/2,
+// where u bounds the fp16 spacing around T. A row i with
+//         s~_i  <=  theta = clamp(T) - 2*eps - 2*u
+// has fp16 score RNE16(s_i) <= RNE16(s~_i + eps) < RNE16(T - eps) (strictly: the 2*u covers
+// the half-ulp of each rounding plus the doubled grid spacing just below a negative power of
+// two), so it cannot enter the canonical top-k and may be dropped. Rows above theta are kept
+// and rescored exactly.  u = fp16 spacing of the binade of |clamp(T)| + 2*eps.
+#define ATLAS_GAMMA 3.0517578125e-05f   /* 2^-15 */
+#define ATLAS_F16_MAX_ROUND 65520.0f    /* values >= this round to fp16 inf */
+ATLAS_HD float ulp16_at(float a) {      // fp16 spacing of the binade containing a (a >= 0)
+    const uint32_t e = (f32_bits(a) >> 23) & 0xff;     // biased fp32 exponent
+    int ex = (int)e - 127;
+    if (ex < -14) ex = -14;
+    if (ex > 15) ex = 15;
+    return bits_f32((uint32_t)(ex - 10 + 127) << 23);
+}
+ATLAS_HD float prune_threshold(float T, float eps) {
+    if (!(T > -ATLAS_F16_MAX_ROUND)) return bits_f32(0xff800000u);   // -inf (also NaN): keep all
+    if (T > ATLAS_F16_MAX_ROUND) T = ATLAS_F16_MAX_ROUND;            // everything above ties at +inf
+    const float a = (T < 0 ? -T : T) + 2.0f * eps;
+    // the last term absorbs the fp32 rounding of this expression itself
+    return (T - 2.0f * eps - 2.0f * ulp16_at(a)) - 4.0f * (a * 1.1920929e-07f);
+}
+
+}  // namespace atlas

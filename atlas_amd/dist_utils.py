@@ -1,0 +1,78 @@
+"""Rank helpers + the two collectives the search path needs.
+
+Replaces the hot-path use of src/dist_utils.py (varsize_all_gather :46-69, varsize_gather :72-99,
+get_varsize :102-113). The reference issues 3 + 4*W collectives per search_knn call (SURVEY §2.3
+C1-C5); here a search is: one size all_gather + one padded fp16 query all_gather (C1+C2, C3 is
+redundant and dropped), one all_gather of packed (score,id) candidates (replaces C4+C5), and one
+object all_gather of the winning passages.
+
+`backend="nccl"` on PyTorch-ROCm is RCCL; tensors handed to a collective live on the device the
+process group's backend expects (cuda for nccl, cpu for gloo) — callers pass device tensors.
+"""
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def is_initialized() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_rank() -> int:
+    return dist.get_rank() if is_initialized() else 0
+
+
+def get_world_size() -> int:
+    return dist.get_world_size() if is_initialized() else 1
+
+
+def barrier() -> None:
+    if is_initialized():
+        dist.barrier()
+
+
+@torch.no_grad()
+def all_gather_queries(queries: torch.Tensor) -> Tuple[torch.Tensor, List[int]]:
+    """(b_r, d) queries of any float dtype -> ((B, d) fp16 of all ranks in rank order, [b_0..b_{W-1}]).
+
+    fp16 on the wire: the scan casts with `.half()` anyway (src/index.py:117), so gathering the
+    fp32 originals (reference C2) moves twice the bytes for the same result.
+    """
+    q16 = queries.to(torch.float16)
+    if not is_initialized():
+        return q16, [q16.shape[0]]
+    W = dist.get_world_size()
+    size = torch.tensor([q16.shape[0]], device=q16.device, dtype=torch.int64)
+    sizes = [torch.zeros_like(size) for _ in range(W)]
+    dist.all_gather(sizes, size)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(sizes)
+    d = q16.shape[1]
+    padded = q16
+    if q16.shape[0] != mx:
+        padded = torch.zeros((mx, d), dtype=torch.float16, device=q16.device)
+        padded[: q16.shape[0]] = q16
+    out = [torch.empty((mx, d), dtype=torch.float16, device=q16.device) for _ in range(W)]
+    dist.all_gather(out, padded.contiguous())
+    allq = torch.cat([o[:n] for o, n in zip(out, sizes)], dim=0)
+    return allq, sizes
+
+
+@torch.no_grad()
+def all_gather_packed(packed: torch.Tensor) -> torch.Tensor:
+    """(B, k) int64 packed candidates -> (W, B, k): ONE fixed-size collective, 8*B*k bytes per rank."""
+    if not is_initialized():
+        return packed.unsqueeze(0)
+    W = dist.get_world_size()
+    out = torch.empty((W,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out, packed.contiguous())
+    return out
+
+
+def all_gather_object(obj) -> list:
+    if not is_initialized():
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out

@@ -1,0 +1,363 @@
+"""HipDistributedIndex — drop-in for the reference's flat `DistributedIndex` (src/index.py:43-160).
+
+Same public surface, same argument meaning, same error behaviour:
+
+    index.init_embeddings(passages, dim=768)            index.py:48-53
+    index.embeddings[:, a:b] = X.T                      atlas.py:79   (a (d,N) view of the slab)
+    index.search_knn(queries, topk) -> (docs, scores)   index.py:122-157
+    index.save_index / load_index                       index.py:61-111  (same files on disk)
+    index.is_index_trained() / train_index()            index.py:159-160
+    index.doc_map, index.is_in_gpu
+
+What differs underneath:
+  * the slab is (N, d) row-major fp16 in HBM (coalesced row reads); `embeddings` is its
+    transposed view, so callers still see the reference's (d, N) tensor;
+  * `_compute_scores_and_indices` is one fused HIP scan (no (B, N) score matrix), returning the
+    canonical result: scores = correctly rounded fp16 of the exact inner product, ties broken by
+    lowest passage id — the summation-order / tie-order independent member of the family of
+    results the reference's backend may produce (include/atlas_hip.h);
+  * the distributed search uses one packed (score,id) all-gather instead of 4*W pickled
+    gathers, and ships passage text only for the k winners of each query.
+
+There is no CPU path: every compute call goes through atlas_amd/_lib.py and raises if the HIP
+library is missing or the slab is not on a GPU.
+"""
+import ctypes
+import math
+import os
+import pickle
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, dist_utils
+
+EMBEDDINGS_DIM: int = 768  # src/retrievers.py:13
+
+_GID_BITS = 47
+_GID_MASK = (1 << _GID_BITS) - 1
+
+
+# --------------------------------------------------------------------------------------------
+# packed candidates, host side (numpy). Same bit layout as csrc/common.h pack_candidate().
+# --------------------------------------------------------------------------------------------
+def _order_key16(score_bits: np.ndarray) -> np.ndarray:
+    h = score_bits.astype(np.int64) & 0xFFFF
+    h = np.where((h & 0x7FFF) == 0, 0, h)
+    return np.where(h & 0x8000, 0xFFFF - h, h | 0x8000)
+
+
+def pack_candidates_host(scores_f16: np.ndarray, idx: np.ndarray, id_mul: int, id_add: int) -> np.ndarray:
+    """(score fp16, local row) -> int64 packed candidate; rows with idx < 0 pack to 0."""
+    key = _order_key16(scores_f16.view(np.uint16))
+    gid = idx.astype(np.int64) * id_mul + id_add
+    packed = (key << _GID_BITS) | (_GID_MASK - (gid & _GID_MASK))
+    return np.where(idx < 0, 0, packed).astype(np.int64)
+
+
+def unpack_candidates_host(packed: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """int64 packed -> (score fp16, global id); packed == 0 -> (-inf, -1)."""
+    key = (packed >> _GID_BITS) & 0xFFFF
+    bits = np.where(key & 0x8000, key & 0x7FFF, 0xFFFF - key).astype(np.uint16)
+    gid = _GID_MASK - (packed & _GID_MASK)
+    empty = packed == 0
+    bits = np.where(empty, np.uint16(0xFC00), bits).astype(np.uint16)
+    gid = np.where(empty, -1, gid).astype(np.int64)
+    return bits.view(np.float16), gid
+
+
+def merge_packed_host(gathered: np.ndarray, k: int) -> np.ndarray:
+    """(W, B, k) packed -> (B, k): the k largest per query, descending (index.py:151 over W*k)."""
+    W, B, kk = gathered.shape
+    flat = np.ascontiguousarray(gathered.transpose(1, 0, 2)).reshape(B, W * kk)
+    return -np.sort(-flat, axis=1, kind="stable")[:, :k]
+
+
+class HipDistributedIndex(object):
+    def __init__(self):
+        self.embeddings = None          # (d, N) fp16 view of the slab, like the reference
+        self.doc_map = dict()
+        self.is_in_gpu = True
+        self._slab = None               # (N, d) fp16, row-major, contiguous
+        self._pmax: Optional[float] = None     # certified upper bound on row norms (None = unknown)
+        self._ws = None
+        self._ws_exact = None
+        self._gid_mode = "round_robin"  # how local rows map to global passage ids
+        self._gid_offset = 0
+        self._gid_bounds = None         # contiguous mode: cumulative shard sizes of all ranks
+        self.last_search_stats = {}
+
+    # ------------------------------------------------------------------ storage
+    def _device(self):
+        if self.is_in_gpu and torch.cuda.is_available():
+            return torch.device("cuda", torch.cuda.current_device())
+        return torch.device("cpu")
+
+    def _set_slab(self, slab: torch.Tensor):
+        assert slab.dtype == torch.float16 and slab.dim() == 2 and slab.is_contiguous()
+        self._slab = slab
+        self.embeddings = slab.T
+        self._pmax = None
+
+    def init_embeddings(self, passages, dim: Optional[int] = EMBEDDINGS_DIM):
+        """index.py:48-53 — allocate a zeroed slab for `passages` and the local doc map."""
+        self.doc_map = {i: doc for i, doc in enumerate(passages)}
+        self._set_slab(torch.zeros((len(passages), dim), dtype=torch.float16, device=self._device()))
+        self._gid_mode = "round_robin"   # src/index_io.py:41: global line c -> rank c % W, slot c // W
+
+    def _check_slab(self):
+        # callers may only write through `embeddings[...] = ...`; if somebody rebinds the
+        # attribute (as the reference's own load_index does), adopt the new tensor
+        e = self.embeddings
+        assert e is not None
+        if self._slab is None or e.data_ptr() != self._slab.data_ptr() or tuple(e.shape) != (self._slab.shape[1], self._slab.shape[0]):
+            self._set_slab(e.T.contiguous() if not e.T.is_contiguous() else e.T)
+
+    # ------------------------------------------------------------------ persistence (index.py:55-111)
+    def _get_saved_embedding_path(self, save_dir: str, shard: int) -> str:
+        return os.path.join(save_dir, f"embeddings.{shard}.pt")
+
+    def _get_saved_passages_path(self, save_dir: str, shard: int) -> str:
+        return os.path.join(save_dir, f"passages.{shard}.pt")
+
+    def save_index(self, path: str, total_saved_shards: int, overwrite_saved_passages: bool = False) -> None:
+        """Same files as the reference: embeddings.{s}.pt = contiguous (d, n) fp16, passages.{s}.pt = pickle."""
+        assert self.embeddings is not None
+        self._check_slab()
+        rank = dist_utils.get_rank()
+        ws = dist_utils.get_world_size()
+        assert total_saved_shards % ws == 0, f"N workers must be a multiple of shards to save"
+        shards_per_worker = total_saved_shards // ws
+        n_embeddings = self.embeddings.shape[1]
+        embeddings_per_shard = math.ceil(n_embeddings / shards_per_worker)
+        assert n_embeddings == len(self.doc_map), len(self.doc_map)
+        for shard_ind, (shard_start) in enumerate(range(0, n_embeddings, embeddings_per_shard)):
+            shard_end = min(shard_start + embeddings_per_shard, n_embeddings)
+            shard_id = shard_ind + rank * shards_per_worker  # get global shard number
+            passage_shard_path = self._get_saved_passages_path(path, shard_id)
+            if not os.path.exists(passage_shard_path) or overwrite_saved_passages:
+                passage_shard = [self.doc_map[i] for i in range(shard_start, shard_end)]
+                with open(passage_shard_path, "wb") as fobj:
+                    pickle.dump(passage_shard, fobj, protocol=pickle.HIGHEST_PROTOCOL)
+            embeddings_shard = self._slab[shard_start:shard_end].T.contiguous()   # (d, n), reference layout
+            torch.save(embeddings_shard, self._get_saved_embedding_path(path, shard_id))
+
+    def load_index(self, path: str, total_saved_shards: int):
+        """Loads sharded embeddings and passages files written by this class or by the reference."""
+        rank = dist_utils.get_rank()
+        ws = dist_utils.get_world_size()
+        assert total_saved_shards % ws == 0, f"N workers must be a multiple of shards to save"
+        shards_per_worker = total_saved_shards // ws
+        passages = []
+        rows = []
+        dev = self._device()
+        for shard_id in range(rank * shards_per_worker, (rank + 1) * shards_per_worker):
+            with open(self._get_saved_passages_path(path, shard_id), "rb") as fobj:
+                passages.append(pickle.load(fobj))
+            e = torch.load(self._get_saved_embedding_path(path, shard_id), map_location="cpu")   # (d, n)
+            rows.append(e.to(torch.float16).T.contiguous().to(dev))                               # (n, d)
+        self.doc_map = {}
+        n_passages = 0
+        for chunk in passages:
+            for p in chunk:
+                self.doc_map[n_passages] = p
+                n_passages += 1
+        self._set_slab(torch.cat(rows, dim=0).contiguous())
+        # saved shards are contiguous runs of passages: global id = offset of this rank + row
+        self._gid_mode = "contiguous"
+        sizes = dist_utils.all_gather_object(int(self._slab.shape[0]))
+        self._gid_bounds = np.cumsum([0] + [int(s) for s in sizes])
+        self._gid_offset = int(self._gid_bounds[rank])
+
+    # ------------------------------------------------------------------ global ids
+    def _gid_params(self) -> Tuple[int, int]:
+        if self._gid_mode == "round_robin":
+            return dist_utils.get_world_size(), dist_utils.get_rank()
+        return 1, self._gid_offset
+
+    def _gid_owner(self, gid: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """global id -> (owner rank, local row)."""
+        if self._gid_mode == "round_robin":
+            W = dist_utils.get_world_size()
+            return gid % W, gid // W
+        owner = np.searchsorted(self._gid_bounds, gid, side="right") - 1
+        return owner, gid - self._gid_bounds[owner]
+
+    # ------------------------------------------------------------------ local search (HIP)
+    def _workspace(self, nbytes: int, exact: bool = False) -> torch.Tensor:
+        attr = "_ws_exact" if exact else "_ws"
+        ws = getattr(self, attr)
+        if ws is None or ws.numel() < nbytes or ws.device != self._slab.device:
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self._slab.device)
+            setattr(self, attr, ws)
+        return ws
+
+    def _require_gpu(self):
+        if self._slab is None:
+            raise _lib.AtlasHipError("index has no embeddings")
+        if not self._slab.is_cuda:
+            raise _lib.AtlasHipError(
+                "HipDistributedIndex computes on an MI355X only: the slab is on the CPU and there is no "
+                "CPU fallback (is_in_gpu=False or no GPU visible)."
+            )
+        return _lib.lib()
+
+    def slab_pmax(self) -> float:
+        """Max L2 row norm of the slab (one streaming pass); cached until the slab is replaced."""
+        L = self._require_gpu()
+        N, d = self._slab.shape
+        out = torch.zeros(1, dtype=torch.float32, device=self._slab.device)
+        stream = torch.cuda.current_stream(self._slab.device).cuda_stream
+        _lib.check(L.atlas_slab_pmax(self._slab.data_ptr(), N, d, out.data_ptr(), stream), "atlas_slab_pmax")
+        return float(out.item())
+
+    def _exact_topk(self, q: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """MFMA-free exact path (any d, k <= 2048): same canonical result as the scan."""
+        L = self._require_gpu()
+        N, d = self._slab.shape
+        B = q.shape[0]
+        code = _lib.torch_dtype_code(q.dtype)
+        if code is None:
+            q, code = q.float(), _lib.DT_F32
+        q = q.contiguous()
+        ws = self._workspace(L.atlas_exact_topk_workspace_bytes(N, B, d, k), exact=True)
+        out_s = torch.empty((B, k), dtype=torch.float16, device=q.device)
+        out_i = torch.empty((B, k), dtype=torch.int64, device=q.device)
+        stream = torch.cuda.current_stream(q.device).cuda_stream
+        _lib.check(L.atlas_exact_topk(q.data_ptr(), code, self._slab.data_ptr(), N, B, d, k, out_s.data_ptr(),
+                                      out_i.data_ptr(), ws.data_ptr(), ws.numel(), stream), "atlas_exact_topk")
+        return out_s, out_i
+
+    def _local_topk(self, q: torch.Tensor, k: int):
+        """Fused scan + top-k over this shard. Returns device (scores fp16 [B,k], rows int64 [B,k])
+        and their host copies (numpy), after the status word has been checked.
+
+        Protocol (include/atlas_hip.h): the scan certifies its pruning margin with an upper bound
+        on the row norms; if a larger row is met the call is repeated once with the measured
+        bound; queries whose candidate band overflowed (mass ties) are redone on the exact path.
+        """
+        L = self._require_gpu()
+        N, d = self._slab.shape
+        B = q.shape[0]
+        if q.device != self._slab.device:
+            q = q.to(self._slab.device)
+        if d != _lib.D_FAST or k > _lib.K_FAST_MAX:
+            if k > _lib.K_EXACT_MAX:
+                raise _lib.AtlasHipError(f"topk={k} exceeds the supported maximum {_lib.K_EXACT_MAX}")
+            s, i = self._exact_topk(q, k)
+            self.last_search_stats = {"path": "exact"}
+            return s, i, s.cpu().numpy(), i.cpu().numpy()
+        code = _lib.torch_dtype_code(q.dtype)
+        if code is None:
+            q, code = q.float(), _lib.DT_F32
+        q = q.contiguous()
+        if self._pmax is None:
+            self._pmax = self.slab_pmax()
+        ws = self._workspace(L.atlas_scan_topk_workspace_bytes(N, B, d, k))
+        # one output buffer -> one D2H copy: [status int32 | scores fp16 | rows int64]
+        n_st = _lib.STATUS_HEADER + B
+        off_s = (n_st * 4 + 15) // 16 * 16
+        off_i = (off_s + B * k * 2 + 15) // 16 * 16
+        total = off_i + B * k * 8
+        out = torch.empty(total, dtype=torch.uint8, device=q.device)
+        stream = torch.cuda.current_stream(q.device).cuda_stream
+        base = out.data_ptr()
+        reruns = 0
+        while True:
+            _lib.check(L.atlas_scan_topk(q.data_ptr(), code, self._slab.data_ptr(), N, B, d, k, float(self._pmax),
+                                         base + off_s, base + off_i, base, ws.data_ptr(), ws.numel(), stream),
+                       "atlas_scan_topk")
+            host = out.cpu().numpy()      # synchronises
+            st = host[: n_st * 4].view(np.int32)
+            flags = int(st[_lib.ST_FLAGS])
+            pmax_seen = float(st[_lib.ST_PMAX_BITS : _lib.ST_PMAX_BITS + 1].view(np.float32)[0])
+            if flags & _lib.F_PMAX_VIOLATION and reruns < 2:
+                self._pmax = pmax_seen    # the scan measured the true maximum: certified on the re-run
+                reruns += 1
+                continue
+            break
+        if flags & (_lib.F_PMAX_VIOLATION | _lib.F_EPS_VIOLATION):
+            raise _lib.AtlasHipError(f"scan could not certify its result (flags={flags}); this is a bug")
+        self._pmax = pmax_seen if pmax_seen > 0 else self._pmax
+        scores = out[off_s : off_s + B * k * 2].view(torch.float16).view(B, k)
+        rows = out[off_i : off_i + B * k * 8].view(torch.int64).view(B, k)
+        h_scores = host[off_s : off_s + B * k * 2].view(np.float16).reshape(B, k).copy()
+        h_rows = host[off_i : off_i + B * k * 8].view(np.int64).reshape(B, k).copy()
+        n_fb = 0
+        if flags & _lib.F_FALLBACK:
+            sel = np.nonzero(st[_lib.STATUS_HEADER :] != 0)[0]
+            n_fb = len(sel)
+            sel_t = torch.as_tensor(sel, device=q.device, dtype=torch.int64)
+            es, ei = self._exact_topk(q.index_select(0, sel_t), k)
+            scores.index_copy_(0, sel_t, es)
+            rows.index_copy_(0, sel_t, ei)
+            h_scores[sel] = es.cpu().numpy()
+            h_rows[sel] = ei.cpu().numpy()
+        self.last_search_stats = {
+            "path": "scan", "reruns": reruns, "fallback_queries": n_fb, "pmax": self._pmax,
+            "candidates": int(st[_lib.ST_N_CANDIDATES]), "rescored": int(st[_lib.ST_N_RESCORED]),
+            "max_err_over_eps": float(st[_lib.ST_MAXERR_BITS : _lib.ST_MAXERR_BITS + 1].view(np.float32)[0]),
+        }
+        return scores, rows, h_scores, h_rows
+
+    def _compute_scores_and_indices(self, allqueries: torch.Tensor, topk: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """index.py:113-120 — (B, d) queries -> (scores fp16 (B, topk) desc, shard-local indices int64 (B, topk))."""
+        self._check_slab()
+        if topk > self._slab.shape[0]:
+            # the reference's torch.topk raises here; keep that contract
+            raise RuntimeError(f"selected index k out of range (topk={topk} > {self._slab.shape[0]} passages in shard)")
+        scores, rows, _, _ = self._local_topk(allqueries, topk)
+        return scores, rows
+
+    # ------------------------------------------------------------------ search (index.py:122-157)
+    @torch.no_grad()
+    def search_knn(self, queries, topk):
+        """
+        Conducts exhaustive search of the k-nearest neighbours using the inner product metric.
+        Collective: every rank calls it the same number of times with the same topk.
+        """
+        self._check_slab()
+        allqueries, allsizes = dist_utils.all_gather_queries(queries)
+        bounds = np.cumsum([0] + list(allsizes))
+        if topk > self._slab.shape[0]:
+            raise RuntimeError(f"selected index k out of range (topk={topk} > {self._slab.shape[0]} passages in shard)")
+        scores_d, rows_d, scores, rows = self._local_topk(allqueries, topk)
+        if not dist_utils.is_initialized():
+            docs = [[self.doc_map[int(x)] for x in sample] for sample in rows]
+            return docs, [[float(s) for s in sample] for sample in scores]
+
+        rank = dist_utils.get_rank()
+        id_mul, id_add = self._gid_params()
+        packed = self._pack(scores_d, rows_d, scores, rows, id_mul, id_add)             # (B, k) int64, device
+        gathered = dist_utils.all_gather_packed(packed)                                  # (W, B, k): ONE collective
+        merged = merge_packed_host(gathered.cpu().numpy(), topk)                         # host merge of W*k per query
+        m_scores, m_gid = unpack_candidates_host(merged)
+        owner, local = self._gid_owner(np.maximum(m_gid, 0))
+        # passage text: each rank contributes the winners it owns (k per query, not W*k)
+        mine = (owner == rank) & (m_gid >= 0)
+        contrib = {int(g): self.doc_map[int(l)] for g, l in zip(m_gid[mine], local[mine])}
+        table = {}
+        for part in dist_utils.all_gather_object(contrib):
+            table.update(part)
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        docs = [[table[int(g)] for g in m_gid[b] if g >= 0] for b in range(lo, hi)]
+        out_scores = [[float(s) for s, g in zip(m_scores[b], m_gid[b]) if g >= 0] for b in range(lo, hi)]
+        return docs, out_scores
+
+    def _pack(self, scores_d, rows_d, scores_h, rows_h, id_mul, id_add) -> torch.Tensor:
+        if scores_d.is_cuda:
+            L = _lib.lib()
+            out = torch.empty(scores_d.shape, dtype=torch.int64, device=scores_d.device)
+            stream = torch.cuda.current_stream(scores_d.device).cuda_stream
+            _lib.check(L.atlas_pack_candidates(scores_d.data_ptr(), rows_d.data_ptr(), scores_d.numel(), id_mul, id_add,
+                                               out.data_ptr(), stream), "atlas_pack_candidates")
+            return out
+        # process groups on CPU tensors (gloo): same bit layout, host arithmetic
+        return torch.from_numpy(pack_candidates_host(scores_h, rows_h, id_mul, id_add))
+
+    def is_index_trained(self) -> bool:
+        return True
+
+    def train_index(self):  # never called for a flat index (atlas.py:86-88)
+        pass

@@ -1,0 +1,141 @@
+/*
+ * atlas_hip.h — C-ABI of the MI355X (gfx950) retrieval hot path.
+ *
+ * This is the drop-in boundary for the exact-MIPS path of facebookresearch/atlas.
+ * The reference has no FFI (it is pure Python on torch ops), so every entry point
+ * below cites the reference *op sequence* it replaces; INTEGRATION.md shows the
+ * ctypes stub a maintainer adds to src/index.py.
+ *
+ * Conventions (all entry points)
+ *   - plain pointers and sizes only; no torch / C++ types cross this boundary
+ *   - every buffer is caller-owned DEVICE memory unless the name says `host`
+ *   - nothing allocates, frees or synchronises; work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream)
+ *   - re-entrant for distinct (stream, workspace) pairs; no mutable global state
+ *   - return value: 0 = enqueued, >0 = hipError_t from a launch, <0 = ATLAS_E_*
+ *
+ * Canonical result (what "top-k" means here):
+ *   score(q,p) = RNE_fp16( sum_k fp16(q_k) * p_k ) with the sum taken in double in a
+ *                fixed 8-chain order (bit-reproducible; = the correctly rounded fp16 of
+ *                the exact inner product except with probability ~1e-13 per score)
+ *   order      = (score desc, passage row asc)          -- ties: lowest row first
+ *   The reference computes fp16(fp32-accumulated sum) with backend-defined summation
+ *   order and backend-defined tie order (src/index.py:117-118); the canonical result is
+ *   the order/tie-independent representative of that family.
+ */
+#ifndef ATLAS_HIP_H
+#define ATLAS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ATLAS_ABI_VERSION 1
+
+/* negative return codes */
+#define ATLAS_E_BADARG     (-1)  /* null pointer, B<=0, k<=0, d unsupported ...        */
+#define ATLAS_E_WORKSPACE  (-2)  /* ws_bytes smaller than *_workspace_bytes()          */
+#define ATLAS_E_UNSUPPORTED (-3) /* shape outside the fast path (use atlas_exact_topk) */
+
+/* query element types accepted by the search entry points (the reference casts with
+ * `.half()` inside _compute_scores_and_indices, src/index.py:117) */
+#define ATLAS_DT_F16  0
+#define ATLAS_DT_F32  1
+#define ATLAS_DT_BF16 2
+
+/* out_status layout: int32[ATLAS_STATUS_HEADER + B] */
+#define ATLAS_STATUS_HEADER      8
+#define ATLAS_ST_FLAGS           0   /* bit-or of ATLAS_F_*                                    */
+#define ATLAS_ST_PMAX_BITS       1   /* float bits: largest passage-row L2 norm seen by scan    */
+#define ATLAS_ST_N_FALLBACK      2   /* number of queries flagged ATLAS_Q_FALLBACK              */
+#define ATLAS_ST_N_CANDIDATES    3   /* total candidates that reached the merge (diagnostic)    */
+#define ATLAS_ST_N_RESCORED      4   /* total exact rescorings done in the merge (diagnostic)   */
+#define ATLAS_ST_MAXERR_BITS     5   /* float bits: max |approx-exact| / eps over rescored rows */
+/* flags */
+#define ATLAS_F_PMAX_VIOLATION   1   /* a row norm exceeded pmax_hint: results NOT certified;
+                                        re-run with pmax_hint >= out_status[ATLAS_ST_PMAX_BITS] */
+#define ATLAS_F_FALLBACK         2   /* >=1 query needs atlas_exact_topk (per-query word != 0)  */
+#define ATLAS_F_EPS_VIOLATION    4   /* a rescored row had |approx-exact| > eps (model broken)  */
+/* per-query status word (out_status[ATLAS_STATUS_HEADER + q]) */
+#define ATLAS_Q_OK        0
+#define ATLAS_Q_FALLBACK  1          /* candidate band overflowed (mass ties): rows not written */
+
+/* ---- library info -------------------------------------------------------------- */
+int         atlas_abi_version(void);
+const char* atlas_build_info(void);          /* "gfx950 <compile date> ..." */
+
+/* ---- search: fused MFMA scan + top-k (replaces src/index.py:113-120) -------------
+ *
+ * Replaces   scores = torch.matmul(allqueries.half(), self.embeddings)   index.py:117
+ *            scores, indices = torch.topk(scores, topk, dim=1)           index.py:118
+ * without materialising `scores`.
+ *
+ *   q          [B x d] row-major, element type q_dtype (converted to fp16 RNE = `.half()`)
+ *   slab_f16   [N x d] row-major fp16 passage slab (the reference keeps (d,N); the Python
+ *              class exposes slab.T so atlas.py:79 is unchanged)
+ *   k          neighbours per query; rows beyond min(k,N) are filled with (-inf, -1)
+ *   pmax_hint  upper bound on the L2 norm of any slab row (the certified error margin
+ *              scales with it); if a larger row is met, ATLAS_F_PMAX_VIOLATION is raised
+ *              and the measured maximum is reported so the caller can re-run once
+ *   out_score  [B x k] fp16, canonical scores, descending
+ *   out_idx    [B x k] int64 shard-local passage rows (same meaning as torch.topk indices)
+ *   out_status int32[ATLAS_STATUS_HEADER + B]
+ *   ws         workspace of >= atlas_scan_topk_workspace_bytes(N,B,d,k) bytes, 256-B aligned
+ *
+ * Fast path requires d == 768 (EMBEDDINGS_DIM, src/retrievers.py:13) and k <= 256;
+ * otherwise returns ATLAS_E_UNSUPPORTED (callers then use atlas_exact_topk).
+ * Any B >= 1 is accepted (processed in chunks of 64 queries, one slab pass per chunk).
+ */
+size_t atlas_scan_topk_workspace_bytes(int64_t N, int B, int d, int k);
+int atlas_scan_topk(const void* q, int q_dtype, const void* slab_f16, int64_t N, int B, int d,
+                    int k, float pmax_hint, void* out_score_f16, int64_t* out_idx,
+                    int32_t* out_status, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- search: exact reference-order path (any d, any k <= 2048) --------------------
+ * Same contract and same canonical result as atlas_scan_topk, computed without MFMA:
+ * every score is formed in the canonical double order and selection is exact. Slow
+ * (VALU fp64, 2 slab passes); used for queries flagged ATLAS_Q_FALLBACK, for shapes
+ * outside the fast path, and as the on-device cross-check in tests.
+ */
+size_t atlas_exact_topk_workspace_bytes(int64_t N, int B, int d, int k);
+int atlas_exact_topk(const void* q, int q_dtype, const void* slab_f16, int64_t N, int B, int d,
+                     int k, void* out_score_f16, int64_t* out_idx, void* ws, size_t ws_bytes,
+                     void* stream);
+
+/* ---- cross-shard merge (replaces the W*k torch.topk merge, src/index.py:151) -------
+ * Packed candidate = uint64: (orderable_fp16(score) << 47) | (2^47-1 - global_id);
+ * larger = better, so the canonical order is a plain descending integer order.
+ *   atlas_pack_candidates: (score fp16, local row) -> packed, global_id = row*id_mul + id_add
+ *                          (round-robin shards, src/index_io.py:41: id_mul=W, id_add=rank;
+ *                           contiguous shards, src/index.py:95-99: id_mul=1, id_add=offset);
+ *                          rows with idx < 0 pack to 0 (= worse than anything real)
+ *   atlas_merge_packed:    in [W][B][k] (an all_gather of the per-rank [B][k]) -> out [B][k]
+ *                          the k largest per query, descending
+ */
+int atlas_pack_candidates(const void* score_f16, const int64_t* idx, int64_t n, int64_t id_mul,
+                          int64_t id_add, uint64_t* out_packed, void* stream);
+int atlas_merge_packed(const uint64_t* gathered, int W, int B, int k, uint64_t* out_packed,
+                       void* stream);
+
+/* ---- index refresh epilogue (replaces src/retrievers.py:50-52 + src/atlas.py:79) ----
+ * Masked mean pooling of the encoder's last hidden state, with the reference's fp16
+ * double rounding (sum -> fp16, then / count -> fp16), written as contiguous rows
+ * slab[row_offset + i, :] instead of the reference's stride-N column scatter.
+ *   hidden_f16 [n x L x d] fp16, mask [n x L] int64 (HF attention_mask), slab [N x d] fp16
+ */
+int atlas_pool_write(const void* hidden_f16, const int64_t* mask, void* slab_f16, int64_t N,
+                     int64_t row_offset, int n, int L, int d, void* stream);
+
+/* ---- slab statistics ------------------------------------------------------------
+ * out_pmax (device float): max L2 norm over rows [0,N). One streaming pass; lets a caller
+ * obtain a certified pmax_hint up front instead of via the violation/re-run protocol.
+ */
+int atlas_slab_pmax(const void* slab_f16, int64_t N, int d, float* out_pmax, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATLAS_HIP_H */
