@@ -125,7 +125,8 @@ ATLAS_HD float ulp16_at(float a) {      // fp16 spacing of the binade containing
     return bits_f32((uint32_t)(ex - 10 + 127) << 23);
 }
 ATLAS_HD float prune_threshold(float T, float eps) {
-    if (!(T > -ATLAS_F16_MAX_ROUND)) return bits_f32(0xff800000u);   // -inf (also NaN): keep all
+    // k-th best may itself round to -inf (or T is NaN): every row ties with it, nothing is prunable
+    if (!(T - eps - 0.0625f > -ATLAS_F16_MAX_ROUND)) return bits_f32(0xff800000u);
     if (T > ATLAS_F16_MAX_ROUND) T = ATLAS_F16_MAX_ROUND;            // everything above ties at +inf
     const float a = (T < 0 ? -T : T) + 2.0f * eps;
     // the last term absorbs the fp32 rounding of this expression itself

@@ -65,9 +65,10 @@ def all_gather_packed(packed: torch.Tensor) -> torch.Tensor:
     if not is_initialized():
         return packed.unsqueeze(0)
     W = dist.get_world_size()
-    out = torch.empty((W,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+    B, k = packed.shape
+    out = torch.empty((W * B, k), dtype=packed.dtype, device=packed.device)   # concatenation along dim 0
     dist.all_gather_into_tensor(out, packed.contiguous())
-    return out
+    return out.view(W, B, k)
 
 
 def all_gather_object(obj) -> list:

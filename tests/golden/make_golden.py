@@ -1,0 +1,125 @@
+"""Generate golden fixtures by running the REFERENCE's own DistributedIndex (src/index.py) on CPU.
+
+Run in the build container only (needs /root/reference):   python tests/golden/make_golden.py
+
+The reference module does not import as-is here (`import faiss`, and src.retrievers drags in a
+transformers-4.18-only modeling_bert), so it is imported UNMODIFIED through an in-memory shim:
+a fake `faiss` module, a fake `src.retrievers` exposing EMBEDDINGS_DIM, `is_in_gpu=False`, and for
+the 2-process case `torch.Tensor.cuda = identity` + gloo. The code that runs is the reference's
+(_compute_scores_and_indices, search_knn, serialize_listdocs, dist_utils.varsize_*).
+
+Outputs (committed): tests/golden/<case>.npz with the reference's top-k scores (fp16) and ids,
+plus the sha256 of the regenerated inputs (tests/synth.py is integer-deterministic).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import synth  # noqa: E402
+
+REF = "/root/reference"
+
+
+def import_reference_index():
+    class _Any(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            return type(name, (), {})
+
+    faiss, contrib, tu = _Any("faiss"), _Any("faiss.contrib"), _Any("faiss.contrib.torch_utils")
+    sys.modules.update({"faiss": faiss, "faiss.contrib": contrib, "faiss.contrib.torch_utils": tu})
+    faiss.contrib, contrib.torch_utils = contrib, tu
+    retr = types.ModuleType("src.retrievers")
+    retr.EMBEDDINGS_DIM = 768
+    sys.modules["src.retrievers"] = retr
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from src.index import DistributedIndex
+
+    return DistributedIndex
+
+
+CASES = {
+    # name: (N, B, k, passage seed, query seed, dup)   -- 'a10k' is BASELINE.json configs[0]
+    "a10k": dict(N=10000, B=64, k=40, ps=11, qs=12, dup=1),
+    "b3k": dict(N=3000, B=7, k=5, ps=21, qs=22, dup=1),
+    "c_dups": dict(N=2048, B=4, k=10, ps=31, qs=32, dup=4),     # every row appears 4x: forced ties
+    "d_k128": dict(N=5000, B=16, k=128, ps=41, qs=42, dup=1),   # rerank-sized k
+}
+DIST_CASE = dict(N=4000, k=8, ps=51, qs=52, batch=(3, 5))         # 2 ranks, uneven batches
+
+
+def make_inputs(c):
+    P = synth.passages_f16(c["N"] // c["dup"], 768, c["ps"])
+    if c["dup"] > 1:
+        P = np.tile(P, (c["dup"], 1))
+    Q = synth.queries_f32(c["B"], 768, c["qs"])
+    return P, Q
+
+
+def run_single(DistributedIndex, P, Q, k):
+    idx = DistributedIndex()
+    idx.is_in_gpu = False
+    idx.init_embeddings([{"id": str(i)} for i in range(P.shape[0])])
+    idx.embeddings[:, :] = torch.from_numpy(P).T
+    s, i = idx._compute_scores_and_indices(torch.from_numpy(Q), k)
+    return s.numpy(), i.numpy()
+
+
+def _dist_worker(rank, W, port, c, out_dir):
+    import torch.distributed as dist
+
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    DistributedIndex = import_reference_index()
+    P = synth.passages_f16(c["N"], 768, c["ps"])
+    Qall = synth.queries_f32(sum(c["batch"]), 768, c["qs"])
+    lo = sum(c["batch"][:rank])
+    Q = Qall[lo : lo + c["batch"][rank]]
+    mine = np.arange(rank, c["N"], W)              # src/index_io.py:41 round robin
+    idx = DistributedIndex()
+    idx.is_in_gpu = False
+    idx.init_embeddings([{"id": str(int(g))} for g in mine])
+    idx.embeddings[:, :] = torch.from_numpy(P[mine]).T
+    docs, scores = idx.search_knn(torch.from_numpy(Q), c["k"])
+    ids = np.array([[int(d["id"]) for d in row] for row in docs], dtype=np.int64)
+    np.savez(os.path.join(out_dir, f"_dist_rank{rank}.npz"), ids=ids,
+             scores=np.array(scores, dtype=np.float32).astype(np.float16))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main():
+    torch.manual_seed(0)
+    DistributedIndex = import_reference_index()
+    for name, c in CASES.items():
+        P, Q = make_inputs(c)
+        s, i = run_single(DistributedIndex, P, Q, c["k"])
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), ref_scores=s.astype(np.float16), ref_ids=i.astype(np.int64),
+                            sha=np.array(synth.sha(P, Q)), **{k: np.array(v) for k, v in c.items()})
+        print(name, s.shape, "written")
+    import torch.multiprocessing as mp
+
+    c = DIST_CASE
+    mp.spawn(_dist_worker, args=(2, 29533, c, HERE), nprocs=2, join=True)
+    parts = [np.load(os.path.join(HERE, f"_dist_rank{r}.npz")) for r in range(2)]
+    P = synth.passages_f16(c["N"], 768, c["ps"])
+    Qall = synth.queries_f32(sum(c["batch"]), 768, c["qs"])
+    np.savez_compressed(os.path.join(HERE, "e_dist_w2.npz"), ref_ids=np.concatenate([p["ids"] for p in parts]),
+                        ref_scores=np.concatenate([p["scores"] for p in parts]), sha=np.array(synth.sha(P, Qall)),
+                        N=np.array(c["N"]), k=np.array(c["k"]), ps=np.array(c["ps"]), qs=np.array(c["qs"]),
+                        batch=np.array(c["batch"]))
+    for r in range(2):
+        os.remove(os.path.join(HERE, f"_dist_rank{r}.npz"))
+    print("e_dist_w2 written")
+
+
+if __name__ == "__main__":
+    main()

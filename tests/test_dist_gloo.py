@@ -1,0 +1,78 @@
+"""The N>1 path on CPU: world_size 2 and 3 over gloo, uneven per-rank batches, round-robin shards.
+The shard-local top-k comes from the oracle (tests/oracle_backend.py); everything else is product host code:
+query all-gather, packing, the single candidate all-gather, host merge, winners-only passage exchange.
+Expected result: identical to the canonical single-shard search over the union (sharding invariance)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, W, port, N, batches, k, out_dir, mode):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    from atlas_amd import HipDistributedIndex
+    from oracle_backend import oracle_local_topk
+
+    HipDistributedIndex._local_topk = oracle_local_topk
+    P = synth.passages_f16(N, 768, 61)
+    Qall = synth.queries_f32(sum(batches), 768, 62)
+    lo = sum(batches[:rank])
+    Q = torch.from_numpy(Qall[lo : lo + batches[rank]])
+    idx = HipDistributedIndex()
+    idx.is_in_gpu = False
+    if mode == "round_robin":
+        mine = np.arange(rank, N, W)                       # src/index_io.py:41
+        idx.init_embeddings([{"id": str(int(g)), "text": f"p{g}"} for g in mine])
+        idx.embeddings[:, :] = torch.from_numpy(P[mine]).T
+    else:                                                   # contiguous shards via save/load (index.py:95-99)
+        full = HipDistributedIndex()
+        full.is_in_gpu = False
+        if rank == 0:
+            full.init_embeddings([{"id": str(g), "text": f"p{g}"} for g in range(N)])
+            full.embeddings[:, :] = torch.from_numpy(P).T
+            # pretend a 1-process job saved 2*W shards
+            import atlas_amd.dist_utils as du
+            r, w = du.get_rank, du.get_world_size
+            du.get_rank, du.get_world_size = (lambda: 0), (lambda: 1)
+            full.save_index(out_dir, 2 * W)
+            du.get_rank, du.get_world_size = r, w
+        dist.barrier()
+        idx.load_index(out_dir, 2 * W)
+    for rep in range(2):                                    # search_knn is a collective: call it twice
+        docs, scores = idx.search_knn(Q, k)
+    ids = np.array([[int(d["id"]) for d in row] for row in docs], dtype=np.int64).reshape(len(docs), k)
+    assert all(d["text"] == f"p{d['id']}" for row in docs for d in row)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), ids=ids, scores=np.array(scores, dtype=np.float32).reshape(len(docs), k))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("W,batches,mode", [(2, (3, 5), "round_robin"), (3, (4, 0, 2), "round_robin"), (2, (2, 2), "contiguous")])
+def test_distributed_search_equals_union(W, batches, mode, tmp_path, oracle_mod):
+    N, k = 1500, 12
+    port = 29600 + W * 7 + len(mode)
+    mp.spawn(_worker, args=(W, port, N, batches, k, str(tmp_path), mode), nprocs=W, join=True)
+    P = synth.passages_f16(N, 768, 61)
+    Q = synth.queries_f32(sum(batches), 768, 62)
+    s, i = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, k)
+    lo = 0
+    for r in range(W):
+        got = np.load(os.path.join(tmp_path, f"r{r}.npz"))
+        n = batches[r]
+        if n:
+            assert np.array_equal(got["ids"], i[lo : lo + n]), (r, mode)
+            assert np.array_equal(got["scores"], s[lo : lo + n].astype(np.float32))
+        else:
+            assert got["ids"].size == 0
+        lo += n

@@ -1,0 +1,156 @@
+"""Host-side logic of HipDistributedIndex (no GPU): API surface of the reference class, (d,N) view semantics,
+packed candidates, save/load in the reference's on-disk format, error behaviour, and the no-fallback rule."""
+import os
+import pickle
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import parity
+import synth
+from atlas_amd import HipDistributedIndex, _lib, index as index_mod
+from atlas_amd.index_io import load_or_initialize_index, load_passages, save_embeddings_and_index
+from oracle_backend import oracle_local_topk
+
+
+def _mk(n, seed=1, dim=768):
+    idx = HipDistributedIndex()
+    idx.is_in_gpu = False
+    passages = [{"id": str(i), "title": f"t{i}", "text": f"passage {i}"} for i in range(n)]
+    idx.init_embeddings(passages, dim)
+    P = synth.passages_f16(n, dim, seed)
+    return idx, passages, P
+
+
+def test_reference_surface():
+    idx, passages, P = _mk(100)
+    assert tuple(idx.embeddings.shape) == (768, 100) and idx.embeddings.dtype == torch.float16
+    assert idx.doc_map[7]["id"] == "7" and idx.is_index_trained() is True
+    for name in ("init_embeddings", "search_knn", "save_index", "load_index", "train_index",
+                 "_compute_scores_and_indices", "_get_saved_embedding_path", "_get_saved_passages_path"):
+        assert callable(getattr(idx, name))
+
+
+def test_embeddings_view_is_the_slab():
+    """atlas.py:79 writes `index.embeddings[:, a:b] = emb.T`; those must be contiguous slab rows."""
+    idx, _, P = _mk(64)
+    emb = torch.from_numpy(P[10:30])
+    idx.embeddings[:, 10:30] = emb.T
+    assert idx._slab.is_contiguous() and idx._slab.shape == (64, 768)
+    assert torch.equal(idx._slab[10:30], emb) and float(idx._slab[:10].abs().sum()) == 0.0
+    assert idx.embeddings.data_ptr() == idx._slab.data_ptr()
+
+
+def test_no_cpu_fallback():
+    idx, _, P = _mk(32)
+    idx.embeddings[:, :] = torch.from_numpy(P).T
+    with pytest.raises(_lib.AtlasHipError, match="no .*CPU fallback|CPU"):
+        idx.search_knn(torch.randn(2, 768), 4)
+    with pytest.raises(_lib.AtlasHipError):
+        idx.slab_pmax()
+
+
+def test_topk_larger_than_shard_raises_like_torch_topk(monkeypatch):
+    monkeypatch.setattr(HipDistributedIndex, "_local_topk", oracle_local_topk)
+    idx, _, P = _mk(8)
+    with pytest.raises(RuntimeError, match="out of range"):
+        idx.search_knn(torch.randn(1, 768), 9)
+
+
+def test_pack_unpack_merge_host(oracle_mod):
+    rng = np.random.default_rng(0)
+    W, B, k = 3, 5, 6
+    s = rng.standard_normal((W, B, k)).astype(np.float16)
+    s[0, 0, :3] = s[1, 0, :3]                       # cross-shard ties
+    s[2, 1, 0] = np.float16(-0.0); s[0, 1, 0] = np.float16(0.0)
+    rows = rng.integers(0, 1000, (W, B, k)).astype(np.int64)
+    rows[1, 2, 4:] = -1                              # padding
+    packed = np.stack([index_mod.pack_candidates_host(s[w], rows[w], W, w) for w in range(W)])
+    assert (packed[1, 2, 4:] == 0).all() and (packed >= 0).all()
+    us, ug = index_mod.unpack_candidates_host(packed)
+    valid = rows >= 0
+    gid = rows * W + np.arange(W)[:, None, None]
+    assert np.array_equal(ug[valid], gid[valid]) and (ug[~valid] == -1).all()
+    assert np.array_equal(parity.f16_ordinal(us[valid]), parity.f16_ordinal(s[valid]))
+    merged = index_mod.merge_packed_host(packed, k)
+    ms, mg = index_mod.unpack_candidates_host(merged)
+    os_, og = oracle_mod.merge(s, np.where(valid, gid, -1))
+    assert np.array_equal(mg, og) and np.array_equal(parity.f16_ordinal(ms), parity.f16_ordinal(os_))
+
+
+def test_pack_matches_device_layout():
+    """numpy packing == csrc/common.h pack_candidate (compiled for the host)"""
+    import ctypes
+    from atlas_amd import build
+
+    H = ctypes.CDLL(build.build_host())
+    H.h_pack_candidate.restype = ctypes.c_uint64
+    H.h_pack_candidate.argtypes = [ctypes.c_uint16, ctypes.c_uint64]
+    rng = np.random.default_rng(1)
+    s = rng.standard_normal(200).astype(np.float16)
+    rows = rng.integers(0, 2 ** 31, 200).astype(np.int64)
+    got = index_mod.pack_candidates_host(s, rows, 8, 3)
+    for j in range(200):
+        assert int(got[j]) == H.h_pack_candidate(int(s[j:j + 1].view(np.uint16)[0]), int(rows[j] * 8 + 3))
+
+
+def test_search_single_process_matches_oracle(monkeypatch, oracle_mod):
+    monkeypatch.setattr(HipDistributedIndex, "_local_topk", oracle_local_topk)
+    idx, passages, P = _mk(500, seed=5)
+    idx.embeddings[:, :] = torch.from_numpy(P).T
+    Q = synth.queries_f32(6, 768, 6)
+    docs, scores = idx.search_knn(torch.from_numpy(Q), 10)
+    s, i = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, 10)
+    assert [[int(d["id"]) for d in row] for row in docs] == i.tolist()
+    assert scores == s.astype(np.float32).tolist() and isinstance(scores[0][0], float)
+
+
+def test_save_load_reference_format(tmp_path, monkeypatch, oracle_mod):
+    monkeypatch.setattr(HipDistributedIndex, "_local_topk", oracle_local_topk)
+    idx, passages, P = _mk(103, seed=9)
+    idx.embeddings[:, :] = torch.from_numpy(P).T
+    idx.save_index(str(tmp_path), 4)
+    # files look exactly like the reference's (src/index.py:61-87): (768, n) fp16 + pickled passage lists
+    n_per = int(np.ceil(103 / 4))
+    for s in range(4):
+        e = torch.load(tmp_path / f"embeddings.{s}.pt")
+        lo, hi = s * n_per, min(103, (s + 1) * n_per)
+        assert e.dtype == torch.float16 and tuple(e.shape) == (768, hi - lo) and e.is_contiguous()
+        assert torch.equal(e, torch.from_numpy(P[lo:hi]).T)
+        assert pickle.load(open(tmp_path / f"passages.{s}.pt", "rb")) == passages[lo:hi]
+    # the reference's own load_index logic on these files (restated): concat along dim=1 gives the (d, N) matrix
+    ref_emb = torch.concat([torch.load(tmp_path / f"embeddings.{s}.pt") for s in range(4)], dim=1)
+    assert torch.equal(ref_emb, torch.from_numpy(P).T)
+    idx2 = HipDistributedIndex()
+    idx2.is_in_gpu = False
+    idx2.load_index(str(tmp_path), 4)
+    assert torch.equal(idx2._slab, torch.from_numpy(P)) and idx2.doc_map == idx.doc_map
+    Q = torch.from_numpy(synth.queries_f32(3, 768, 10))
+    assert idx2.search_knn(Q, 5) == idx.search_knn(Q, 5)
+    # passages are not rewritten unless asked (index.py:80-83)
+    before = os.path.getmtime(tmp_path / "passages.0.pt")
+    idx.save_index(str(tmp_path), 4)
+    assert os.path.getmtime(tmp_path / "passages.0.pt") == before
+    with pytest.raises(AssertionError):
+        HipDistributedIndex().save_index(str(tmp_path), 4)
+
+
+def test_index_io_factory(tmp_path):
+    f = tmp_path / "p.jsonl"
+    f.write_text('{"id": "0", "title": "A", "section": "s", "text": "x"}\n{"id": "1", "title": "B", "text": "y"}\n')
+    assert load_passages([str(f)])[0]["title"] == "A: s"          # index_io.py:30-31
+    opt = types.SimpleNamespace(index_mode="flat", load_index_path=None, passages=[str(f)], use_file_passages=False,
+                                max_passages=-1)
+    from atlas_amd import index as im
+    orig = im.HipDistributedIndex._device
+    im.HipDistributedIndex._device = lambda self: torch.device("cpu")
+    try:
+        index, passages = load_or_initialize_index(opt)
+    finally:
+        im.HipDistributedIndex._device = orig
+    assert isinstance(index, HipDistributedIndex) and len(passages) == 2 and tuple(index.embeddings.shape) == (768, 2)
+    opt.index_mode = "faiss"
+    with pytest.raises(ValueError, match="unsupported index mode"):
+        load_or_initialize_index(opt)
