@@ -21,7 +21,7 @@ D_FAST, K_FAST_MAX, K_EXACT_MAX = 768, 256, 2048
 
 SYMBOLS = [
     "atlas_abi_version", "atlas_build_info",
-    "atlas_scan_topk_workspace_bytes", "atlas_scan_topk",
+    "atlas_scan_topk_workspace_bytes", "atlas_scan_topk", "atlas_scan_topk_ex",
     "atlas_exact_topk_workspace_bytes", "atlas_exact_topk",
     "atlas_pack_candidates", "atlas_merge_packed",
     "atlas_pool_write", "atlas_slab_pmax",
@@ -56,6 +56,8 @@ def lib():
     L.atlas_scan_topk_workspace_bytes.argtypes = [i64, i32, i32, i32]
     L.atlas_scan_topk.restype = i32
     L.atlas_scan_topk.argtypes = [vp, i32, vp, i64, i32, i32, i32, f32, vp, vp, vp, vp, sz, vp]
+    L.atlas_scan_topk_ex.restype = i32
+    L.atlas_scan_topk_ex.argtypes = [vp, i32, vp, i64, i32, i32, i32, f32, vp, vp, vp, vp, sz, vp, vp, vp]
     L.atlas_exact_topk_workspace_bytes.restype = sz
     L.atlas_exact_topk_workspace_bytes.argtypes = [i64, i32, i32, i32]
     L.atlas_exact_topk.restype = i32

@@ -147,36 +147,39 @@ scan_kernel(const ScanParams p) {
     uint2* my_lists = p.lists + (size_t)blockIdx.x * 64 * p.cap;
 
     // Passage rows stream HBM -> VGPR through buffer loads (cdna guide T8). ONE descriptor per
-    // wave spans [first row of this wave's first tile, N): the per-lane offset is one constant
-    // VGPR, the tile / k-step / fragment strides ride in the scalar offset, so the k-loop has no
-    // address VALU, and rows at or past N read as zero through the descriptor's bounds check.
+    // wave spans [first row of this wave's first tile, N). The hardware bounds check covers
+    // voffset + immediate only (not soffset), so everything that selects a ROW lives in the
+    // per-lane voffset (one VGPR per fragment, bumped once per tile) and rows at or past N read
+    // as zero; the k-step (< one row) rides in the scalar offset. No address VALU in the k-loop.
     //   lane l loads row (l & 15) of fragment pf, bytes [64*s + 16*(l>>4), +16)   (MFMA A operand)
     const int64_t wrow0 = r_begin + (int64_t)wave * PF * 16;
     int64_t span = (wrow0 < p.N) ? (p.N - wrow0) * (int64_t)ROWB : 0;
     if (span > 0xfffffff0ll) span = 0xfffffff0ll;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const unsigned char*)p.slab + (span > 0 ? wrow0 : 0) * (int64_t)ROWB), 0, (int)span, 0x00020000);
-    const int voff = lrow * ROWB + lgrp * 16;
 
-    // fill cursor: byte offset (tile, k-step) of the next ring refill; runs RING-1 steps ahead of
-    // the consumer and parks out of bounds (loads return 0, touch nothing) after the last tile
-    int fill_step = 0, fill_tile = 0;
-    auto fill_soff = [&]() -> int {
-        const int o = fill_tile * (TILE * ROWB) + fill_step * 64;
-        return (fill_tile < ntiles) ? o : (int)0xfffffff0u;
-    };
+    // fill cursor: (rows of the tile being fetched -> vo[], k-step -> fill_step); it runs RING-1
+    // steps ahead of the consumer. Past the last tile it keeps walking forward: those loads hit
+    // rows of the next workgroup's range (harmless) or fall out of bounds (return 0).
+    unsigned vo[PF];
+#pragma unroll
+    for (int pf = 0; pf < PF; ++pf) vo[pf] = (unsigned)((pf * 16 + lrow) * ROWB + lgrp * 16);
+    int fill_step = 0;
     auto fill_advance = [&]() {
         ++fill_step;
-        if (fill_step == KSTEPS) { fill_step = 0; ++fill_tile; }
+        if (fill_step == KSTEPS) {          // scalar condition: next tile of this wave
+            fill_step = 0;
+#pragma unroll
+            for (int pf = 0; pf < PF; ++pf) vo[pf] += (unsigned)(TILE * ROWB);
+        }
     };
 
     u32x4 abuf[RING][PF];
 #pragma unroll
     for (int s = 0; s < RING - 1; ++s) {
-        const int so = fill_soff();
 #pragma unroll
         for (int pf = 0; pf < PF; ++pf)
-            abuf[s][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, so + pf * 16 * ROWB, 0);
+            abuf[s][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)vo[pf], fill_step * 64, 0);
         fill_advance();
         // keep issue order == ring order: hipcc's waitcnt for slot 0 is the minimum over the loop
         // entry and the back edge, so a shuffled prologue would cost ring depth on every revolution
@@ -193,7 +196,10 @@ scan_kernel(const ScanParams p) {
     for (int pf = 0; pf < PF; ++pf) nrm[pf] = 0.f;
     float pm = 0.0f;   // running max of row sum-of-squares seen by this lane's row group
 
-    int64_t row0 = wrow0;      // first row of this wave's current tile
+    // rows relative to r_begin fit 32 bits (plan guarantees rows_per_wg * 1536 < 2^32)
+    const int nrows = (int)(r_end > r_begin ? r_end - r_begin : 0);
+    const uint32_t gbase = (uint32_t)r_begin;          // shard-local row ids are < 2^32
+    int row0 = wave * PF * 16;   // first row (relative) of this wave's current tile
     int par = 0;               // tile parity (double-buffers the compaction-request flag)
     int cstep = 0;             // consumer k-step inside the tile
 
@@ -209,10 +215,9 @@ scan_kernel(const ScanParams p) {
             // RING-1 steps), then consume slot j. sched_barrier pins that order: left alone,
             // hipcc sinks the loads to the loop end and waits vmcnt(0) at the top.
             const int fill = (j + RING - 1) % RING;
-            const int so = fill_soff();
 #pragma unroll
             for (int pf = 0; pf < PF; ++pf)
-                abuf[fill][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, so + pf * 16 * ROWB, 0);
+                abuf[fill][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)vo[pf], fill_step * 64, 0);
             fill_advance();
             __builtin_amdgcn_sched_barrier(0);
             uint4 b[4];
@@ -244,7 +249,7 @@ scan_kernel(const ScanParams p) {
 
         // ------------------------- end of a tile: filter --------------------------------
         cstep = 0;
-        if (row0 < r_end) {        // wave-uniform
+        if (row0 < nrows) {        // wave-uniform
             // full row norms: the 4 lanes {l, l+16, l+32, l+48} hold the 4 k-groups of row l&15
 #pragma unroll
             for (int pf = 0; pf < PF; ++pf) {
@@ -254,12 +259,12 @@ scan_kernel(const ScanParams p) {
                 pm = fmaxf(pm, x);
             }
             // rows past the end of this workgroup's range never become candidates
-            if (row0 + PF * 16 > r_end) {
+            if (row0 + PF * 16 > nrows) {
 #pragma unroll
                 for (int pf = 0; pf < PF; ++pf)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (row0 + pf * 16 + lgrp * 4 + r >= r_end) {
+                        if (row0 + pf * 16 + lgrp * 4 + r >= nrows) {
 #pragma unroll
                             for (int qf = 0; qf < 4; ++qf) acc[pf][qf][r] = neg_inf();
                         }
@@ -277,7 +282,7 @@ scan_kernel(const ScanParams p) {
                     for (int r = 0; r < 4; ++r) any |= acc[pf][qf][r] > th[qf];
             if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
                 // rare path: append candidates to the workgroup's per-query lists
-                const uint32_t rbase = (uint32_t)row0 + (uint32_t)lgrp * 4u;
+                const uint32_t rbase = gbase + (uint32_t)row0 + (uint32_t)lgrp * 4u;
 #pragma unroll
                 for (int pf = 0; pf < PF; ++pf)
 #pragma unroll
@@ -289,7 +294,7 @@ scan_kernel(const ScanParams p) {
                                 const int qq = qf * 16 + lrow;
                                 const uint32_t slot = atomicAdd(&s_cnt[qq], 1u);
                                 if (slot < (uint32_t)p.cap)
-                                    my_lists[(size_t)qq * p.cap + slot] =
+                                    my_lists[(uint32_t)(qq * p.cap) + slot] =
                                         make_uint2(f32_bits(v), rbase + (uint32_t)(pf * 16 + r));
                                 if (slot >= (uint32_t)p.keep_max) s_flag[par] = 1u;
                             }
@@ -811,10 +816,19 @@ size_t atlas_scan_topk_workspace_bytes(int64_t N, int B, int d, int k) {
 int atlas_scan_topk(const void* q, int q_dtype, const void* slab_f16, int64_t N, int B, int d, int k,
                     float pmax_hint, void* out_score_f16, int64_t* out_idx, int32_t* out_status, void* ws,
                     size_t ws_bytes, void* stream_) {
+    return atlas_scan_topk_ex(q, q_dtype, slab_f16, N, B, d, k, pmax_hint, out_score_f16, out_idx, out_status, ws,
+                              ws_bytes, stream_, nullptr, nullptr);
+}
+
+int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t N, int B, int d, int k,
+                       float pmax_hint, void* out_score_f16, int64_t* out_idx, int32_t* out_status, void* ws,
+                       size_t ws_bytes, void* stream_, void* ev_scan_begin, void* ev_scan_end) {
     if (!q || (!slab_f16 && N > 0) || !out_score_f16 || !out_idx || !out_status || !ws) return ATLAS_E_BADARG;
     if (B <= 0 || k <= 0 || N < 0 || q_dtype < 0 || q_dtype > 2 || !(pmax_hint >= 0.f)) return ATLAS_E_BADARG;
     if (d != D_FAST || k > K_FAST_MAX || N >= (int64_t)0xffffffffll) return ATLAS_E_UNSUPPORTED;
     const ScanPlan pl = make_plan(N, d, k, device_cus());
+    // per-lane byte offsets inside one workgroup's range are 32-bit (buffer voffset)
+    if ((pl.rows_per_wg + 2 * SCAN_TILE) * (int64_t)(D_FAST * 2) >= (int64_t)0xfff00000ll) return ATLAS_E_UNSUPPORTED;
     if (ws_bytes < pl.total) return ATLAS_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     unsigned char* w = (unsigned char*)ws;
@@ -841,7 +855,9 @@ int atlas_scan_topk(const void* q, int q_dtype, const void* slab_f16, int64_t N,
         sp.gstat = (uint32_t*)(w + pl.off_gstat); sp.qflag = (uint32_t*)(w + pl.off_qflag);
         sp.rows_per_wg = pl.rows_per_wg; sp.nq = nq; sp.k = k; sp.cap = pl.cap; sp.keep_max = pl.keep_max;
         sp.pmax2_hint = pmax_hint * pmax_hint;
+        if (q0 == 0 && ev_scan_begin) (void)hipEventRecord((hipEvent_t)ev_scan_begin, stream);
         hipLaunchKernelGGL(scan, dim3(pl.G), dim3(SCAN_NW * 64), pl.scan_lds, stream, sp);
+        if (q0 == 0 && ev_scan_end) (void)hipEventRecord((hipEvent_t)ev_scan_end, stream);
         MergeParams mp{};
         mp.slab = (const uint16_t*)slab_f16; mp.N = N; mp.d = d;
         mp.qrow = (const uint16_t*)(w + pl.off_qrow); mp.qeps = sp.qeps;

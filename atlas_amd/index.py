@@ -331,7 +331,7 @@ class HipDistributedIndex(object):
         id_mul, id_add = self._gid_params()
         packed = self._pack(scores_d, rows_d, scores, rows, id_mul, id_add)             # (B, k) int64, device
         gathered = dist_utils.all_gather_packed(packed)                                  # (W, B, k): ONE collective
-        merged = merge_packed_host(gathered.cpu().numpy(), topk)                         # host merge of W*k per query
+        merged = self._merge(gathered, topk)                                             # (B, k) numpy, W*k -> k per query
         m_scores, m_gid = unpack_candidates_host(merged)
         owner, local = self._gid_owner(np.maximum(m_gid, 0))
         # passage text: each rank contributes the winners it owns (k per query, not W*k)
@@ -355,6 +355,17 @@ class HipDistributedIndex(object):
             return out
         # process groups on CPU tensors (gloo): same bit layout, host arithmetic
         return torch.from_numpy(pack_candidates_host(scores_h, rows_h, id_mul, id_add))
+
+    def _merge(self, gathered: torch.Tensor, k: int) -> np.ndarray:
+        """W*k -> k per query under the canonical order (replaces index.py:151)."""
+        W, B, kk = gathered.shape
+        if gathered.is_cuda and W * kk <= 8192:
+            L = _lib.lib()
+            out = torch.empty((B, k), dtype=torch.int64, device=gathered.device)
+            stream = torch.cuda.current_stream(gathered.device).cuda_stream
+            _lib.check(L.atlas_merge_packed(gathered.data_ptr(), W, B, k, out.data_ptr(), stream), "atlas_merge_packed")
+            return out.cpu().numpy()
+        return merge_packed_host(gathered.cpu().numpy(), k)
 
     def is_index_trained(self) -> bool:
         return True

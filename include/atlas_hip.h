@@ -93,6 +93,13 @@ size_t atlas_scan_topk_workspace_bytes(int64_t N, int B, int d, int k);
 int atlas_scan_topk(const void* q, int q_dtype, const void* slab_f16, int64_t N, int B, int d,
                     int k, float pmax_hint, void* out_score_f16, int64_t* out_idx,
                     int32_t* out_status, void* ws, size_t ws_bytes, void* stream);
+/* Same call with two optional hipEvent_t handles (NULL = skip) recorded on `stream` immediately
+ * before and after the scan kernel of the first 64-query chunk: lets a harness time the dominant
+ * kernel alone, on the stream it actually runs on (bench.py's roofline figure). */
+int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t N, int B, int d,
+                       int k, float pmax_hint, void* out_score_f16, int64_t* out_idx,
+                       int32_t* out_status, void* ws, size_t ws_bytes, void* stream,
+                       void* ev_scan_begin, void* ev_scan_end);
 
 /* ---- search: exact reference-order path (any d, any k <= 2048) --------------------
  * Same contract and same canonical result as atlas_scan_topk, computed without MFMA:

@@ -1,0 +1,259 @@
+"""Parity tests proper (MI355X): the HIP path, called through the C-ABI, against the CPU oracle — bit-exact
+scores and ids — plus the reference golden vectors, edge cases, and size-independent properties at 1M rows."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import parity
+import synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _index(cls, P):
+    idx = cls()
+    idx.init_embeddings([{"id": str(i)} for i in range(P.shape[0])], P.shape[1])
+    idx.embeddings[:, :] = torch.from_numpy(P).cuda().T          # the write atlas.py:79 performs
+    return idx
+
+
+def _search(idx, Q, k):
+    s, i = idx._compute_scores_and_indices(torch.from_numpy(Q).cuda(), k)
+    return s.cpu().numpy(), i.cpu().numpy()
+
+
+def test_single_hip_runtime_in_process(gpu_index_cls):
+    """the extension must bind to the HIP runtime torch loaded (one libamdhip64 in the process)"""
+    from atlas_amd import _lib
+
+    _lib.lib()
+    maps = open("/proc/self/maps").read()
+    libs = {ln.split()[-1] for ln in maps.splitlines() if "libamdhip64" in ln}
+    assert len(libs) == 1, libs
+    assert any("libatlas_hip.so" in ln for ln in maps.splitlines())
+
+
+@pytest.mark.parametrize("N,B,k,ps", [(10000, 64, 40, 11), (3000, 7, 5, 21), (100000, 64, 40, 71), (4097, 1, 1, 72),
+                                     (70000, 33, 128, 73), (512, 64, 256, 74), (130000, 130, 40, 75)])
+def test_scan_bit_exact_vs_oracle(N, B, k, ps, gpu_index_cls, oracle_mod):
+    P = synth.passages_f16(N, 768, ps)
+    Q = synth.queries_f32(B, 768, ps + 1)
+    idx = _index(gpu_index_cls, P)
+    s, i = _search(idx, Q, k)
+    es, ei = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, k)
+    parity.assert_identical(s, i, es, ei, f"N={N} B={B} k={k}")
+    st = idx.last_search_stats
+    assert st["path"] == "scan" and st["fallback_queries"] == 0, st
+    assert st["max_err_over_eps"] < 0.25, st        # measured MFMA error vs the certified bound
+
+
+@pytest.mark.parametrize("case", ["a10k", "b3k", "c_dups", "d_k128"])
+def test_scan_vs_reference_golden(case, gpu_index_cls, oracle_mod):
+    """HIP path vs the outputs of the reference's own DistributedIndex (tie-/1-ulp-aware, see parity.py)."""
+    g = np.load(os.path.join(G, f"{case}.npz"))
+    N, B, dup, k = int(g["N"]), int(g["B"]), int(g["dup"]), int(g["k"])
+    P = synth.passages_f16(N // dup, 768, int(g["ps"]))
+    if dup > 1:
+        P = np.tile(P, (dup, 1))
+    Q = synth.queries_f32(B, 768, int(g["qs"]))
+    assert synth.sha(P, Q) == str(g["sha"])
+    idx = _index(gpu_index_cls, P)
+    s, i = _search(idx, Q, k)
+    es, ei, full = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, k, return_full=True)
+    parity.assert_identical(s, i, es, ei, case)
+    st = parity.compare_with_reference(g["ref_scores"], g["ref_ids"], full, s, i)
+    assert st["max_ulp"] <= 1
+
+
+def test_query_dtypes_match_half_cast(gpu_index_cls, oracle_mod):
+    P = synth.passages_f16(5000, 768, 81)
+    Q = synth.queries_f32(9, 768, 82) * 3.0
+    idx = _index(gpu_index_cls, P)
+    q = torch.from_numpy(Q).cuda()
+    for qq in (q, q.half(), q.bfloat16()):
+        s, i = idx._compute_scores_and_indices(qq, 10)
+        ref_q = qq.half().cpu().numpy()                   # what `.half()` gives (src/index.py:117)
+        es, ei = oracle_mod.search(ref_q, P, 10)
+        parity.assert_identical(s.cpu().numpy(), i.cpu().numpy(), es, ei, str(qq.dtype))
+
+
+def test_mass_ties_take_the_exact_path(gpu_index_cls, oracle_mod):
+    """1000 identical rows straddling the cut: the candidate band overflows, the query is redone exactly;
+    canonical order returns the lowest ids."""
+    P = synth.passages_f16(3000, 768, 83)
+    P[500:1500] = P[7]
+    Q = P[7:8].astype(np.float32) * 30.0                  # the duplicated row is the best match
+    Q = np.concatenate([Q, synth.queries_f32(3, 768, 84)])
+    idx = _index(gpu_index_cls, P)
+    s, i = _search(idx, Q, 40)
+    es, ei = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, 40)
+    parity.assert_identical(s, i, es, ei, "mass ties")
+    assert i[0, 0] == 7 and i[0, 1:40].tolist() == list(range(500, 539))
+    assert idx.last_search_stats["fallback_queries"] >= 1
+
+
+def test_degenerate_slabs(gpu_index_cls, oracle_mod):
+    Q = synth.queries_f32(5, 768, 85)
+    for P in (np.zeros((300, 768), np.float16), -np.abs(synth.passages_f16(300, 768, 86)) * np.sign(Q[0]).astype(np.float16)):
+        idx = _index(gpu_index_cls, P)
+        s, i = _search(idx, Q, 7)
+        es, ei = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, 7)
+        parity.assert_identical(s, i, es, ei, "degenerate")
+    P = synth.passages_f16(17, 768, 87)                    # shard smaller than one tile; k == N
+    idx = _index(gpu_index_cls, P)
+    s, i = _search(idx, Q, 17)
+    es, ei = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, 17)
+    parity.assert_identical(s, i, es, ei, "tiny")
+    with pytest.raises(RuntimeError, match="out of range"):   # torch.topk's contract (index.py:118)
+        _search(idx, Q, 18)
+
+
+def test_large_norm_row_triggers_recertification(gpu_index_cls, oracle_mod):
+    """the scan's error margin is certified with the max row norm; a later, larger row must be noticed"""
+    P = synth.passages_f16(20000, 768, 88)
+    Q = synth.queries_f32(8, 768, 89)
+    idx = _index(gpu_index_cls, P)
+    _search(idx, Q, 10)
+    p_before = idx._pmax
+    big = (synth.passages_f16(1, 768, 90).astype(np.float32) * 50).astype(np.float16)
+    idx.embeddings[:, 12345:12346] = torch.from_numpy(big).cuda().T
+    P[12345] = big[0]
+    s, i = _search(idx, Q, 10)
+    es, ei = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, 10)
+    parity.assert_identical(s, i, es, ei, "after big row")
+    assert idx.last_search_stats["reruns"] == 1 and idx._pmax > 10 * p_before
+
+
+@pytest.mark.parametrize("d,k", [(96, 300), (768, 1000), (1000, 10)])
+def test_exact_path_any_shape(d, k, gpu_index_cls, oracle_mod):
+    P = synth.passages_f16(4000, d, 91)
+    Q = synth.queries_f32(4, d, 92)
+    idx = _index(gpu_index_cls, P)
+    s, i = _search(idx, Q, k)
+    es, ei = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, k)
+    parity.assert_identical(s, i, es, ei, f"exact d={d} k={k}")
+    assert idx.last_search_stats["path"] == "exact"
+
+
+def test_search_knn_returns_reference_types(gpu_index_cls, oracle_mod):
+    P = synth.passages_f16(2000, 768, 93)
+    Q = synth.queries_f32(3, 768, 94)
+    idx = gpu_index_cls()
+    passages = [{"id": str(i), "title": f"t{i}", "text": f"x{i}"} for i in range(2000)]
+    idx.init_embeddings(passages)
+    idx.embeddings[:, :] = torch.from_numpy(P).cuda().T
+    docs, scores = idx.search_knn(torch.from_numpy(Q).cuda(), 6)
+    es, ei = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, 6)
+    assert [[d["id"] for d in row] for row in docs] == [[str(x) for x in row] for row in ei.tolist()]
+    assert docs[0][0] is passages[ei[0, 0]] and isinstance(scores[0][0], float)
+    assert scores == es.astype(np.float32).tolist()
+
+
+def test_pack_merge_kernels_match_host(gpu_index_cls):
+    from atlas_amd import _lib, index as im
+
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    W, B, k = 8, 64, 40
+    s = rng.standard_normal((W, B, k)).astype(np.float16)
+    s[:, 0, :] = s[0, 0, :]                                  # ties across shards
+    rows = rng.integers(0, 4_000_000, (W, B, k)).astype(np.int64)
+    rows[3, 5, 30:] = -1
+    packed_h = np.stack([im.pack_candidates_host(s[w], rows[w], W, w) for w in range(W)])
+    sd, rd = torch.from_numpy(s).cuda(), torch.from_numpy(rows).cuda()
+    packed_d = torch.empty((W, B, k), dtype=torch.int64, device="cuda")
+    for w in range(W):
+        _lib.check(L.atlas_pack_candidates(sd[w].data_ptr(), rd[w].data_ptr(), B * k, W, w, packed_d[w].data_ptr(), None), "pack")
+    torch.cuda.synchronize()
+    assert np.array_equal(packed_d.cpu().numpy(), packed_h)
+    out = torch.empty((B, k), dtype=torch.int64, device="cuda")
+    _lib.check(L.atlas_merge_packed(packed_d.data_ptr(), W, B, k, out.data_ptr(), None), "merge")
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), im.merge_packed_host(packed_h, k))
+
+
+def test_pool_write_matches_oracle(gpu_index_cls, oracle_mod):
+    from atlas_amd import _lib
+
+    L = _lib.lib()
+    n, Lq, d = 37, 50, 768
+    H = (synth.normal_f32(n * Lq, d, 95, 0.7)).astype(np.float16).reshape(n, Lq, d)
+    lens = np.random.default_rng(4).integers(1, Lq + 1, n)
+    mask = (np.arange(Lq)[None, :] < lens[:, None]).astype(np.int64)
+    H[0, lens[0]:, :] = np.float16(np.nan)                   # masked positions must not leak (masked_fill, retrievers.py:50)
+    slab = torch.zeros((100, d), dtype=torch.float16, device="cuda")
+    hd, md = torch.from_numpy(H).cuda(), torch.from_numpy(mask).cuda()
+    _lib.check(L.atlas_pool_write(hd.data_ptr(), md.data_ptr(), slab.data_ptr(), 100, 20, n, Lq, d, None), "pool_write")
+    torch.cuda.synchronize()
+    exp = oracle_mod.pool(H, mask)
+    got = slab.cpu().numpy()
+    assert np.array_equal(got[20:57].view(np.uint16), exp.view(np.uint16))
+    assert not got[:20].any() and not got[57:].any()
+    # and the torch formulation the reference runs (fp16 copy on the GPU) agrees to <= 1 fp16 ulp
+    lh = hd.masked_fill(~md[..., None].bool(), 0.0)
+    ref = (lh.sum(dim=1) / md.sum(dim=1)[..., None]).cpu().numpy()
+    assert np.abs(parity.f16_ordinal(ref) - parity.f16_ordinal(exp)).max() <= 1
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json configs[1] size (1M x 768, 64 queries, top-40): size-independent properties
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def big(gpu_index_cls):
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    N = 1_000_000
+    slab = torch.empty((N, 768), dtype=torch.float16, device="cuda")
+    for r0 in range(0, N, 100_000):
+        x = torch.randn((100_000, 768), generator=g, device="cuda")
+        slab[r0 : r0 + 100_000] = (x / x.norm(dim=1, keepdim=True)).half()
+    q = torch.randn((64, 768), generator=g, device="cuda")
+    idx = gpu_index_cls()
+    idx.init_embeddings([None] * 0)
+    idx._set_slab(slab)
+    idx.doc_map = {}
+    return idx, slab, q
+
+
+def test_1m_scan_equals_exact_path(big):
+    """the MFMA fast path and the MFMA-free exact path are independent implementations of the same result"""
+    idx, slab, q = big
+    s, i = idx._compute_scores_and_indices(q, 40)
+    assert idx.last_search_stats["path"] == "scan" and idx.last_search_stats["fallback_queries"] == 0
+    assert idx.last_search_stats["max_err_over_eps"] < 0.25
+    es, ei = idx._exact_topk(q[:8], 40)
+    assert torch.equal(s[:8], es) and torch.equal(i[:8], ei)
+    # scores really are the rounded inner products of the rows returned (fp64 on device)
+    sub = slab[i[:4].reshape(-1)].double().view(4, 40, 768)
+    dots = torch.einsum("bkd,bd->bk", sub, q[:4].half().double())
+    assert torch.equal(dots.half(), s[:4])
+    assert (s[:, :-1] >= s[:, 1:]).all()
+
+
+def test_1m_sharding_invariance(big, gpu_index_cls):
+    """top-k of 8 round-robin shards, packed + merged, is identical to the single-shard result"""
+    from atlas_amd import index as im
+
+    idx, slab, q = big
+    s, i = idx._compute_scores_and_indices(q, 40)
+    W = 8
+    packed = []
+    for r in range(W):
+        sh = gpu_index_cls()
+        sh._set_slab(slab[r::W].contiguous())
+        ss, ii = sh._compute_scores_and_indices(q, 40)
+        packed.append(im.pack_candidates_host(ss.cpu().numpy(), ii.cpu().numpy(), W, r))
+    merged = idx._merge(torch.from_numpy(np.stack(packed)).cuda(), 40)
+    ms, mg = im.unpack_candidates_host(merged)
+    parity.assert_identical(ms, mg, s.cpu().numpy(), i.cpu().numpy(), "8 shards vs 1")
+
+
+def test_1m_oracle_subset(big, oracle_mod):
+    """4 queries against the CPU oracle at full 1M size"""
+    idx, slab, q = big
+    s, i = idx._compute_scores_and_indices(q[:4], 40)
+    es, ei = oracle_mod.search(q[:4].half().cpu().numpy(), slab.cpu().numpy(), 40)
+    parity.assert_identical(s.cpu().numpy(), i.cpu().numpy(), es, ei, "1M oracle")
