@@ -19,33 +19,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "common.h"
+#include "scan_kernel.h"
 #include "../../include/atlas_hip.h"
 
 using namespace atlas;
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-#define D_FAST 768               // EMBEDDINGS_DIM, src/retrievers.py:13
-#define KSTEPS (D_FAST / 32)     // 24 MFMA k-steps of 32
-#define QCHUNK 64                // queries per slab pass (4 MFMA column groups of 16)
-#define QFRAG_U4 (KSTEPS * 4 * 64)   // uint4 elements of the fragment-ordered query image
 #define K_FAST_MAX 256
 #define K_EXACT_MAX 2048
 #define MERGE_SMAX 2048          // max candidates rescored per query in the merge
 
-static __device__ __forceinline__ float neg_inf() { return bits_f32(0xff800000u); }
-static __device__ __forceinline__ float pos_inf() { return bits_f32(0x7f800000u); }
-
-// raw workgroup barrier that orders LDS only: prefetched global loads stay in flight
-// (a __syncthreads() here would drain vmcnt once per tile; cdna guide §5 "Pipelining across barriers")
-static __device__ __forceinline__ void wg_barrier_lds() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 // ------------------------------------------------------------------------------------------
 // prep: one block per query slot (64 slots; slots >= nq are zero queries with eps 0)
@@ -53,8 +40,18 @@ static __device__ __forceinline__ void wg_barrier_lds() {
 __global__ void __launch_bounds__(256)
 prep_queries_kernel(const void* __restrict__ q, int q_dtype, int q0, int nq, int d, float pmax,
                     uint16_t* __restrict__ qrow /*[64][d]*/, uint16_t* __restrict__ qfrag /*fragment order*/,
-                    float* __restrict__ qeps /*[64]*/) {
+                    float* __restrict__ qeps /*[64]*/, uint32_t* __restrict__ scan_state /*gstat[64] | qflag[64] or null*/,
+                    int32_t* __restrict__ out_status /*or null*/) {
     const int j = blockIdx.x;
+    // also resets the per-call state words (saves two memset dispatches per search)
+    if (scan_state != nullptr) {
+        if (j == 0 && threadIdx.x < 64) scan_state[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) scan_state[64 + j] = 0u;
+    }
+    if (out_status != nullptr) {
+        if (q0 == 0 && j == 0 && threadIdx.x < ATLAS_STATUS_HEADER) out_status[threadIdx.x] = 0;
+        if (j < nq && threadIdx.x == 0) out_status[ATLAS_STATUS_HEADER + q0 + j] = 0;
+    }
     __shared__ double red[256];
     double ss = 0.0;
     for (int k = threadIdx.x; k < d; k += 256) {
@@ -88,302 +85,6 @@ prep_queries_kernel(const void* __restrict__ q, int q_dtype, int q0, int nq, int
 }
 
 // ------------------------------------------------------------------------------------------
-// scan
-// ------------------------------------------------------------------------------------------
-struct ScanParams {
-    const uint16_t* slab;     // [N][768] fp16
-    int64_t N;
-    const uint4* qfrag;       // [24][4][64] uint4
-    const float* qeps;        // [64]
-    uint2* lists;             // [G][64][cap]  {f32 bits of approx score, row}
-    uint32_t* counts;         // [G][64]
-    uint32_t* gstat;          // [0] max row sumsq (float bits, atomicMax)  [1] flags
-    uint32_t* qflag;          // [64] per-query fallback flag (band overflow)
-    int64_t rows_per_wg;
-    int nq, k, cap, keep_max;
-    float pmax2_hint;
-};
-
-struct ScanSmem {   // byte offsets into dynamic LDS
-    static constexpr int q_off = 0;                       // 98304 B
-    static constexpr int theta_off = QFRAG_U4 * 16;       // 64 f32
-    static constexpr int cnt_off = theta_off + 256;       // 64 u32
-    static constexpr int flag_off = cnt_off + 256;        // 64 B (word 0 used)
-    static constexpr int keys_off = flag_off + 64;        // NW * cap u32
-};
-
-template <int NW, int PF, int RING>
-__global__ void __launch_bounds__(NW * 64)
-scan_kernel(const ScanParams p) {
-    // RING slots of PF fragments: RING-1 k-steps of loads in flight while one slot is consumed
-    static_assert(KSTEPS % RING == 0 && RING >= 2, "prefetch ring must divide the k-steps");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint4* s_q = (uint4*)(smem + ScanSmem::q_off);
-    float* s_theta = (float*)(smem + ScanSmem::theta_off);
-    uint32_t* s_cnt = (uint32_t*)(smem + ScanSmem::cnt_off);
-    uint32_t* s_flag = (uint32_t*)(smem + ScanSmem::flag_off);   // plain LDS words; ordered by wg_barrier_lds()
-    uint32_t* s_keys = (uint32_t*)(smem + ScanSmem::keys_off);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lrow = lane & 15, lgrp = lane >> 4;
-    constexpr int TILE = NW * PF * 16;       // rows per workgroup tile
-    constexpr int ROWB = D_FAST * 2;         // bytes per slab row
-    constexpr int RPT = KSTEPS / RING;       // ring revolutions per tile
-
-    for (int i = tid; i < QFRAG_U4; i += NW * 64) s_q[i] = p.qfrag[i];
-    if (tid < 64) {
-        s_theta[tid] = (tid < p.nq) ? neg_inf() : pos_inf();
-        s_cnt[tid] = 0;
-    }
-    if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
-    __syncthreads();
-
-    const int64_t r_begin = (int64_t)blockIdx.x * p.rows_per_wg;
-    int64_t r_end = r_begin + p.rows_per_wg;
-    if (r_end > p.N) r_end = p.N;
-    const int ntiles = (r_end > r_begin) ? (int)((r_end - r_begin + TILE - 1) / TILE) : 0;   // workgroup-uniform
-    uint2* my_lists = p.lists + (size_t)blockIdx.x * 64 * p.cap;
-
-    // Passage rows stream HBM -> VGPR through buffer loads (cdna guide T8). ONE descriptor per
-    // wave spans [first row of this wave's first tile, N). The hardware bounds check covers
-    // voffset + immediate only (not soffset), so everything that selects a ROW lives in the
-    // per-lane voffset (one VGPR per fragment, bumped once per tile) and rows at or past N read
-    // as zero; the k-step (< one row) rides in the scalar offset. No address VALU in the k-loop.
-    //   lane l loads row (l & 15) of fragment pf, bytes [64*s + 16*(l>>4), +16)   (MFMA A operand)
-    const int64_t wrow0 = r_begin + (int64_t)wave * PF * 16;
-    int64_t span = (wrow0 < p.N) ? (p.N - wrow0) * (int64_t)ROWB : 0;
-    if (span > 0xfffffff0ll) span = 0xfffffff0ll;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const unsigned char*)p.slab + (span > 0 ? wrow0 : 0) * (int64_t)ROWB), 0, (int)span, 0x00020000);
-
-    // fill cursor: (rows of the tile being fetched -> vo[], k-step -> fill_step); it runs RING-1
-    // steps ahead of the consumer. Past the last tile it keeps walking forward: those loads hit
-    // rows of the next workgroup's range (harmless) or fall out of bounds (return 0).
-    unsigned vo[PF];
-#pragma unroll
-    for (int pf = 0; pf < PF; ++pf) vo[pf] = (unsigned)((pf * 16 + lrow) * ROWB + lgrp * 16);
-    int fill_step = 0;
-    auto fill_advance = [&]() {
-        ++fill_step;
-        if (fill_step == KSTEPS) {          // scalar condition: next tile of this wave
-            fill_step = 0;
-#pragma unroll
-            for (int pf = 0; pf < PF; ++pf) vo[pf] += (unsigned)(TILE * ROWB);
-        }
-    };
-
-    u32x4 abuf[RING][PF];
-#pragma unroll
-    for (int s = 0; s < RING - 1; ++s) {
-#pragma unroll
-        for (int pf = 0; pf < PF; ++pf)
-            abuf[s][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)vo[pf], fill_step * 64, 0);
-        fill_advance();
-        // keep issue order == ring order: hipcc's waitcnt for slot 0 is the minimum over the loop
-        // entry and the back edge, so a shuffled prologue would cost ring depth on every revolution
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
-    f32x4 acc[PF][4];
-#pragma unroll
-    for (int pf = 0; pf < PF; ++pf)
-#pragma unroll
-        for (int qf = 0; qf < 4; ++qf) acc[pf][qf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float nrm[PF];
-#pragma unroll
-    for (int pf = 0; pf < PF; ++pf) nrm[pf] = 0.f;
-    float pm = 0.0f;   // running max of row sum-of-squares seen by this lane's row group
-
-    // rows relative to r_begin fit 32 bits (plan guarantees rows_per_wg * 1536 < 2^32)
-    const int nrows = (int)(r_end > r_begin ? r_end - r_begin : 0);
-    const uint32_t gbase = (uint32_t)r_begin;          // shard-local row ids are < 2^32
-    int row0 = wave * PF * 16;   // first row (relative) of this wave's current tile
-    int par = 0;               // tile parity (double-buffers the compaction-request flag)
-    int cstep = 0;             // consumer k-step inside the tile
-
-    // One flat loop over ring revolutions of all tiles: the ring rotation is the same every
-    // iteration (no register shuffling at tile boundaries), and the per-tile work (filter,
-    // barrier) hangs off every RPT-th revolution.
-#pragma unroll 1
-    for (int rev = 0; rev < ntiles * RPT; ++rev) {
-        const uint4* bq = s_q + lane + cstep * (4 * 64);
-#pragma unroll
-        for (int j = 0; j < RING; ++j) {
-            // refill the slot freed by the previous step first (its loads stay in flight for
-            // RING-1 steps), then consume slot j. sched_barrier pins that order: left alone,
-            // hipcc sinks the loads to the loop end and waits vmcnt(0) at the top.
-            const int fill = (j + RING - 1) % RING;
-#pragma unroll
-            for (int pf = 0; pf < PF; ++pf)
-                abuf[fill][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)vo[pf], fill_step * 64, 0);
-            fill_advance();
-            __builtin_amdgcn_sched_barrier(0);
-            uint4 b[4];
-#pragma unroll
-            for (int qf = 0; qf < 4; ++qf) b[qf] = bq[(j * 4 + qf) * 64];
-#pragma unroll
-            for (int pf = 0; pf < PF; ++pf) {
-                const u32x4 a = abuf[j][pf];
-                const f16x8 av = __builtin_bit_cast(f16x8, a);
-#pragma unroll
-                for (int qf = 0; qf < 4; ++qf)
-                    acc[pf][qf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                        av, __builtin_bit_cast(f16x8, b[qf]), acc[pf][qf], 0, 0, 0);
-                // row sum of squares (certifies pmax_hint): 4 x v_dot2_f32_f16
-                // (element copies first: __builtin_bit_cast straight on an ext-vector element
-                //  reads element 0 for every swizzle on ROCm 7.2's clang)
-                const unsigned ax = a.x, ay = a.y, az = a.z, aw = a.w;
-                const f16x2 h0 = __builtin_bit_cast(f16x2, ax), h1 = __builtin_bit_cast(f16x2, ay);
-                const f16x2 h2 = __builtin_bit_cast(f16x2, az), h3 = __builtin_bit_cast(f16x2, aw);
-                nrm[pf] = __builtin_amdgcn_fdot2(h0, h0, nrm[pf], false);
-                nrm[pf] = __builtin_amdgcn_fdot2(h1, h1, nrm[pf], false);
-                nrm[pf] = __builtin_amdgcn_fdot2(h2, h2, nrm[pf], false);
-                nrm[pf] = __builtin_amdgcn_fdot2(h3, h3, nrm[pf], false);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        cstep += RING;
-        if (cstep < KSTEPS) continue;
-
-        // ------------------------- end of a tile: filter --------------------------------
-        cstep = 0;
-        if (row0 < nrows) {        // wave-uniform
-            // full row norms: the 4 lanes {l, l+16, l+32, l+48} hold the 4 k-groups of row l&15
-#pragma unroll
-            for (int pf = 0; pf < PF; ++pf) {
-                float x = nrm[pf];
-                x += __shfl_xor(x, 16);
-                x += __shfl_xor(x, 32);
-                pm = fmaxf(pm, x);
-            }
-            // rows past the end of this workgroup's range never become candidates
-            if (row0 + PF * 16 > nrows) {
-#pragma unroll
-                for (int pf = 0; pf < PF; ++pf)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (row0 + pf * 16 + lgrp * 4 + r >= nrows) {
-#pragma unroll
-                            for (int qf = 0; qf < 4; ++qf) acc[pf][qf][r] = neg_inf();
-                        }
-            }
-            // threshold filter: lane l owns query 16*qf + (l&15) in acc[.][qf]
-            float th[4];
-#pragma unroll
-            for (int qf = 0; qf < 4; ++qf) th[qf] = s_theta[qf * 16 + lrow];
-            bool any = false;
-#pragma unroll
-            for (int pf = 0; pf < PF; ++pf)
-#pragma unroll
-                for (int qf = 0; qf < 4; ++qf)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) any |= acc[pf][qf][r] > th[qf];
-            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-                // rare path: append candidates to the workgroup's per-query lists
-                const uint32_t rbase = gbase + (uint32_t)row0 + (uint32_t)lgrp * 4u;
-#pragma unroll
-                for (int pf = 0; pf < PF; ++pf)
-#pragma unroll
-                    for (int qf = 0; qf < 4; ++qf)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float v = acc[pf][qf][r];
-                            if (v > th[qf]) {
-                                const int qq = qf * 16 + lrow;
-                                const uint32_t slot = atomicAdd(&s_cnt[qq], 1u);
-                                if (slot < (uint32_t)p.cap)
-                                    my_lists[(uint32_t)(qq * p.cap) + slot] =
-                                        make_uint2(f32_bits(v), rbase + (uint32_t)(pf * 16 + r));
-                                if (slot >= (uint32_t)p.keep_max) s_flag[par] = 1u;
-                            }
-                        }
-                // Drain the list stores here, with the builtin (hipcc's waitcnt pass sees it, unlike
-                // inline asm): gfx9 counts stores and loads in one vmcnt and assumes they retire out
-                // of order, so a store left pending on this rare path would force vmcnt(0) in front
-                // of every ring slot of the hot loop.
-                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt/lgkmcnt untouched
-            }
-        }
-#pragma unroll
-        for (int pf = 0; pf < PF; ++pf) {
-            nrm[pf] = 0.f;
-#pragma unroll
-            for (int qf = 0; qf < 4; ++qf) acc[pf][qf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-
-        wg_barrier_lds();
-        if (s_flag[par] != 0u) {
-            // compaction: some list crossed keep_max. Every wave has drained its list stores
-            // (above); each wave compacts the queries it owns (lists are private to this CU).
-            wg_barrier_lds();
-            if (tid == 0) s_flag[par] = 0u;
-            for (int qq = wave; qq < p.nq; qq += NW) {
-                const uint32_t n = s_cnt[qq];
-                if (n <= (uint32_t)p.k) continue;                 // nothing can be pruned yet
-                uint2* L = my_lists + (size_t)qq * p.cap;
-                uint32_t* K = s_keys + wave * p.cap;
-                for (uint32_t i = lane; i < n; i += 64) K[i] = f32_order_key(bits_f32(L[i].x));
-                // k-th largest key: greedy bit search (largest v with count(keys >= v) >= k)
-                uint32_t prefix = 0;
-                for (int bit = 31; bit >= 0; --bit) {
-                    const uint32_t cand = prefix | (1u << bit);
-                    uint32_t c = 0;
-                    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-                        const uint32_t i = i0 + lane;
-                        const bool ge = (i < n) && (K[i] >= cand);
-                        c += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ge));
-                    }
-                    if (c >= (uint32_t)p.k) prefix = cand;
-                }
-                const float T = f32_from_order_key(prefix);
-                const float theta = prune_threshold(T, p.qeps[qq]);
-                // in-place stable compaction of entries with score > theta
-                uint32_t kept = 0;
-                for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-                    const uint32_t i = i0 + lane;
-                    uint2 e = make_uint2(0, 0);
-                    bool keep = false;
-                    if (i < n) { e = L[i]; keep = bits_f32(e.x) > theta; }
-                    const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
-                    const uint32_t pos = kept + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (keep) L[pos] = e;
-                    kept += (uint32_t)__popcll(m);
-                }
-                if (lane == 0) {
-                    if (kept > (uint32_t)p.keep_max) {
-                        // candidate band wider than the list (mass ties): hand this query to
-                        // the exact path and stop collecting for it
-                        p.qflag[qq] = 1u;
-                        s_cnt[qq] = 0;
-                        s_theta[qq] = pos_inf();
-                    } else {
-                        s_cnt[qq] = kept;
-                        s_theta[qq] = theta;
-                    }
-                }
-            }
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            wg_barrier_lds();
-        }
-        row0 += TILE;
-        par ^= 1;
-    }
-
-    __syncthreads();
-    if (tid < 64) p.counts[(size_t)blockIdx.x * 64 + tid] = (tid < p.nq) ? s_cnt[tid] : 0u;
-    // publish the largest row norm^2 seen (x1.001: v_dot2 accumulates in fp32)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) pm = fmaxf(pm, __shfl_xor(pm, o));
-    if (lane == 0 && pm > 0.f) {
-        pm *= 1.001f;
-        atomicMax(&p.gstat[0], f32_bits(pm));
-        if (pm > p.pmax2_hint) atomicOr(&p.gstat[1], (uint32_t)ATLAS_F_PMAX_VIOLATION);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // merge + exact rescoring: one block per query
 // ------------------------------------------------------------------------------------------
 struct MergeParams {
@@ -393,6 +94,7 @@ struct MergeParams {
     const uint2* lists; const uint32_t* counts; int G; int cap;
     const uint32_t* gstat; const uint32_t* qflag;
     int k, q0;                   // q0: first query of this chunk (output row offset)
+    int key_cap;                 // approximate-score keys that fit in LDS
     uint16_t* out_score; int64_t* out_idx; int32_t* out_status;
 };
 
@@ -436,18 +138,23 @@ static __device__ __forceinline__ double exact_dot_dev(const uint16_t* __restric
     return ((c0 + c1) + (c2 + c3)) + ((c4 + c5) + (c6 + c7));
 }
 
+// one block per query. Steps: (1) gather the approximate-score keys of every workgroup's list into
+// LDS; (2) k-th largest by a greedy bit search that starts at the first bit where the keys differ and
+// stops 2^-15 (relative) short of exact -- any lower bound of the k-th is a valid T; (3) candidate band
+// s~ > prune_threshold(T); (4) exact rescoring in the canonical order; (5) rank by counting.
 template <int NT>
 __global__ void __launch_bounds__(NT)
 merge_rescore_kernel(const MergeParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // layout: qs[d] u16 (padded to 16 B) | hist[256] | misc[8] | s_row[SMAX] u32 | s_app[SMAX] f32 | s_key[SMAX] u64
+    // layout: qs[d] u16 (padded to 16 B) | misc[16] | s_off[1025] (padded) | s_row[SMAX] | s_app[SMAX] | s_key[SMAX] u64 | keys[key_cap]
     uint16_t* qs = (uint16_t*)smem;
     const int qbytes = ((p.d * 2 + 15) / 16) * 16;
-    uint32_t* hist = (uint32_t*)(smem + qbytes);
-    uint32_t* misc = hist + 256;            // [0] prefix [1] remaining k [2] nsurv [3] total [4] maxerr bits [5] flags
-    uint32_t* s_row = misc + 8;
+    uint32_t* misc = (uint32_t*)(smem + qbytes);   // [0] count [1] kmax [2] kmin [3] total [4] maxerr bits [5] nsurv
+    uint32_t* s_off = misc + 16;                   // exclusive prefix of list lengths, G+1 entries (G <= 1024)
+    uint32_t* s_row = s_off + 1040;
     float* s_app = (float*)(s_row + MERGE_SMAX);
     uint64_t* s_key = (uint64_t*)(s_app + MERGE_SMAX);
+    uint32_t* keys = (uint32_t*)(s_key + MERGE_SMAX);
 
     const int q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -457,80 +164,90 @@ merge_rescore_kernel(const MergeParams p) {
     int64_t* o_idx = p.out_idx + (size_t)(p.q0 + q) * k;
     int32_t* o_qst = p.out_status + ATLAS_STATUS_HEADER + p.q0 + q;
 
-    if (p.qflag[q] != 0u) {   // scan overflowed this query's band -> exact path will fill the row
+    auto fallback = [&]() {
         if (tid == 0) {
             *o_qst = ATLAS_Q_FALLBACK;
             atomicOr((uint32_t*)&p.out_status[ATLAS_ST_FLAGS], (uint32_t)ATLAS_F_FALLBACK);
             atomicAdd((uint32_t*)&p.out_status[ATLAS_ST_N_FALLBACK], 1u);
         }
-        return;
-    }
-    for (int i = tid; i < p.d; i += NT) qs[i] = p.qrow[(size_t)q * p.d + i];
-    if (tid < 8) misc[tid] = 0;
-    if (tid == 1) misc[1] = (uint32_t)k;
-    __syncthreads();
+    };
+    if (p.qflag[q] != 0u) { fallback(); return; }   // the scan overflowed this query's band
 
-    // ---- k-th largest approximate score over all lists: 4 x 8-bit radix passes ----
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        for (int i = tid; i < 256; i += NT) hist[i] = 0;
-        __syncthreads();
-        const uint32_t prefix = misc[0];
-        uint32_t local_total = 0;
-        for (int w = wave; w < p.G; w += NWV) {
-            const uint32_t n = p.counts[(size_t)w * 64 + q];
-            const uint2* L = p.lists + ((size_t)w * 64 + q) * p.cap;
-            for (uint32_t i = lane; i < n; i += 64) {
-                const uint32_t key = f32_order_key(bits_f32(L[i].x));
-                if (pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8)))
-                    atomicAdd(&hist[(key >> shift) & 255u], 1u);
-            }
-            local_total += n;
-        }
-        if (pass == 0 && lane == 0) atomicAdd(&misc[3], local_total);
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t rem = misc[1], b = 255, acc = 0;
-            // from the top bin down: first bin where the cumulative count reaches rem
-            for (int bi = 255; bi >= 0; --bi) {
-                if (acc + hist[bi] >= rem) { b = (uint32_t)bi; break; }
-                acc += hist[bi];
-                if (bi == 0) b = 0;
-            }
-            misc[1] = rem - acc;          // rank inside the chosen bin
-            misc[0] = prefix | (b << shift);
-        }
-        __syncthreads();
+    for (int i = tid; i < p.d; i += NT) qs[i] = p.qrow[(size_t)q * p.d + i];
+    if (tid < 16) misc[tid] = (tid == 2) ? 0xffffffffu : 0u;
+    // exclusive scan of the list lengths (G <= 1024)
+    for (int i = tid; i <= p.G; i += NT) s_off[i] = (i < p.G) ? p.counts[(size_t)i * 64 + q] : 0u;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i <= p.G; ++i) { const uint32_t c = s_off[i]; s_off[i] = run; run += c; }
     }
-    const uint32_t total = misc[3];
+    __syncthreads();
+    const uint32_t total = s_off[p.G];
+    if (total > (uint32_t)p.key_cap) { fallback(); return; }   // TODO(perf): stream from L2 instead
+    // (1) keys -> LDS, with min / max
+    uint32_t kmax = 0, kmin = 0xffffffffu;
+    for (int w = wave; w < p.G; w += NWV) {
+        const uint32_t base = s_off[w], n = s_off[w + 1] - base;
+        const uint2* L = p.lists + ((size_t)w * 64 + q) * p.cap;
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint32_t key = f32_order_key(bits_f32(L[i].x));
+            keys[base + i] = key;
+            kmax = key > kmax ? key : kmax;
+            kmin = key < kmin ? key : kmin;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = __shfl_xor(kmax, o), b = __shfl_xor(kmin, o);
+        kmax = a > kmax ? a : kmax;
+        kmin = b < kmin ? b : kmin;
+    }
+    if (lane == 0) { atomicMax(&misc[1], kmax); atomicMin(&misc[2], kmin); }
+    __syncthreads();
     float theta = neg_inf();
     const float eps = p.qeps[q];
-    if (total >= (uint32_t)k) theta = prune_threshold(f32_from_order_key(misc[0]), eps);
-
-    // ---- collect the candidate band ----
+    if (total >= (uint32_t)k) {
+        // (2) greedy bit search below the common prefix of all keys
+        kmax = misc[1]; kmin = misc[2];
+        const uint32_t diff = kmax ^ kmin;
+        const int top = diff ? 31 - __builtin_clz(diff) : -1;        // highest differing bit
+        uint32_t prefix = (top >= 31) ? 0u : (kmax & ~((2u << top) - 1u));   // common leading bits
+        if (top < 0) prefix = kmax;
+        const int stop = top - 22 > 0 ? top - 22 : 0;
+        for (int bit = top; bit >= stop; --bit) {
+            const uint32_t cand = prefix | (1u << bit);
+            __syncthreads();
+            if (tid == 0) misc[0] = 0;
+            __syncthreads();
+            uint32_t c = 0;
+            for (uint32_t i = tid; i < total; i += NT) c += (keys[i] >= cand) ? 1u : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+            if (lane == 0 && c) atomicAdd(&misc[0], c);
+            __syncthreads();
+            if (misc[0] >= (uint32_t)k) prefix = cand;
+        }
+        theta = prune_threshold(f32_from_order_key(prefix), eps);
+    }
+    __syncthreads();
+    // (3) candidate band
     for (int w = wave; w < p.G; w += NWV) {
-        const uint32_t n = p.counts[(size_t)w * 64 + q];
+        const uint32_t n = s_off[w + 1] - s_off[w];
         const uint2* L = p.lists + ((size_t)w * 64 + q) * p.cap;
         for (uint32_t i = lane; i < n; i += 64) {
             const uint2 e = L[i];
             if (bits_f32(e.x) > theta) {
-                const uint32_t s = atomicAdd(&misc[2], 1u);
+                const uint32_t s = atomicAdd(&misc[5], 1u);
                 if (s < MERGE_SMAX) { s_row[s] = e.y; s_app[s] = bits_f32(e.x); }
             }
         }
     }
     __syncthreads();
-    const uint32_t nsurv = misc[2];
-    if (nsurv > MERGE_SMAX) {
-        if (tid == 0) {
-            *o_qst = ATLAS_Q_FALLBACK;
-            atomicOr((uint32_t*)&p.out_status[ATLAS_ST_FLAGS], (uint32_t)ATLAS_F_FALLBACK);
-            atomicAdd((uint32_t*)&p.out_status[ATLAS_ST_N_FALLBACK], 1u);
-        }
-        return;
-    }
+    const uint32_t nsurv = misc[5];
+    if (nsurv > MERGE_SMAX) { fallback(); return; }
 
-    // ---- exact rescoring in the canonical order, canonical keys ----
+    // (4) exact rescoring in the canonical order, canonical keys
     for (uint32_t i = tid; i < nsurv; i += NT) {
         const uint32_t row = s_row[i];
         const double s = exact_dot_dev(qs, p.slab + (size_t)row * p.d, p.d);
@@ -542,7 +259,7 @@ merge_rescore_kernel(const MergeParams p) {
         atomicMax(&misc[4], f32_bits(ratio));
     }
     __syncthreads();
-    // rank by counting (keys are unique: the row is part of the key)
+    // (5) rank by counting (keys are unique: the row is part of the key)
     for (uint32_t i = tid; i < nsurv; i += NT) {
         const uint64_t ki = s_key[i];
         uint32_t pos = 0;
@@ -724,7 +441,7 @@ slab_pmax_kernel(const uint16_t* __restrict__ slab, int64_t N, int d, uint32_t* 
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         best = fmaxf(best, s);
     }
-    if (lane == 0 && best > 0.f) atomicMax(out_bits, f32_bits(sqrtf(best) * 1.00001f));
+    if (lane == 0 && best > 0.f) atomicMax(out_bits, f32_bits(sqrtf(best * 1.002f)));   // >= what the scan will measure
 }
 
 // ==========================================================================================
@@ -732,16 +449,34 @@ slab_pmax_kernel(const uint16_t* __restrict__ slab, int64_t N, int d, uint32_t* 
 // ==========================================================================================
 namespace {
 
-constexpr int SCAN_NW = 8, SCAN_PF = 4, SCAN_RING = 4;
-constexpr int SCAN_TILE = SCAN_NW * SCAN_PF * 16;
-
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// scan_kernel instantiations selectable at run time (tuning: ATLAS_SCAN_VARIANT=<index>)
+struct ScanVariant { int nw, pf, ring; void (*kern)(const ScanParams); const char* name; };
+const ScanVariant kVariants[] = {
+    {16, 1, 8, scan_kernel<16, 1, 8>, "scan_kernel<16,1,8>"},
+    {8, 2, 8, scan_kernel<8, 2, 8>, "scan_kernel<8,2,8>"},
+    {8, 4, 4, scan_kernel<8, 4, 4>, "scan_kernel<8,4,4>"},
+    {16, 2, 4, scan_kernel<16, 2, 4>, "scan_kernel<16,2,4>"},
+    {12, 2, 4, scan_kernel<12, 2, 4>, "scan_kernel<12,2,4>"},
+};
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+int scan_variant_index() {
+    const char* e = getenv("ATLAS_SCAN_VARIANT");
+    int v = e ? atoi(e) : 0;
+    return (v >= 0 && v < kNumVariants) ? v : 0;
+}
+
+constexpr int MERGE_NT = 1024;
+constexpr int SAMPLE_MAX = 16384;
 
 struct ScanPlan {
     int G;               // workgroups
     int64_t rows_per_wg;
-    int keep_max, cap;
-    size_t off_qfrag, off_qrow, off_qeps, off_counts, off_gstat, off_qflag, off_lists, total;
+    int keep_max, cap, tile, buf_cap;
+    int S; int64_t sample_stride;     // sample pre-pass: S rows (0 = none), tile j starts at j*sample_stride
+    int key_cap;
+    size_t off_qfrag, off_qrow, off_qeps, off_theta0, off_counts, off_gstat, off_qflag, off_sample, off_lists, total;
     size_t scan_lds, merge_lds;
 };
 
@@ -755,29 +490,45 @@ int device_cus() {
     return cus;
 }
 
-ScanPlan make_plan(int64_t N, int d, int k, int cus) {
+ScanPlan make_plan(int64_t N, int d, int k, int cus, const ScanVariant& v) {
     ScanPlan pl{};
     // one workgroup per CU (the 96 KB query image allows exactly one resident workgroup);
     // every workgroup gets a contiguous, 16-row aligned range of equal size
-    int64_t frags = (N + 15) / 16;
+    const int64_t frags = (N + 15) / 16;
     int64_t G = cus;
-    if (G > (frags + SCAN_NW - 1) / SCAN_NW) G = (frags + SCAN_NW - 1) / SCAN_NW;
+    if (G > (frags + v.nw - 1) / v.nw) G = (frags + v.nw - 1) / v.nw;
     if (G < 1) G = 1;
+    if (G > 1024) G = 1024;
     pl.G = (int)G;
     pl.rows_per_wg = ((frags + G - 1) / G) * 16;
+    pl.tile = v.nw * v.pf * 16;
     pl.keep_max = (2 * k > k + 64) ? 2 * k : k + 64;
-    pl.cap = pl.keep_max + SCAN_TILE;
+    pl.buf_cap = 4096;                                   // 32 KB of LDS
+    pl.cap = pl.keep_max + pl.buf_cap + pl.tile;         // a flush can land in one list
+    // sample pre-pass: ~N/64 rows in tiles of 64, spread evenly (distinct rows: stride >= 256)
+    pl.S = 0; pl.sample_stride = 0;
+    if (N >= 65536) {
+        int64_t S = (N / 64 + 63) / 64 * 64;
+        if (S < 4096) S = 4096;
+        if (S > SAMPLE_MAX) S = SAMPLE_MAX;
+        pl.S = (int)S;
+        pl.sample_stride = (N / (S / 64)) & ~(int64_t)15;
+    }
     size_t o = 0;
     pl.off_qfrag = o;  o += (size_t)QFRAG_U4 * 16;
     pl.off_qrow = o;   o += align_up((size_t)QCHUNK * d * 2, 256);
     pl.off_qeps = o;   o += 256;
+    pl.off_theta0 = o; o += 256;
     pl.off_gstat = o;  o += 256;
     pl.off_qflag = o;  o += 256;
     pl.off_counts = o; o += align_up((size_t)pl.G * 64 * 4, 256);
+    pl.off_sample = o; o += (size_t)QCHUNK * SAMPLE_MAX * 4;
     pl.off_lists = o;  o += (size_t)pl.G * 64 * pl.cap * 8;
     pl.total = align_up(o, 256);
-    pl.scan_lds = (size_t)ScanSmem::keys_off + (size_t)SCAN_NW * pl.cap * 4;
-    pl.merge_lds = align_up((size_t)d * 2, 16) + 256 * 4 + 8 * 4 + (size_t)MERGE_SMAX * (4 + 4 + 8);
+    pl.scan_lds = (size_t)ScanSmem::buf_off + (size_t)pl.buf_cap * 8;
+    const size_t merge_fixed = align_up((size_t)d * 2, 16) + 16 * 4 + 1040 * 4 + (size_t)MERGE_SMAX * (4 + 4 + 8);
+    pl.key_cap = (int)((160 * 1024 - 1024 - merge_fixed) / 4);
+    pl.merge_lds = merge_fixed + (size_t)pl.key_cap * 4;
     return pl;
 }
 
@@ -805,12 +556,21 @@ void allow_lds(KernelT kern) {   // opt in to the full 160 KiB of LDS (idempoten
 extern "C" {
 
 int atlas_abi_version(void) { return ATLAS_ABI_VERSION; }
-const char* atlas_build_info(void) { return "atlas_hip gfx950 scan(NW=8,PF=4,RING=4) " __DATE__ " " __TIME__; }
+const char* atlas_build_info(void) {
+    static char buf[160];
+    snprintf(buf, sizeof(buf), "atlas_hip gfx950 %s " __DATE__ " " __TIME__, kVariants[scan_variant_index()].name);
+    return buf;
+}
 
 size_t atlas_scan_topk_workspace_bytes(int64_t N, int B, int d, int k) {
     (void)B;
     if (N < 0 || d <= 0 || k <= 0) return 0;
-    return make_plan(N, d, k, device_cus()).total;
+    size_t mx = 0;     // the variant is a run-time choice: size for the largest
+    for (int v = 0; v < kNumVariants; ++v) {
+        const size_t t = make_plan(N, d, k, device_cus(), kVariants[v]).total;
+        mx = t > mx ? t : mx;
+    }
+    return mx;
 }
 
 int atlas_scan_topk(const void* q, int q_dtype, const void* slab_f16, int64_t N, int B, int d, int k,
@@ -826,45 +586,58 @@ int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t
     if (!q || (!slab_f16 && N > 0) || !out_score_f16 || !out_idx || !out_status || !ws) return ATLAS_E_BADARG;
     if (B <= 0 || k <= 0 || N < 0 || q_dtype < 0 || q_dtype > 2 || !(pmax_hint >= 0.f)) return ATLAS_E_BADARG;
     if (d != D_FAST || k > K_FAST_MAX || N >= (int64_t)0xffffffffll) return ATLAS_E_UNSUPPORTED;
-    const ScanPlan pl = make_plan(N, d, k, device_cus());
+    const ScanVariant& var = kVariants[scan_variant_index()];
+    const ScanPlan pl = make_plan(N, d, k, device_cus(), var);
     // per-lane byte offsets inside one workgroup's range are 32-bit (buffer voffset)
-    if ((pl.rows_per_wg + 2 * SCAN_TILE) * (int64_t)(D_FAST * 2) >= (int64_t)0xfff00000ll) return ATLAS_E_UNSUPPORTED;
+    if ((pl.rows_per_wg + 2 * pl.tile) * (int64_t)(D_FAST * 2) >= (int64_t)0xfff00000ll) return ATLAS_E_UNSUPPORTED;
+    if (pl.rows_per_wg + 2 * pl.tile >= (1 << 26)) return ATLAS_E_UNSUPPORTED;   // buffer entries carry 26-bit rows
     if (ws_bytes < pl.total) return ATLAS_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     unsigned char* w = (unsigned char*)ws;
 
-    auto scan = scan_kernel<SCAN_NW, SCAN_PF, SCAN_RING>;
-    auto merge = merge_rescore_kernel<512>;
-    allow_lds(scan);
+    auto merge = merge_rescore_kernel<MERGE_NT>;
+    allow_lds(var.kern);
     allow_lds(merge);
+    allow_lds(sample_scores_kernel);
 
-    hipError_t e = hipMemsetAsync(out_status, 0, sizeof(int32_t) * (ATLAS_STATUS_HEADER + (size_t)B), stream);
-    if (e != hipSuccess) return (int)e;
-
+    hipError_t e = hipSuccess;
     for (int q0 = 0; q0 < B; q0 += QCHUNK) {
         const int nq = (B - q0 < QCHUNK) ? (B - q0) : QCHUNK;
-        e = hipMemsetAsync(w + pl.off_gstat, 0, 512, stream);          // gstat + qflag
-        if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(prep_queries_kernel, dim3(QCHUNK), dim3(256), 0, stream, q, q_dtype, q0, nq, d,
                            pmax_hint, (uint16_t*)(w + pl.off_qrow), (uint16_t*)(w + pl.off_qfrag),
-                           (float*)(w + pl.off_qeps));
+                           (float*)(w + pl.off_qeps), (uint32_t*)(w + pl.off_gstat), out_status);
+        // initial thresholds: certified k-th of an evenly spread sample, or -inf
+        if (pl.S > 0) {
+            SampleParams sm{};
+            sm.slab = (const uint16_t*)slab_f16; sm.N = N; sm.qfrag = (const uint4*)(w + pl.off_qfrag);
+            sm.scores = (float*)(w + pl.off_sample); sm.S = pl.S; sm.stride_rows = pl.sample_stride;
+            hipLaunchKernelGGL(sample_scores_kernel, dim3(pl.S / 64), dim3(256), (size_t)QFRAG_U4 * 16, stream, sm);
+            hipLaunchKernelGGL(sample_theta_kernel, dim3(QCHUNK), dim3(1024), (size_t)pl.S * 4, stream,
+                               (const float*)(w + pl.off_sample), pl.S, k, (const float*)(w + pl.off_qeps), nq,
+                               (float*)(w + pl.off_theta0));
+        } else {
+            e = hipMemsetD32Async((hipDeviceptr_t)(w + pl.off_theta0), (int)0xff800000u, 64, stream);   // -inf
+            if (e != hipSuccess) return (int)e;
+        }
         ScanParams sp{};
         sp.slab = (const uint16_t*)slab_f16; sp.N = N;
         sp.qfrag = (const uint4*)(w + pl.off_qfrag); sp.qeps = (const float*)(w + pl.off_qeps);
+        sp.theta0 = (const float*)(w + pl.off_theta0);
         sp.lists = (uint2*)(w + pl.off_lists); sp.counts = (uint32_t*)(w + pl.off_counts);
         sp.gstat = (uint32_t*)(w + pl.off_gstat); sp.qflag = (uint32_t*)(w + pl.off_qflag);
         sp.rows_per_wg = pl.rows_per_wg; sp.nq = nq; sp.k = k; sp.cap = pl.cap; sp.keep_max = pl.keep_max;
+        sp.buf_cap = pl.buf_cap;
         sp.pmax2_hint = pmax_hint * pmax_hint;
         if (q0 == 0 && ev_scan_begin) (void)hipEventRecord((hipEvent_t)ev_scan_begin, stream);
-        hipLaunchKernelGGL(scan, dim3(pl.G), dim3(SCAN_NW * 64), pl.scan_lds, stream, sp);
+        hipLaunchKernelGGL(var.kern, dim3(pl.G), dim3(var.nw * 64), pl.scan_lds, stream, sp);
         if (q0 == 0 && ev_scan_end) (void)hipEventRecord((hipEvent_t)ev_scan_end, stream);
         MergeParams mp{};
         mp.slab = (const uint16_t*)slab_f16; mp.N = N; mp.d = d;
         mp.qrow = (const uint16_t*)(w + pl.off_qrow); mp.qeps = sp.qeps;
         mp.lists = sp.lists; mp.counts = sp.counts; mp.G = pl.G; mp.cap = pl.cap;
-        mp.gstat = sp.gstat; mp.qflag = sp.qflag; mp.k = k; mp.q0 = q0;
+        mp.gstat = sp.gstat; mp.qflag = sp.qflag; mp.k = k; mp.q0 = q0; mp.key_cap = pl.key_cap;
         mp.out_score = (uint16_t*)out_score_f16; mp.out_idx = out_idx; mp.out_status = out_status;
-        hipLaunchKernelGGL(merge, dim3(nq), dim3(512), pl.merge_lds, stream, mp);
+        hipLaunchKernelGGL(merge, dim3(nq), dim3(MERGE_NT), pl.merge_lds, stream, mp);
     }
     return (int)hipGetLastError();
 }
@@ -892,7 +665,8 @@ int atlas_exact_topk(const void* q, int q_dtype, const void* slab_f16, int64_t N
         const int nq = (B - q0 < QCHUNK) ? (B - q0) : QCHUNK;
         // prep reuses the fast path's converter (no fragment image: qfrag == nullptr)
         hipLaunchKernelGGL(prep_queries_kernel, dim3(QCHUNK), dim3(256), 0, stream, q, q_dtype, q0, nq, d, 0.f,
-                           (uint16_t*)(w + pl.off_qrow), (uint16_t*)nullptr, (float*)(w + pl.off_qeps));
+                           (uint16_t*)(w + pl.off_qrow), (uint16_t*)nullptr, (float*)(w + pl.off_qeps),
+                           (uint32_t*)nullptr, (int32_t*)nullptr);
         for (int j = 0; j < nq; ++j) {
             hipError_t e = hipMemsetAsync(w + pl.off_hists, 0, 8 * 256 * 4 + 256, stream);   // hists + nsel
             if (e != hipSuccess) return (int)e;
@@ -946,7 +720,7 @@ int atlas_slab_pmax(const void* slab_f16, int64_t N, int d, float* out_pmax, voi
     hipError_t e = hipMemsetAsync(out_pmax, 0, 4, stream);
     if (e != hipSuccess) return (int)e;
     if (N == 0) return 0;
-    int grid = (int)((N + 3) / 4);
+    int grid = (int)((N + 3) / 4 > 65536 ? 65536 : (N + 3) / 4);
     if (grid > device_cus() * 16) grid = device_cus() * 16;
     hipLaunchKernelGGL(slab_pmax_kernel, dim3(grid), dim3(256), 0, stream, (const uint16_t*)slab_f16, N, d,
                        (uint32_t*)out_pmax);
