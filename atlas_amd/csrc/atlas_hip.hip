@@ -40,13 +40,13 @@ using namespace atlas;
 __global__ void __launch_bounds__(256)
 prep_queries_kernel(const void* __restrict__ q, int q_dtype, int q0, int nq, int d, float pmax,
                     uint16_t* __restrict__ qrow /*[64][d]*/, uint16_t* __restrict__ qfrag /*fragment order*/,
-                    float* __restrict__ qeps /*[64]*/, uint32_t* __restrict__ scan_state /*gstat[64] | qflag[64] or null*/,
+                    float* __restrict__ qeps /*[64]*/, uint32_t* __restrict__ scan_state /*gstat[64] | qflag[64] | dense_cnt[64] or null*/,
                     int32_t* __restrict__ out_status /*or null*/) {
     const int j = blockIdx.x;
     // also resets the per-call state words (saves two memset dispatches per search)
     if (scan_state != nullptr) {
         if (j == 0 && threadIdx.x < 64) scan_state[threadIdx.x] = 0u;
-        if (threadIdx.x == 0) scan_state[64 + j] = 0u;
+        if (threadIdx.x == 0) { scan_state[64 + j] = 0u; scan_state[128 + j] = 0u; }
     }
     if (out_status != nullptr) {
         if (q0 == 0 && j == 0 && threadIdx.x < ATLAS_STATUS_HEADER) out_status[threadIdx.x] = 0;
@@ -91,74 +91,59 @@ struct MergeParams {
     const uint16_t* slab; int64_t N; int d;
     const uint16_t* qrow;        // [64][d]
     const float* qeps;           // [64]
-    const uint2* lists; const uint32_t* counts; int G; int cap;
+    const uint2* dense; const uint32_t* dense_cnt; int dense_cap;   // [64][dense_cap] candidates per query
     const uint32_t* gstat; const uint32_t* qflag;
     int k, q0;                   // q0: first query of this chunk (output row offset)
     int key_cap;                 // approximate-score keys that fit in LDS
+    unsigned long long* dbg;     // optional per-phase cycle stamps of block 0 (tuning only; null in production)
     uint16_t* out_score; int64_t* out_idx; int32_t* out_status;
 };
 
-static __device__ __forceinline__ double exact_dot_dev(const uint16_t* __restrict__ qs /*LDS*/,
-                                                       const uint16_t* __restrict__ prow, int d) {
-    // canonical order (common.h exact_dot_f16): chain j takes elements j, j+8, ...; fixed combine tree.
-    // Chains live in named registers (a runtime-indexed array would go to scratch).
-    double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
-    int i = 0;
-    if ((d & 7) == 0) {
-        const uint4* p4 = (const uint4*)prow;
-        const uint4* q4 = (const uint4*)qs;
-        for (; i < d; i += 8) {
-            const f16x8 pv = __builtin_bit_cast(f16x8, p4[i >> 3]);
-            const f16x8 qv = __builtin_bit_cast(f16x8, q4[i >> 3]);
-            c0 += (double)(float)qv[0] * (double)(float)pv[0];
-            c1 += (double)(float)qv[1] * (double)(float)pv[1];
-            c2 += (double)(float)qv[2] * (double)(float)pv[2];
-            c3 += (double)(float)qv[3] * (double)(float)pv[3];
-            c4 += (double)(float)qv[4] * (double)(float)pv[4];
-            c5 += (double)(float)qv[5] * (double)(float)pv[5];
-            c6 += (double)(float)qv[6] * (double)(float)pv[6];
-            c7 += (double)(float)qv[7] * (double)(float)pv[7];
-        }
+// Canonical exact score (common.h exact_dot_f16) computed by ONE WAVE: lane j is chain j and adds the
+// products of elements j, j+64, ... in order; the chains are combined by an xor butterfly (distance 1,
+// 2, .. 32), which is the canonical balanced tree because IEEE addition is commutative. Every lane
+// returns the same double. Loads are 2 B per lane, 128 B contiguous per wave access.
+//   qs: query (fp16 bits) in LDS or global; prow: slab row in global memory
+static __device__ __forceinline__ double wave_exact_dot(const uint16_t* __restrict__ qs,
+                                                        const uint16_t* __restrict__ prow, const int d, const int lane) {
+    double c = 0.0;
+    if (d == D_FAST) {
+        uint16_t pv[D_FAST / 64];
+#pragma unroll
+        for (int i = 0; i < D_FAST / 64; ++i) pv[i] = prow[i * 64 + lane];          // all 12 loads in flight
+#pragma unroll
+        for (int i = 0; i < D_FAST / 64; ++i)
+            c += (double)(float)__builtin_bit_cast(_Float16, qs[i * 64 + lane]) *
+                 (double)(float)__builtin_bit_cast(_Float16, pv[i]);
     } else {
-#define ATLAS_TERM(j) (f16_bits_to_f64(qs[i + j]) * f16_bits_to_f64(prow[i + j]))
-        for (; i + 8 <= d; i += 8) {
-            c0 += ATLAS_TERM(0); c1 += ATLAS_TERM(1); c2 += ATLAS_TERM(2); c3 += ATLAS_TERM(3);
-            c4 += ATLAS_TERM(4); c5 += ATLAS_TERM(5); c6 += ATLAS_TERM(6); c7 += ATLAS_TERM(7);
-        }
-        const int rem = d - i;
-        if (rem > 0) c0 += ATLAS_TERM(0);
-        if (rem > 1) c1 += ATLAS_TERM(1);
-        if (rem > 2) c2 += ATLAS_TERM(2);
-        if (rem > 3) c3 += ATLAS_TERM(3);
-        if (rem > 4) c4 += ATLAS_TERM(4);
-        if (rem > 5) c5 += ATLAS_TERM(5);
-        if (rem > 6) c6 += ATLAS_TERM(6);
-#undef ATLAS_TERM
+        for (int e = lane; e < d; e += 64)
+            c += (double)(float)__builtin_bit_cast(_Float16, qs[e]) * (double)(float)__builtin_bit_cast(_Float16, prow[e]);
     }
-    return ((c0 + c1) + (c2 + c3)) + ((c4 + c5) + (c6 + c7));
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) c += __shfl_xor(c, m);
+    return c;
 }
 
 // one block per query. Steps: (1) gather the approximate-score keys of every workgroup's list into
 // LDS; (2) k-th largest by a greedy bit search that starts at the first bit where the keys differ and
 // stops 2^-15 (relative) short of exact -- any lower bound of the k-th is a valid T; (3) candidate band
-// s~ > prune_threshold(T); (4) exact rescoring in the canonical order; (5) rank by counting.
+// s~ > prune_threshold(T); (4) exact rescoring in the canonical order: rows staged in LDS with coalesced
+// loads, 8 lanes per candidate (lane j = chain j), chains combined by the canonical tree; (5) rank.
 template <int NT>
 __global__ void __launch_bounds__(NT)
 merge_rescore_kernel(const MergeParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // layout: qs[d] u16 (padded to 16 B) | misc[16] | s_off[1025] (padded) | s_row[SMAX] | s_app[SMAX] | s_key[SMAX] u64 | keys[key_cap]
+    // layout: qs[d] u16 (padded to 16 B) | misc[64] | s_row[SMAX] | s_app[SMAX] | s_key[SMAX] u64 | keys[key_cap]
     uint16_t* qs = (uint16_t*)smem;
     const int qbytes = ((p.d * 2 + 15) / 16) * 16;
-    uint32_t* misc = (uint32_t*)(smem + qbytes);   // [0] count [1] kmax [2] kmin [3] total [4] maxerr bits [5] nsurv
-    uint32_t* s_off = misc + 16;                   // exclusive prefix of list lengths, G+1 entries (G <= 1024)
-    uint32_t* s_row = s_off + 1040;
+    uint32_t* misc = (uint32_t*)(smem + qbytes);   // [1] kmax [2] kmin [4] maxerr bits [5] nsurv [16..63] 3 rotating x 16 bucket counts
+    uint32_t* s_row = misc + 64;
     float* s_app = (float*)(s_row + MERGE_SMAX);
     uint64_t* s_key = (uint64_t*)(s_app + MERGE_SMAX);
     uint32_t* keys = (uint32_t*)(s_key + MERGE_SMAX);
 
     const int q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NWV = NT / 64;
     const int k = p.k;
     uint16_t* o_score = p.out_score + (size_t)(p.q0 + q) * k;
     int64_t* o_idx = p.out_idx + (size_t)(p.q0 + q) * k;
@@ -173,29 +158,21 @@ merge_rescore_kernel(const MergeParams p) {
     };
     if (p.qflag[q] != 0u) { fallback(); return; }   // the scan overflowed this query's band
 
+    if (p.dbg && q == 0 && tid == 0) p.dbg[0] = __builtin_readcyclecounter();
     for (int i = tid; i < p.d; i += NT) qs[i] = p.qrow[(size_t)q * p.d + i];
-    if (tid < 16) misc[tid] = (tid == 2) ? 0xffffffffu : 0u;
-    // exclusive scan of the list lengths (G <= 1024)
-    for (int i = tid; i <= p.G; i += NT) s_off[i] = (i < p.G) ? p.counts[(size_t)i * 64 + q] : 0u;
+    if (tid < 64) misc[tid] = (tid == 2) ? 0xffffffffu : 0u;
+    const uint32_t total = p.dense_cnt[q];
+    if (total > (uint32_t)p.key_cap || total > (uint32_t)p.dense_cap) { fallback(); return; }   // TODO(perf): stream from L2
+    const uint2* D = p.dense + (size_t)q * p.dense_cap;
     __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (int i = 0; i <= p.G; ++i) { const uint32_t c = s_off[i]; s_off[i] = run; run += c; }
-    }
-    __syncthreads();
-    const uint32_t total = s_off[p.G];
-    if (total > (uint32_t)p.key_cap) { fallback(); return; }   // TODO(perf): stream from L2 instead
-    // (1) keys -> LDS, with min / max
+    if (p.dbg && q == 0 && tid == 0) p.dbg[1] = __builtin_readcyclecounter();
+    // (1) keys -> LDS (coalesced), with min / max
     uint32_t kmax = 0, kmin = 0xffffffffu;
-    for (int w = wave; w < p.G; w += NWV) {
-        const uint32_t base = s_off[w], n = s_off[w + 1] - base;
-        const uint2* L = p.lists + ((size_t)w * 64 + q) * p.cap;
-        for (uint32_t i = lane; i < n; i += 64) {
-            const uint32_t key = f32_order_key(bits_f32(L[i].x));
-            keys[base + i] = key;
-            kmax = key > kmax ? key : kmax;
-            kmin = key < kmin ? key : kmin;
-        }
+    for (uint32_t i = tid; i < total; i += NT) {
+        const uint32_t key = f32_order_key(bits_f32(D[i].x));
+        keys[i] = key;
+        kmax = key > kmax ? key : kmax;
+        kmin = key < kmin ? key : kmin;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -205,60 +182,108 @@ merge_rescore_kernel(const MergeParams p) {
     }
     if (lane == 0) { atomicMax(&misc[1], kmax); atomicMin(&misc[2], kmin); }
     __syncthreads();
+    if (p.dbg && q == 0 && tid == 0) p.dbg[2] = __builtin_readcyclecounter();
     float theta = neg_inf();
     const float eps = p.qeps[q];
     if (total >= (uint32_t)k) {
-        // (2) greedy bit search below the common prefix of all keys
+        // (2) a lower bound T of the k-th largest key from ONE 1024-bin histogram over [kmin, kmax]
+        // (any T with count(keys >= T) >= k is valid; the bin width, (kmax-kmin)/1024, only widens the
+        // candidate band by the few entries that share the k-th's bin)
         kmax = misc[1]; kmin = misc[2];
-        const uint32_t diff = kmax ^ kmin;
-        const int top = diff ? 31 - __builtin_clz(diff) : -1;        // highest differing bit
-        uint32_t prefix = (top >= 31) ? 0u : (kmax & ~((2u << top) - 1u));   // common leading bits
-        if (top < 0) prefix = kmax;
-        const int stop = top - 22 > 0 ? top - 22 : 0;
-        for (int bit = top; bit >= stop; --bit) {
-            const uint32_t cand = prefix | (1u << bit);
-            __syncthreads();
-            if (tid == 0) misc[0] = 0;
-            __syncthreads();
-            uint32_t c = 0;
-            for (uint32_t i = tid; i < total; i += NT) c += (keys[i] >= cand) ? 1u : 0u;
+        const uint32_t span = kmax - kmin;
+        const int shift = span >= 1024u ? (32 - __builtin_clz(span)) - 10 : 0;     // (key-kmin)>>shift < 1024
+        uint32_t* hist = (uint32_t*)s_key;                                          // 4 KB of the (still unused) key area
+        for (int i = tid; i < 1024; i += NT) hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < total; i += NT) atomicAdd(&hist[(keys[i] - kmin) >> shift], 1u);
+        __syncthreads();
+        if (tid < 64) {
+            // lane l owns bins [16l, 16l+16); suffix sums across lanes find the lane, then the bin
+            uint32_t own = 0;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-            if (lane == 0 && c) atomicAdd(&misc[0], c);
-            __syncthreads();
-            if (misc[0] >= (uint32_t)k) prefix = cand;
+            for (int b = 0; b < 16; ++b) own += hist[tid * 16 + b];
+            uint32_t suf = own;                                   // inclusive suffix sum over lanes >= l
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = __shfl_down(suf, o);
+                if (tid + o < 64) suf += y;
+            }
+            const uint32_t above = suf - own;                     // keys in lanes > l
+            if (above < (uint32_t)k && suf >= (uint32_t)k) {      // exactly one lane
+                uint32_t acc = above; int bin = tid * 16;
+                for (int b = 15; b >= 0; --b) {
+                    acc += hist[tid * 16 + b];
+                    if (acc >= (uint32_t)k) { bin = tid * 16 + b; break; }
+                }
+                misc[3] = kmin + ((uint32_t)bin << shift);        // lower edge of the bin holding rank k
+            }
         }
+        __syncthreads();
+        const uint32_t prefix = misc[3];
         theta = prune_threshold(f32_from_order_key(prefix), eps);
     }
-    __syncthreads();
-    // (3) candidate band
-    for (int w = wave; w < p.G; w += NWV) {
-        const uint32_t n = s_off[w + 1] - s_off[w];
-        const uint2* L = p.lists + ((size_t)w * 64 + q) * p.cap;
-        for (uint32_t i = lane; i < n; i += 64) {
-            const uint2 e = L[i];
-            if (bits_f32(e.x) > theta) {
-                const uint32_t s = atomicAdd(&misc[5], 1u);
-                if (s < MERGE_SMAX) { s_row[s] = e.y; s_app[s] = bits_f32(e.x); }
+    if (p.dbg && q == 0 && tid == 0) p.dbg[3] = __builtin_readcyclecounter();
+    // (3) candidate band (keys in LDS decide; only band members are re-read)
+    const uint32_t theta_key = f32_order_key(theta);
+    for (uint32_t i = tid; i < total; i += NT) {
+        if (keys[i] > theta_key) {
+            const uint2 e = D[i];
+            const uint32_t sidx = atomicAdd(&misc[5], 1u);
+            if (sidx < MERGE_SMAX) { s_row[sidx] = e.y; s_app[sidx] = bits_f32(e.x); }
+        }
+    }
+    __syncthreads();                                  // band complete; keys[] is dead from here on
+    const uint32_t nsurv = misc[5];
+    if (nsurv > MERGE_SMAX) { fallback(); return; }
+
+    if (p.dbg && q == 0 && tid == 0) p.dbg[4] = __builtin_readcyclecounter();
+    // (4) exact rescoring in the canonical order: one wave per candidate, 4 candidates per wave in flight
+    // (their 48 two-byte row loads go out together: one HBM latency instead of four)
+    if (p.d == D_FAST) {
+        constexpr int NWV = NT / 64, R = 4;
+        for (uint32_t i0 = wave; i0 < nsurv; i0 += NWV * R) {
+            uint16_t pv[R][D_FAST / 64];
+            uint32_t row[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t i = i0 + r * NWV;
+                row[r] = s_row[i < nsurv ? i : i0];                    // clamped: loads stay unconditional
+                const uint16_t* prow = p.slab + (size_t)row[r] * D_FAST;
+#pragma unroll
+                for (int t = 0; t < D_FAST / 64; ++t) pv[r][t] = prow[t * 64 + lane];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t i = i0 + r * NWV;
+                double c = 0.0;
+#pragma unroll
+                for (int t = 0; t < D_FAST / 64; ++t)
+                    c += (double)(float)__builtin_bit_cast(_Float16, qs[t * 64 + lane]) *
+                         (double)(float)__builtin_bit_cast(_Float16, pv[r][t]);
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) c += __shfl_xor(c, m);   // canonical tree (common.h)
+                if (lane == 0 && i < nsurv) {
+                    s_key[i] = local_key(f64_to_f16_bits_rto(c), row[r]);
+                    const float err = fabsf((float)((double)s_app[i] - c));   // a-posteriori check of the error model
+                    const float ratio = eps > 0.f ? err / eps : (err > 0.f ? 2.0f : 0.0f);
+                    atomicMax(&misc[4], f32_bits(ratio));
+                }
+            }
+        }
+    } else {
+        for (uint32_t i = wave; i < nsurv; i += NT / 64) {
+            const uint32_t row = s_row[i];
+            const double sc = wave_exact_dot(qs, p.slab + (size_t)row * p.d, p.d, lane);
+            if (lane == 0) {
+                s_key[i] = local_key(f64_to_f16_bits_rto(sc), row);
+                const float err = fabsf((float)((double)s_app[i] - sc));
+                const float ratio = eps > 0.f ? err / eps : (err > 0.f ? 2.0f : 0.0f);
+                atomicMax(&misc[4], f32_bits(ratio));
             }
         }
     }
     __syncthreads();
-    const uint32_t nsurv = misc[5];
-    if (nsurv > MERGE_SMAX) { fallback(); return; }
-
-    // (4) exact rescoring in the canonical order, canonical keys
-    for (uint32_t i = tid; i < nsurv; i += NT) {
-        const uint32_t row = s_row[i];
-        const double s = exact_dot_dev(qs, p.slab + (size_t)row * p.d, p.d);
-        const uint16_t h = f64_to_f16_bits(s);
-        s_key[i] = local_key(h, row);
-        // a-posteriori check of the error model on every rescored row
-        const float err = fabsf((float)((double)s_app[i] - s));
-        const float ratio = eps > 0.f ? err / eps : (err > 0.f ? 2.0f : 0.0f);
-        atomicMax(&misc[4], f32_bits(ratio));
-    }
-    __syncthreads();
+    if (p.dbg && q == 0 && tid == 0) p.dbg[5] = __builtin_readcyclecounter();
     // (5) rank by counting (keys are unique: the row is part of the key)
     for (uint32_t i = tid; i < nsurv; i += NT) {
         const uint64_t ki = s_key[i];
@@ -270,6 +295,7 @@ merge_rescore_kernel(const MergeParams p) {
         }
     }
     for (uint32_t i = nsurv + tid; i < (uint32_t)k; i += NT) { o_score[i] = 0xfc00; o_idx[i] = -1; }
+    if (p.dbg && q == 0 && tid == 0) p.dbg[6] = __builtin_readcyclecounter();
     if (tid == 0) {
         *o_qst = ATLAS_Q_OK;
         atomicAdd((uint32_t*)&p.out_status[ATLAS_ST_N_CANDIDATES], total);
@@ -293,9 +319,10 @@ exact_keys_kernel(const uint16_t* __restrict__ slab, int64_t N, int d, const uin
     uint16_t* qs = (uint16_t*)smem;
     for (int i = threadIdx.x; i < d; i += 256) qs[i] = qrow[i];
     __syncthreads();
-    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < N; r += (int64_t)gridDim.x * 256) {
-        const double s = exact_dot_dev(qs, slab + (size_t)r * d, d);
-        keys[r] = local_key(f64_to_f16_bits(s), (uint32_t)r);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < N; r += (int64_t)gridDim.x * 4) {   // one wave per row
+        const double s = wave_exact_dot(qs, slab + (size_t)r * d, d, lane);
+        if (lane == 0) keys[r] = local_key(f64_to_f16_bits_rto(s), (uint32_t)r);
     }
 }
 
@@ -468,6 +495,7 @@ int scan_variant_index() {
 }
 
 constexpr int MERGE_NT = 1024;
+unsigned long long* g_merge_dbg = nullptr;   // tuning hook (atlas_dbg_set_merge_stamps); never set in production
 constexpr int SAMPLE_MAX = 16384;
 
 struct ScanPlan {
@@ -476,7 +504,8 @@ struct ScanPlan {
     int keep_max, cap, tile, buf_cap;
     int S; int64_t sample_stride;     // sample pre-pass: S rows (0 = none), tile j starts at j*sample_stride
     int key_cap;
-    size_t off_qfrag, off_qrow, off_qeps, off_theta0, off_counts, off_gstat, off_qflag, off_sample, off_lists, total;
+    int dense_cap;
+    size_t off_qfrag, off_qrow, off_qeps, off_theta0, off_gstat, off_qflag, off_dense_cnt, off_sample, off_dense, off_lists, total;
     size_t scan_lds, merge_lds;
 };
 
@@ -519,14 +548,16 @@ ScanPlan make_plan(int64_t N, int d, int k, int cus, const ScanVariant& v) {
     pl.off_qrow = o;   o += align_up((size_t)QCHUNK * d * 2, 256);
     pl.off_qeps = o;   o += 256;
     pl.off_theta0 = o; o += 256;
-    pl.off_gstat = o;  o += 256;
+    pl.off_gstat = o;  o += 256;          // gstat | qflag | dense_cnt are contiguous (prep zeroes them)
     pl.off_qflag = o;  o += 256;
-    pl.off_counts = o; o += align_up((size_t)pl.G * 64 * 4, 256);
+    pl.off_dense_cnt = o; o += 256;
     pl.off_sample = o; o += (size_t)QCHUNK * SAMPLE_MAX * 4;
+    pl.dense_cap = 32768;
+    pl.off_dense = o;  o += (size_t)QCHUNK * pl.dense_cap * 8;
     pl.off_lists = o;  o += (size_t)pl.G * 64 * pl.cap * 8;
     pl.total = align_up(o, 256);
     pl.scan_lds = (size_t)ScanSmem::buf_off + (size_t)pl.buf_cap * 8;
-    const size_t merge_fixed = align_up((size_t)d * 2, 16) + 16 * 4 + 1040 * 4 + (size_t)MERGE_SMAX * (4 + 4 + 8);
+    const size_t merge_fixed = align_up((size_t)d * 2, 16) + 64 * 4 + (size_t)MERGE_SMAX * (4 + 4 + 8);
     pl.key_cap = (int)((160 * 1024 - 1024 - merge_fixed) / 4);
     pl.merge_lds = merge_fixed + (size_t)pl.key_cap * 4;
     return pl;
@@ -554,6 +585,20 @@ void allow_lds(KernelT kern) {   // opt in to the full 160 KiB of LDS (idempoten
 }  // namespace
 
 extern "C" {
+
+// test hook, deliberately not in include/atlas_hip.h: the device's double -> fp16 conversions, elementwise
+// (out[2i] = software single-rounding path, out[2i+1] = hardware round-to-odd path)
+__global__ void dbg_f64_to_f16_kernel(const double* in, uint16_t* out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { out[2 * i] = f64_to_f16_bits(in[i]); out[2 * i + 1] = f64_to_f16_bits_rto(in[i]); }
+}
+extern "C" int atlas_dbg_f64_to_f16(const double* in, uint16_t* out, int n, void* stream) {
+    hipLaunchKernelGGL(dbg_f64_to_f16_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, out, n);
+    return (int)hipGetLastError();
+}
+
+// tuning hook, deliberately not in include/atlas_hip.h: device buffer of >= 8 u64 for merge phase stamps
+void atlas_dbg_set_merge_stamps(unsigned long long* p) { g_merge_dbg = p; }
 
 int atlas_abi_version(void) { return ATLAS_ABI_VERSION; }
 const char* atlas_build_info(void) {
@@ -610,10 +655,10 @@ int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t
         if (pl.S > 0) {
             SampleParams sm{};
             sm.slab = (const uint16_t*)slab_f16; sm.N = N; sm.qfrag = (const uint4*)(w + pl.off_qfrag);
-            sm.scores = (float*)(w + pl.off_sample); sm.S = pl.S; sm.stride_rows = pl.sample_stride;
+            sm.top2 = (float*)(w + pl.off_sample); sm.S = pl.S; sm.stride_rows = pl.sample_stride;
             hipLaunchKernelGGL(sample_scores_kernel, dim3(pl.S / 64), dim3(256), (size_t)QFRAG_U4 * 16, stream, sm);
-            hipLaunchKernelGGL(sample_theta_kernel, dim3(QCHUNK), dim3(1024), (size_t)pl.S * 4, stream,
-                               (const float*)(w + pl.off_sample), pl.S, k, (const float*)(w + pl.off_qeps), nq,
+            hipLaunchKernelGGL(sample_theta_kernel, dim3(QCHUNK / 4), dim3(256), 0, stream,
+                               (const float*)(w + pl.off_sample), pl.S / 64, k, (const float*)(w + pl.off_qeps), nq,
                                (float*)(w + pl.off_theta0));
         } else {
             e = hipMemsetD32Async((hipDeviceptr_t)(w + pl.off_theta0), (int)0xff800000u, 64, stream);   // -inf
@@ -623,7 +668,8 @@ int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t
         sp.slab = (const uint16_t*)slab_f16; sp.N = N;
         sp.qfrag = (const uint4*)(w + pl.off_qfrag); sp.qeps = (const float*)(w + pl.off_qeps);
         sp.theta0 = (const float*)(w + pl.off_theta0);
-        sp.lists = (uint2*)(w + pl.off_lists); sp.counts = (uint32_t*)(w + pl.off_counts);
+        sp.lists = (uint2*)(w + pl.off_lists);
+        sp.dense = (uint2*)(w + pl.off_dense); sp.dense_cnt = (uint32_t*)(w + pl.off_dense_cnt); sp.dense_cap = pl.dense_cap;
         sp.gstat = (uint32_t*)(w + pl.off_gstat); sp.qflag = (uint32_t*)(w + pl.off_qflag);
         sp.rows_per_wg = pl.rows_per_wg; sp.nq = nq; sp.k = k; sp.cap = pl.cap; sp.keep_max = pl.keep_max;
         sp.buf_cap = pl.buf_cap;
@@ -634,8 +680,9 @@ int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t
         MergeParams mp{};
         mp.slab = (const uint16_t*)slab_f16; mp.N = N; mp.d = d;
         mp.qrow = (const uint16_t*)(w + pl.off_qrow); mp.qeps = sp.qeps;
-        mp.lists = sp.lists; mp.counts = sp.counts; mp.G = pl.G; mp.cap = pl.cap;
+        mp.dense = sp.dense; mp.dense_cnt = sp.dense_cnt; mp.dense_cap = pl.dense_cap;
         mp.gstat = sp.gstat; mp.qflag = sp.qflag; mp.k = k; mp.q0 = q0; mp.key_cap = pl.key_cap;
+        mp.dbg = g_merge_dbg;
         mp.out_score = (uint16_t*)out_score_f16; mp.out_idx = out_idx; mp.out_status = out_status;
         hipLaunchKernelGGL(merge, dim3(nq), dim3(MERGE_NT), pl.merge_lds, stream, mp);
     }
@@ -661,6 +708,8 @@ int atlas_exact_topk(const void* q, int q_dtype, const void* slab_f16, int64_t N
     int grid = (int)((N + 255) / 256);
     if (grid > cus * 8) grid = cus * 8;
     if (grid < 1) grid = 1;
+    int grid_rows = (int)((N + 3) / 4 > (int64_t)cus * 32 ? (int64_t)cus * 32 : (N + 3) / 4);
+    if (grid_rows < 1) grid_rows = 1;
     for (int q0 = 0; q0 < B; q0 += QCHUNK) {
         const int nq = (B - q0 < QCHUNK) ? (B - q0) : QCHUNK;
         // prep reuses the fast path's converter (no fragment image: qfrag == nullptr)
@@ -670,7 +719,7 @@ int atlas_exact_topk(const void* q, int q_dtype, const void* slab_f16, int64_t N
         for (int j = 0; j < nq; ++j) {
             hipError_t e = hipMemsetAsync(w + pl.off_hists, 0, 8 * 256 * 4 + 256, stream);   // hists + nsel
             if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(exact_keys_kernel, dim3(grid), dim3(256), (size_t)align_up((size_t)d * 2, 16), stream,
+            hipLaunchKernelGGL(exact_keys_kernel, dim3(grid_rows), dim3(256), (size_t)align_up((size_t)d * 2, 16), stream,
                                (const uint16_t*)slab_f16, N, d, (const uint16_t*)(w + pl.off_qrow) + (size_t)j * d,
                                (uint64_t*)(w + pl.off_keys));
             for (int pass = 0; pass < 8; ++pass)

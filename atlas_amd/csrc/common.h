@@ -55,6 +55,29 @@ ATLAS_HD uint16_t f64_to_f16_bits(double x) {
     return (uint16_t)(sign | out);
 }
 ATLAS_HD uint16_t f32_to_f16_bits(float x) { return f64_to_f16_bits((double)x); }  // exact widen
+
+// Same result as f64_to_f16_bits in ~10 instructions on the GPU: double -> float with ROUND-TO-ODD
+// (truncate, then OR the sticky bit into the LSB), then the hardware float -> half RNE. Round-to-odd
+// into 24 bits followed by RNE into <= 11 bits equals one RNE from the exact value (24 >= 11 + 2).
+ATLAS_HD uint16_t f64_to_f16_bits_rto(double x) {
+    const uint64_t u = f64_bits(x);
+    const uint16_t sign = (uint16_t)((u >> 48) & 0x8000);
+    const double a = bits_f64(u & 0x7fffffffffffffffull);
+    if (a != a) return (uint16_t)(sign | 0x7e00);
+    const float f = (float)a;                        // RNE (v_cvt_f32_f64); inf above FLT_MAX
+    uint32_t fb = f32_bits(f);
+    const double back = (double)f;
+    if (back != a) {                                 // inexact: make it truncation + sticky
+        if (back > a) fb -= 1u;                      // step back towards zero (also turns +inf into FLT_MAX)
+        fb |= 1u;
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    const _Float16 h = (_Float16)bits_f32(fb);       // v_cvt_f16_f32: RNE, fp16 subnormals kept
+    return (uint16_t)(sign | __builtin_bit_cast(uint16_t, h));
+#else
+    return (uint16_t)(sign | f64_to_f16_bits((double)bits_f32(fb)));
+#endif
+}
 ATLAS_HD uint16_t bf16_bits_to_f16_bits(uint16_t b) {
     return f32_to_f16_bits(bits_f32((uint32_t)b << 16));
 }
@@ -88,21 +111,19 @@ ATLAS_HD uint64_t pack_candidate(uint16_t h, uint64_t gid) {
 }
 
 // ---- canonical exact score -------------------------------------------------------------
-// 8 interleaved double chains (chain j takes elements j, j+8, ...), combined by a fixed
-// tree. fp16*fp16 is exact in double, so `c + q*p` rounds once whether or not the compiler
-// contracts it to an fma: the result depends only on this order. oracle/oracle.c restates it.
-struct Chains8 { double c[8]; };
-ATLAS_HD void chains_init(Chains8& s) { for (int j = 0; j < 8; ++j) s.c[j] = 0.0; }
-ATLAS_HD double chains_finish(const Chains8& s) {
-    return ((s.c[0] + s.c[1]) + (s.c[2] + s.c[3])) + ((s.c[4] + s.c[5]) + (s.c[6] + s.c[7]));
-}
+// 64 interleaved double chains (chain j takes elements j, j+64, ... in order), combined by a fixed
+// balanced tree: for m = 1,2,4,..,32: c[j] += c[j+m] for j = 0, 2m, 4m, ...  (on the GPU: one wave per
+// row, lane j = chain j, xor-butterfly; IEEE addition is commutative so both give the same bits).
+// fp16*fp16 is exact in double, so `c + q*p` rounds once whether or not the compiler contracts it to
+// an fma: the result depends only on this order. oracle/oracle.c restates it independently.
+#define ATLAS_NCHAIN 64
 ATLAS_HD double exact_dot_f16(const uint16_t* q, const uint16_t* p, int d) {
-    Chains8 s; chains_init(s);
-    int i = 0;
-    for (; i + 8 <= d; i += 8)
-        for (int j = 0; j < 8; ++j) s.c[j] += f16_bits_to_f64(q[i + j]) * f16_bits_to_f64(p[i + j]);
-    for (int j = 0; i + j < d; ++j) s.c[j] += f16_bits_to_f64(q[i + j]) * f16_bits_to_f64(p[i + j]);
-    return chains_finish(s);
+    double c[ATLAS_NCHAIN];
+    for (int j = 0; j < ATLAS_NCHAIN; ++j) c[j] = 0.0;
+    for (int i = 0; i < d; ++i) c[i % ATLAS_NCHAIN] += f16_bits_to_f64(q[i]) * f16_bits_to_f64(p[i]);
+    for (int m = 1; m < ATLAS_NCHAIN; m <<= 1)
+        for (int j = 0; j < ATLAS_NCHAIN; j += 2 * m) c[j] = c[j] + c[j + m];
+    return c[0];
 }
 
 // ---- certified pruning margin ---------------------------------------------------------

@@ -27,6 +27,29 @@ static __device__ __forceinline__ void wg_barrier_lds() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+
+// global -> LDS copy of the 96 KiB query image with all loads of a thread in flight at once
+// (the naive loop compiles to load / s_waitcnt vmcnt(0) / ds_write per element: one L2 latency each)
+template <int NT>
+static __device__ __forceinline__ void copy_qfrag_to_lds(uint4* __restrict__ s_q, const uint4* __restrict__ g, const int tid) {
+    constexpr int PER = (QFRAG_U4 + NT - 1) / NT;      // 6 for 1024 threads, 24 for 256
+    constexpr int BATCH = PER < 12 ? PER : 12;
+#pragma unroll 1
+    for (int b0 = 0; b0 < PER; b0 += BATCH) {
+        uint4 tmp[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int i = tid + (b0 + u) * NT;
+            tmp[u] = (i < QFRAG_U4) ? g[i] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int i = tid + (b0 + u) * NT;
+            if (i < QFRAG_U4) s_q[i] = tmp[u];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // scan
 // ------------------------------------------------------------------------------------------
@@ -37,7 +60,9 @@ struct ScanParams {
     const float* qeps;        // [64]
     const float* theta0;      // [64] initial per-query thresholds from the sample pre-pass (or -inf)
     uint2* lists;             // [G][64][cap]  {f32 bits of approx score, row}
-    uint32_t* counts;         // [G][64]
+    uint2* dense;             // [64][dense_cap] every workgroup's final candidates, per query, contiguous
+    uint32_t* dense_cnt;      // [64] entries used in dense[q] (atomicAdd by workgroups)
+    int dense_cap;
     uint32_t* gstat;          // [0] max row sumsq (float bits, atomicMax)  [1] flags
     uint32_t* qflag;          // [64] per-query fallback flag (band overflow)
     int64_t rows_per_wg;
@@ -51,7 +76,8 @@ struct ScanSmem {   // byte offsets into dynamic LDS
     static constexpr int theta_off = QFRAG_U4 * 16;       // 64 f32
     static constexpr int cnt_off = theta_off + 256;       // 64 u32
     static constexpr int flag_off = cnt_off + 256;        // 64 B: [0],[1] flush/compaction request by tile parity, [2] buffer fill
-    static constexpr int buf_off = flag_off + 64;         // buf_cap x {u32 score bits, u32 (query<<26)|row}
+    static constexpr int aux_off = flag_off + 64;         // 3 x 64 u32: per-query base / running position / buffered count (final hand-over)
+    static constexpr int buf_off = aux_off + 768;         // buf_cap x {u32 score bits, u32 (query<<26)|row}
 };
 
 template <int NW, int PF, int RING>
@@ -73,14 +99,6 @@ scan_kernel(const ScanParams p) {
     constexpr int TILE = NW * PF * 16;       // rows per workgroup tile
     constexpr int ROWB = D_FAST * 2;         // bytes per slab row
     constexpr int RPT = KSTEPS / RING;       // ring revolutions per tile
-
-    for (int i = tid; i < QFRAG_U4; i += NW * 64) s_q[i] = p.qfrag[i];
-    if (tid < 64) {
-        s_theta[tid] = (tid < p.nq) ? p.theta0[tid] : pos_inf();
-        s_cnt[tid] = 0;
-    }
-    if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; }
-    __syncthreads();
 
     const int64_t r_begin = (int64_t)blockIdx.x * p.rows_per_wg;
     int64_t r_end = r_begin + p.rows_per_wg;
@@ -127,6 +145,16 @@ scan_kernel(const ScanParams p) {
         // entry and the back edge, so a shuffled prologue would cost ring depth on every revolution
         __builtin_amdgcn_sched_barrier(0);
     }
+
+    // the query image is copied into LDS AFTER the first ring loads are in flight (their HBM latency
+    // overlaps the 96 KiB copy from L2)
+    copy_qfrag_to_lds<NW * 64>(s_q, p.qfrag, tid);
+    if (tid < 64) {
+        s_theta[tid] = (tid < p.nq) ? p.theta0[tid] : pos_inf();
+        s_cnt[tid] = 0;
+    }
+    if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; }
+    __syncthreads();
 
     f32x4 acc[PF][4];
 #pragma unroll
@@ -343,17 +371,58 @@ scan_kernel(const ScanParams p) {
         }
 
         wg_barrier_lds();
-        const bool last_tile = (rev + 1 == ntiles * RPT);
         // the request word of this tile's parity cannot change until every wave has passed the next
         // barrier, so all waves take the same branch
-        if (s_flag[par] != 0u || last_tile) flush_and_compact(par, last_tile);
+        if (s_flag[par] != 0u) flush_and_compact(par, false);
         row0 += TILE;
         par ^= 1;
     }
-    if (ntiles == 0) flush_and_compact(0, true);
 
-    __syncthreads();
-    if (tid < 64) p.counts[(size_t)blockIdx.x * 64 + tid] = (tid < p.nq) ? s_cnt[tid] : 0u;
+    // Final hand-over: each query's candidates of ALL workgroups end up contiguous in dense[q], so the
+    // merge kernel reads them with coalesced loads and needs no per-workgroup bookkeeping. Buffered
+    // entries go LDS -> dense directly; ONE global atomicAdd per (workgroup, query) reserves the range
+    // (64 lanes issue them together: one L2 round trip).
+    {
+        uint32_t* s_base = (uint32_t*)(smem + ScanSmem::aux_off);
+        uint32_t* s_pos = s_base + 64;
+        uint32_t* s_nbuf = s_base + 128;
+        wg_barrier_lds();
+        const uint32_t nbuf = s_flag[2] < (uint32_t)p.buf_cap ? s_flag[2] : (uint32_t)p.buf_cap;
+        if (tid < 64) { s_pos[tid] = 0u; s_nbuf[tid] = 0u; }
+        wg_barrier_lds();
+        for (uint32_t i = tid; i < nbuf; i += NW * 64) atomicAdd(&s_nbuf[s_buf[i].y >> 26], 1u);
+        wg_barrier_lds();
+        if (tid < 64) {
+            uint32_t base = 0xffffffffu;
+            if (tid < p.nq) {
+                const uint32_t listed = s_cnt[tid] < (uint32_t)p.cap ? s_cnt[tid] : (uint32_t)p.cap;
+                const uint32_t n = s_nbuf[tid] + listed;
+                if (s_cnt[tid] > (uint32_t)p.cap) { p.qflag[tid] = 1u; }          // a list overflowed -> exact path
+                else if (n > 0) {
+                    base = atomicAdd(&p.dense_cnt[tid], n);
+                    if (base + n > (uint32_t)p.dense_cap) { p.qflag[tid] = 1u; base = 0xffffffffu; }
+                }
+            }
+            s_base[tid] = base;
+        }
+        wg_barrier_lds();
+        for (uint32_t i = tid; i < nbuf; i += NW * 64) {
+            const uint2 e = s_buf[i];
+            const uint32_t qq = e.y >> 26, b = s_base[qq];
+            if (b != 0xffffffffu) {
+                const uint32_t pos = atomicAdd(&s_pos[qq], 1u);
+                p.dense[(size_t)qq * p.dense_cap + b + pos] = make_uint2(e.x, gbase + (e.y & 0x03ffffffu));
+            }
+        }
+        wg_barrier_lds();
+        for (int qq = wave; qq < p.nq; qq += NW) {       // entries flushed to the lists earlier (large shards only)
+            const uint32_t n = s_cnt[qq] < (uint32_t)p.cap ? s_cnt[qq] : (uint32_t)p.cap, b = s_base[qq];
+            if (n == 0 || b == 0xffffffffu) continue;
+            const uint2* L = my_lists + (size_t)qq * p.cap;
+            uint2* D = p.dense + (size_t)qq * p.dense_cap + b + s_nbuf[qq];
+            for (uint32_t i = lane; i < n; i += 64) D[i] = L[i];
+        }
+    }
     // publish the largest row norm^2 seen (x1.001: v_dot2 accumulates in fp32)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) pm = fmaxf(pm, __shfl_xor(pm, o));
@@ -374,7 +443,7 @@ scan_kernel(const ScanParams p) {
 struct SampleParams {
     const uint16_t* slab; int64_t N;
     const uint4* qfrag;
-    float* scores;            // [64][S] approximate scores (fp32), -inf for rows >= N
+    float* top2;              // [64][S/64][2]: the two best approximate scores of each 64-row sample tile
     int S;                    // multiple of 64
     int64_t stride_rows;      // first row of sample tile j = j * stride_rows (multiple of 16, >= 64)
 };
@@ -385,82 +454,117 @@ sample_scores_kernel(const SampleParams p) {
     uint4* s_q = (uint4*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, lgrp = lane >> 4;
-    for (int i = tid; i < QFRAG_U4; i += 256) s_q[i] = p.qfrag[i];
-    __syncthreads();
     const int64_t row0 = (int64_t)blockIdx.x * p.stride_rows + wave * 16;
     int64_t r = row0 + lrow;
     if (r >= p.N) r = p.N - 1;
     const uint4* src = (const uint4*)((const unsigned char*)p.slab + r * (int64_t)(D_FAST * 2) + lgrp * 16);
+    // all 24 fragments of this wave's 16 rows go out first (HBM latency overlaps the query copy)
+    uint4 a[KSTEPS];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) a[s] = src[s * 4];
+    copy_qfrag_to_lds<256>(s_q, p.qfrag, tid);
+    __syncthreads();
     f32x4 acc[4];
 #pragma unroll
     for (int qf = 0; qf < 4; ++qf) acc[qf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 6
+#pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
-        const uint4 a = src[s * 4];
-        const f16x8 av = __builtin_bit_cast(f16x8, a);
+        const f16x8 av = __builtin_bit_cast(f16x8, a[s]);
 #pragma unroll
         for (int qf = 0; qf < 4; ++qf)
             acc[qf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
                 av, __builtin_bit_cast(f16x8, s_q[(s * 4 + qf) * 64 + lane]), acc[qf], 0, 0, 0);
     }
-    const int slot0 = blockIdx.x * 64 + wave * 16 + lgrp * 4;
+    // two best scores per query over this block's 64 rows: per lane (4 rows) -> across the 4 lane groups
+    // that share a query column (xor 16, 32) -> across the 4 waves through LDS. Any subset of real
+    // scores gives a certified threshold; with 256 tiles, missing a 3rd score of one tile is rare.
+    auto merge2 = [](float& a1, float& a2, const float b1, const float b2) {
+        const float hi = fmaxf(a1, b1), lo = fminf(a1, b1);
+        a2 = fmaxf(lo, fmaxf(a2, b2));
+        a1 = hi;
+    };
+    float* s_t2 = (float*)smem;                      // reuse the query image: [4 waves][64 queries][2]
+    float t1[4], t2[4];
 #pragma unroll
-    for (int qf = 0; qf < 4; ++qf)
+    for (int qf = 0; qf < 4; ++qf) {
+        t1[qf] = neg_inf(); t2[qf] = neg_inf();
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const bool valid = row0 + lgrp * 4 + rr < p.N;
-            p.scores[(size_t)(qf * 16 + lrow) * p.S + slot0 + rr] = valid ? acc[qf][rr] : neg_inf();
+            const float v = (row0 + lgrp * 4 + rr < p.N) ? acc[qf][rr] : neg_inf();
+            merge2(t1[qf], t2[qf], v, neg_inf());
         }
+        merge2(t1[qf], t2[qf], __shfl_xor(t1[qf], 16), __shfl_xor(t2[qf], 16));
+        merge2(t1[qf], t2[qf], __shfl_xor(t1[qf], 32), __shfl_xor(t2[qf], 32));
+    }
+    __syncthreads();                                  // everyone is done reading the query image
+    if (lgrp == 0) {
+#pragma unroll
+        for (int qf = 0; qf < 4; ++qf) {
+            s_t2[(wave * 64 + qf * 16 + lrow) * 2 + 0] = t1[qf];
+            s_t2[(wave * 64 + qf * 16 + lrow) * 2 + 1] = t2[qf];
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float a1 = s_t2[tid * 2], a2 = s_t2[tid * 2 + 1];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) merge2(a1, a2, s_t2[(w * 64 + tid) * 2], s_t2[(w * 64 + tid) * 2 + 1]);
+        const int nblk = p.S / 64;
+        p.top2[((size_t)tid * nblk + blockIdx.x) * 2 + 0] = a1;
+        p.top2[((size_t)tid * nblk + blockIdx.x) * 2 + 1] = a2;
+    }
 }
 
-// one block of 1024 threads per query: k-th largest of the S sample scores (greedy bit search on
-// order keys held in LDS) -> theta0 = prune_threshold(k-th, eps): certified, since the sample rows
-// are rows of the slab (k rows with exact score >= k-th - eps exist).
-__global__ void __launch_bounds__(1024)
-sample_theta_kernel(const float* __restrict__ scores, int S, int k, const float* __restrict__ qeps, int nq,
-                    float* __restrict__ theta0) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* keys = (uint32_t*)smem;              // S keys
-    __shared__ uint32_t s_count;
-    const int q = blockIdx.x, tid = threadIdx.x;
-    if (q >= nq) { if (tid == 0) theta0[q] = pos_inf(); return; }
-    __shared__ uint32_t s_mm[2];
-    if (tid == 0) { s_mm[0] = 0u; s_mm[1] = 0xffffffffu; }
-    __syncthreads();
+// k-th largest of KPL register keys per lane across ONE wave (keys == 0 are padding): greedy bit
+// search below the wave's common key prefix, counting with v_cmp + s_bcnt1 only (no LDS, no barrier).
+// Returns the largest v (to `res_bits` bits below the first differing bit) with count(keys >= v) >= kk.
+template <int KPL>
+static __device__ __forceinline__ uint32_t wave_kth_key(const uint32_t (&key)[KPL], const uint32_t kk, const int res_bits) {
     uint32_t kmax = 0, kmin = 0xffffffffu;
-    for (int i = tid; i < S; i += 1024) {
-        const uint32_t key = f32_order_key(scores[(size_t)q * S + i]);
-        keys[i] = key;
-        kmax = key > kmax ? key : kmax;
-        kmin = key < kmin ? key : kmin;
-    }
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) { kmax = key[u] > kmax ? key[u] : kmax; kmin = key[u] < kmin ? key[u] : kmin; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const uint32_t a = __shfl_xor(kmax, o), b = __shfl_xor(kmin, o);
         kmax = a > kmax ? a : kmax;
         kmin = b < kmin ? b : kmin;
     }
-    if ((tid & 63) == 0) { atomicMax(&s_mm[0], kmax); atomicMin(&s_mm[1], kmin); }
-    __syncthreads();
-    kmax = s_mm[0]; kmin = s_mm[1];
     const uint32_t diff = kmax ^ kmin;
     const int top = diff ? 31 - __builtin_clz(diff) : -1;
     uint32_t prefix = (top < 0) ? kmax : ((top >= 31) ? 0u : (kmax & ~((2u << top) - 1u)));
-    const int stop = top - 22 > 0 ? top - 22 : 0;     // any lower bound of the k-th is a valid threshold
+    const int stop = top - res_bits > 0 ? top - res_bits : 0;
     for (int bit = top; bit >= stop; --bit) {
         const uint32_t cand = prefix | (1u << bit);
-        if (tid == 0) s_count = 0;
-        __syncthreads();
         uint32_t c = 0;
-        for (int i = tid; i < S; i += 1024) c += (keys[i] >= cand) ? 1u : 0u;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        if ((tid & 63) == 0 && c) atomicAdd(&s_count, c);
-        __syncthreads();
-        if (s_count >= (uint32_t)k) prefix = cand;
-        __syncthreads();
+        for (int u = 0; u < KPL; ++u) c += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(key[u] >= cand));
+        if (c >= kk) prefix = cand;
     }
-    if (tid == 0) theta0[q] = (S >= k) ? prune_threshold(f32_from_order_key(prefix), qeps[q]) : neg_inf();
+    return prefix;
+}
+
+// One wave per query (4 queries per 256-thread block): k-th largest of the 2*nblk tile maxima written by
+// sample_scores_kernel (nblk <= 256 -> 8 keys per lane), entirely in registers. All of them are scores of
+// distinct slab rows, so prune_threshold(k-th) is a certified initial threshold for the scan.
+__global__ void __launch_bounds__(256)
+sample_theta_kernel(const float* __restrict__ top2, int nblk, int k, const float* __restrict__ qeps, int nq,
+                    float* __restrict__ theta0) {
+    const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= 64) return;
+    if (q >= nq) { if (lane == 0) theta0[q] = pos_inf(); return; }
+    const int n = nblk * 2;
+    uint32_t key[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = lane + u * 64;
+        const float v = top2[(size_t)q * n + (i < n ? i : n - 1)];      // unconditional (clamped) loads: all in flight
+        key[u] = (i < n && v > neg_inf()) ? f32_order_key(v) : 0u;       // 0 = padding, below every real key
+    }
+    uint32_t valid = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) valid += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(key[u] != 0u));
+    const uint32_t kth = wave_kth_key<8>(key, (uint32_t)k, 22);
+    if (lane == 0) theta0[q] = (valid >= (uint32_t)k) ? prune_threshold(f32_from_order_key(kth), qeps[q]) : neg_inf();
 }
 
 }  // namespace atlas

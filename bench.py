@@ -166,7 +166,7 @@ def main():
         from oracle import ref_port   # checker/baseline only; never on the product path
 
         n = min(args.cpu_sample, rows)
-        cpu = ref_port.time_reference_flat(slab[:n].cpu(), q.cpu(), k, args.cpu_seconds)
+        cpu = ref_port.time_reference_flat(slab[:n].cpu(), q.cpu(), k, args.cpu_seconds, workload_rows=args.passages)
 
     if rank == 0:
         algo_bytes = rows * D * 2

@@ -16,7 +16,7 @@
  *
  * Canonical result (what "top-k" means here):
  *   score(q,p) = RNE_fp16( sum_k fp16(q_k) * p_k ) with the sum taken in double in a
- *                fixed 8-chain order (bit-reproducible; = the correctly rounded fp16 of
+ *                fixed 64-chain order (bit-reproducible; = the correctly rounded fp16 of
  *                the exact inner product except with probability ~1e-13 per score)
  *   order      = (score desc, passage row asc)          -- ties: lowest row first
  *   The reference computes fp16(fp32-accumulated sum) with backend-defined summation

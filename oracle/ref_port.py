@@ -20,25 +20,45 @@ def reference_flat_search(q: torch.Tensor, embeddings_dN: torch.Tensor, topk: in
     return torch.topk(scores, topk, dim=1)
 
 
-def time_reference_flat(slab_rows: torch.Tensor, q: torch.Tensor, topk: int, budget_s: float) -> dict:
-    """slab_rows: (n, 768) fp16 CPU sample of the workload; returns the cpu_baseline JSON object."""
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    emb = slab_rows.T.contiguous()          # the reference's (d, n) layout (index.py:51)
-    n = emb.shape[1]
-    reference_flat_search(q, emb, topk)     # warm-up
+def _time(fn, min_runs, budget_s, max_runs=20):
+    fn()                                     # warm-up
     times = []
     t_end = time.perf_counter() + budget_s
-    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 50):
+    while len(times) < min_runs or (time.perf_counter() < t_end and len(times) < max_runs):
         t0 = time.perf_counter()
-        reference_flat_search(q, emb, topk)
+        fn()
         times.append(time.perf_counter() - t0)
     times.sort()
-    med = times[len(times) // 2]
+    return times[len(times) // 2], len(times)
+
+
+def time_reference_flat(slab_rows: torch.Tensor, q: torch.Tensor, topk: int, budget_s: float, workload_rows: int = None) -> dict:
+    """slab_rows: (n, 768) fp16 CPU rows of the workload; returns the cpu_baseline JSON object.
+
+    The sample is bounded to about `budget_s` of CPU work: a 20k-row probe sets the sample size. `value` is
+    queries/s scaled to `workload_rows` (time is linear in rows: one GEMM column and one top-k element per row);
+    the raw measurement is kept next to it.
+    """
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n_all = slab_rows.shape[0]
+    workload_rows = workload_rows or n_all
+    probe_n = min(20_000, n_all)
+    probe = slab_rows[:probe_n].T.contiguous()          # the reference's (d, n) layout (index.py:51)
+    t_probe, _ = _time(lambda: reference_flat_search(q, probe, topk), 1, 0.0)
+    n = int(min(n_all, max(probe_n, probe_n * (budget_s / 5.0) / max(t_probe, 1e-6))))
+    emb = slab_rows[:n].T.contiguous()
+    med, runs = _time(lambda: reference_flat_search(q, emb, topk), 2, budget_s * 0.6)
+    # secondary line: the same two calls in fp32 ("FAISS-equivalent arithmetic", NOT FAISS; BASELINE.md §3 line B)
+    emb32 = emb.float()
+    q32 = q.float()
+    med32, runs32 = _time(lambda: torch.topk(torch.matmul(q32, emb32), topk, dim=1), 2, budget_s * 0.2)
     return {
-        "value": q.shape[0] / med, "unit": "queries/s", "cores": cores, "kind": "port",
+        "value": q.shape[0] / med * (n / workload_rows), "unit": "queries/s", "cores": cores, "kind": "port",
         "sample": f"first {n} rows of the workload x 768 fp16, {q.shape[0]} queries, top-{topk}; "
-                  f"torch.matmul(fp16)+torch.topk (src/index.py:117-118), median of {len(times)} runs, "
-                  f"{torch.get_num_threads()} threads",
-        "seconds_per_batch": med, "rows": n,
+                  f"torch.matmul(fp16)+torch.topk (src/index.py:117-118) on the host, median of {runs} runs, "
+                  f"{torch.get_num_threads()} threads; value = measured rate x {n}/{workload_rows} rows",
+        "measured_queries_per_s_on_sample": q.shape[0] / med, "seconds_per_batch_on_sample": med, "rows": n,
+        "fp32_arith_queries_per_s_scaled": q.shape[0] / med32 * (n / workload_rows),
+        "fp32_note": "same two torch calls in fp32 (what FAISS IndexFlatIP computes); NOT FAISS (not installed, not a reference path)",
     }

@@ -81,19 +81,20 @@ def test_query_dtypes_match_half_cast(gpu_index_cls, oracle_mod):
         parity.assert_identical(s.cpu().numpy(), i.cpu().numpy(), es, ei, str(qq.dtype))
 
 
-def test_mass_ties_take_the_exact_path(gpu_index_cls, oracle_mod):
-    """1000 identical rows straddling the cut: the candidate band overflows, the query is redone exactly;
-    canonical order returns the lowest ids."""
-    P = synth.passages_f16(3000, 768, 83)
-    P[500:1500] = P[7]
-    Q = P[7:8].astype(np.float32) * 30.0                  # the duplicated row is the best match
-    Q = np.concatenate([Q, synth.queries_f32(3, 768, 84)])
-    idx = _index(gpu_index_cls, P)
-    s, i = _search(idx, Q, 40)
-    es, ei = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, 40)
-    parity.assert_identical(s, i, es, ei, "mass ties")
-    assert i[0, 0] == 7 and i[0, 1:40].tolist() == list(range(500, 539))
-    assert idx.last_search_stats["fallback_queries"] >= 1
+def test_mass_ties(gpu_index_cls, oracle_mod):
+    """Many identical rows straddling the cut. 1000 of them fit the candidate band (all are rescored, the lowest
+    ids win); 3000 overflow it, the query is flagged and redone on the exact path. Same canonical answer."""
+    for ndup, expect_fallback in ((1000, False), (3000, True)):
+        P = synth.passages_f16(6000, 768, 83)
+        P[500 : 500 + ndup] = P[7]
+        Q = P[7:8].astype(np.float32) * 30.0                  # the duplicated row is the best match
+        Q = np.concatenate([Q, synth.queries_f32(3, 768, 84)])
+        idx = _index(gpu_index_cls, P)
+        s, i = _search(idx, Q, 40)
+        es, ei = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, 40)
+        parity.assert_identical(s, i, es, ei, f"mass ties {ndup}")
+        assert i[0, 0] == 7 and i[0, 1:40].tolist() == list(range(500, 539))
+        assert (idx.last_search_stats["fallback_queries"] >= 1) == expect_fallback, idx.last_search_stats
 
 
 def test_degenerate_slabs(gpu_index_cls, oracle_mod):
@@ -151,6 +152,31 @@ def test_search_knn_returns_reference_types(gpu_index_cls, oracle_mod):
     assert [[d["id"] for d in row] for row in docs] == [[str(x) for x in row] for row in ei.tolist()]
     assert docs[0][0] is passages[ei[0, 0]] and isinstance(scores[0][0], float)
     assert scores == es.astype(np.float32).tolist()
+
+
+def test_device_f64_to_f16_conversions(gpu_index_cls, oracle_mod):
+    """both device double->fp16 paths (bit-level, and hardware round-to-odd + v_cvt_f16_f32) are single RNE roundings"""
+    from atlas_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(7)
+    allh = np.arange(0, 0x7C00, dtype=np.uint16).view(np.float16).astype(np.float64)
+    mids = (allh[:-1] + allh[1:]) / 2
+    x = np.concatenate([mids, np.nextafter(mids, 0), np.nextafter(mids, np.inf), allh,
+                        mids * (1 + 2.0 ** -30), mids * (1 - 2.0 ** -30),            # inside one float ulp of a tie
+                        rng.standard_normal(200000) * np.exp(rng.uniform(-25, 13, 200000)),
+                        [0.0, 65504.0, 65519.999, 65520.0, 65536.0, 1e300, 2.0 ** -25, 2.0 ** -25 * (1 + 1e-12), 5e-324, np.inf]])
+    x = np.concatenate([x, -x])
+    xd = torch.from_numpy(x).cuda()
+    out = torch.empty(2 * x.size, dtype=torch.int16, device="cuda")
+    L.atlas_dbg_f64_to_f16.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    assert L.atlas_dbg_f64_to_f16(xd.data_ptr(), out.data_ptr(), x.size, None) == 0
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint16).reshape(-1, 2)
+    with np.errstate(over="ignore"):
+        want = x.astype(np.float16).view(np.uint16)
+    assert np.array_equal(got[:, 0], want), np.argwhere(got[:, 0] != want)[:5]
+    assert np.array_equal(got[:, 1], want), (np.argwhere(got[:, 1] != want)[:5], x[got[:, 1] != want][:5])
 
 
 def test_pack_merge_kernels_match_host(gpu_index_cls):

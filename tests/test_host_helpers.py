@@ -17,6 +17,8 @@ def H():
     L.h_f16_to_f64.argtypes = [ctypes.c_uint16]
     L.h_f64_to_f16.restype = ctypes.c_uint16
     L.h_f64_to_f16.argtypes = [ctypes.c_double]
+    L.h_f64_to_f16_rto.restype = ctypes.c_uint16
+    L.h_f64_to_f16_rto.argtypes = [ctypes.c_double]
     L.h_f32_to_f16.restype = ctypes.c_uint16
     L.h_f32_to_f16.argtypes = [ctypes.c_float]
     L.h_bf16_to_f16.restype = ctypes.c_uint16
@@ -63,7 +65,7 @@ def test_f64_to_f16_rounding(H, oracle_mod):
     for x in xs:
         a, b = H.h_f64_to_f16(float(x)), O.oracle_f64_to_f16(float(x))
         n = int(np.float64(x).astype(np.float16).view(np.uint16))
-        assert a == b == n, (x, a, b, n)
+        assert a == b == n == H.h_f64_to_f16_rto(float(x)), (x, a, b, n, H.h_f64_to_f16_rto(float(x)))
     assert H.h_f64_to_f16(float("nan")) & 0x7C00 == 0x7C00
 
 

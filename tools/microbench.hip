@@ -105,12 +105,13 @@ static float run_scan(const void* slab, int64_t N, const void* qfrag, const void
     unsigned char* w = (unsigned char*)ws;
     ScanParams sp{};
     sp.slab = (const uint16_t*)slab; sp.N = N; sp.qfrag = (const uint4*)qfrag; sp.qeps = (const float*)qeps; sp.theta0 = (const float*)theta0;
-    sp.gstat = (uint32_t*)w; sp.qflag = (uint32_t*)(w + 256); sp.counts = (uint32_t*)(w + 512);
-    sp.lists = (uint2*)(w + 512 + 256 * 64 * 4);
+    sp.gstat = (uint32_t*)w; sp.qflag = (uint32_t*)(w + 256); sp.dense_cnt = (uint32_t*)(w + 512);
+    sp.dense = (uint2*)(w + 1024); sp.dense_cap = 32768;
+    sp.lists = (uint2*)(w + 1024 + 64 * 32768 * 8);
     sp.rows_per_wg = pl.rows_per_wg; sp.nq = nq; sp.k = k; sp.cap = pl.cap; sp.keep_max = pl.keep_max; sp.buf_cap = pl.buf_cap; sp.pmax2_hint = 4.0f;
     auto kern = scan_kernel<NW, PF, RING>;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    return time_ms([&] { hipMemsetAsync(w, 0, 512, 0); hipLaunchKernelGGL(kern, dim3(pl.G), dim3(NW * 64), pl.lds, 0, sp); }, iters);
+    return time_ms([&] { hipMemsetAsync(w, 0, 1024, 0); hipLaunchKernelGGL(kern, dim3(pl.G), dim3(NW * 64), pl.lds, 0, sp); }, iters);
 }
 
 extern "C" float mb_scan(int variant, const void* slab, int64_t N, const void* qfrag, const void* qeps, const void* theta0, void* ws, int nq, int k, int iters) {
