@@ -170,6 +170,16 @@ def main():
 
     if rank == 0:
         algo_bytes = rows * D * 2
+        # HBM traffic per launch from the committed PMC pass (profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE in
+        # its own run, calibrated against a known-size stream as the microarch guide prescribes); null if that shard
+        # size / kernel variant was not profiled
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pmc.get("kernel") == L.atlas_build_info().decode().split()[2]:
+                traffic = pmc["per_rows"].get(str(rows), {}).get("traffic_bytes")
+        except Exception:
+            traffic = None
         achieved = algo_bytes / (scan_ms * 1e-3) / 1e9
         line = {
             "metric": "queries/sec, exact MIPS d=768 top-40 (index search hot path)",
@@ -192,7 +202,7 @@ def main():
             },
             "roofline": {
                 "kernel": L.atlas_build_info().decode().split()[2], "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch (PMC FETCH_SIZE, calibrated)",
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_mean": scan_ms, "kernel_ms_min": scan_ms_min,
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
             },
