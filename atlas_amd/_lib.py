@@ -25,7 +25,23 @@ SYMBOLS = [
     "atlas_exact_topk_workspace_bytes", "atlas_exact_topk",
     "atlas_pack_candidates", "atlas_merge_packed",
     "atlas_pool_write", "atlas_slab_pmax",
+    "atlas_contriever_workspace_bytes", "atlas_contriever_embed",
 ]
+
+BERT_MAX_LAYERS = 24
+
+
+class BertLayerW(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("qkv_w", "qkv_b", "o_w", "o_b", "ln1_w", "ln1_b", "ff1_w", "ff1_b",
+                                               "ff2_w", "ff2_b", "ln2_w", "ln2_b")]
+
+
+class BertWeights(ctypes.Structure):
+    _fields_ = [("n_layers", ctypes.c_int), ("n_heads", ctypes.c_int), ("hidden", ctypes.c_int),
+                ("intermediate", ctypes.c_int), ("eps", ctypes.c_float),
+                ("word_emb", ctypes.c_void_p), ("pos_emb", ctypes.c_void_p), ("type_emb", ctypes.c_void_p),
+                ("emb_ln_w", ctypes.c_void_p), ("emb_ln_b", ctypes.c_void_p),
+                ("layers", BertLayerW * BERT_MAX_LAYERS)]
 
 
 class AtlasHipError(RuntimeError):
@@ -68,6 +84,10 @@ def lib():
     L.atlas_merge_packed.argtypes = [vp, i32, i32, i32, vp, vp]
     L.atlas_pool_write.restype = i32
     L.atlas_pool_write.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, vp]
+    L.atlas_contriever_workspace_bytes.restype = sz
+    L.atlas_contriever_workspace_bytes.argtypes = [i32, i32]
+    L.atlas_contriever_embed.restype = i32
+    L.atlas_contriever_embed.argtypes = [ctypes.POINTER(BertWeights), vp, vp, vp, i32, i32, vp, vp, sz, vp]
     L.atlas_slab_pmax.restype = i32
     L.atlas_slab_pmax.argtypes = [vp, i64, i32, vp, vp]
     if L.atlas_abi_version() != ABI_VERSION:

@@ -1,0 +1,272 @@
+"""Contriever retriever with the reference's module surface (src/retrievers.py), HIP passage encoder underneath.
+
+What is mirrored (same names, argument meaning, state-dict keys):
+    EMBEDDINGS_DIM                       retrievers.py:13
+    Contriever(config, pooling="average").forward(input_ids, attention_mask, token_type_ids, ..., normalize=False)
+                                         retrievers.py:16-60  (HF BertModel parameter names, so checkpoints
+                                         `retriever.contriever.*` load unchanged, model_io.py:62-71)
+    BaseRetriever / DualEncoderRetriever / UntiedDualEncoderRetriever   retrievers.py:63-135
+
+What runs on the GPU: the fp16 inference copy that `Atlas.build_index` / `retrieve_with_rerank` create with
+`copy.deepcopy(retriever).half().eval()` (atlas.py:54-59, 78, 168) — i.e. every passage embedding of an index
+refresh — goes through the C-ABI `atlas_contriever_embed` (hand-written MFMA GEMMs, fused attention, the
+reference's non-standard LayerNorm, pooling). There is no eager-PyTorch fallback for that path.
+
+Not provided yet (raises AtlasHipError): forward in fp32/bf16 or with autograd (query embedding in model
+precision and retriever training, atlas.py:104, 457-465) — SURVEY.md §8 "next"; the reference module keeps
+serving those until a fp32 HIP encoder exists.
+"""
+import copy
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+EMBEDDINGS_DIM: int = 768
+
+
+class BertConfigLite:
+    """the fields of the HF BertConfig this path reads (facebook/contriever = BERT-base, README.md:267-274)"""
+
+    def __init__(self, vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12,
+                 initializer_range=0.02, pad_token_id=0, pooling="average"):
+        self.__dict__.update(locals())
+        del self.__dict__["self"]
+
+
+class _LayerNormParams(nn.Module):        # parameters of modeling_bert.py:94-103 (the arithmetic lives in encoder.hip)
+    def __init__(self, hidden_size, eps):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.bias = nn.Parameter(torch.zeros(hidden_size))
+        self.variance_epsilon = eps
+
+
+class _Embeddings(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(c.vocab_size, c.hidden_size, padding_idx=c.pad_token_id)
+        self.position_embeddings = nn.Embedding(c.max_position_embeddings, c.hidden_size)
+        self.token_type_embeddings = nn.Embedding(c.type_vocab_size, c.hidden_size)
+        self.LayerNorm = _LayerNormParams(c.hidden_size, c.layer_norm_eps)
+
+
+class _SelfAttention(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.query = nn.Linear(c.hidden_size, c.hidden_size)
+        self.key = nn.Linear(c.hidden_size, c.hidden_size)
+        self.value = nn.Linear(c.hidden_size, c.hidden_size)
+
+
+class _DenseLN(nn.Module):
+    def __init__(self, c, in_features):
+        super().__init__()
+        self.dense = nn.Linear(in_features, c.hidden_size)
+        self.LayerNorm = _LayerNormParams(c.hidden_size, c.layer_norm_eps)
+
+
+class _Attention(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.self = _SelfAttention(c)
+        self.output = _DenseLN(c, c.hidden_size)
+
+
+class _Intermediate(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(c.hidden_size, c.intermediate_size)
+
+
+class _Layer(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.attention = _Attention(c)
+        self.intermediate = _Intermediate(c)
+        self.output = _DenseLN(c, c.intermediate_size)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.layer = nn.ModuleList([_Layer(c) for _ in range(c.num_hidden_layers)])
+
+
+class Contriever(nn.Module):
+    def __init__(self, config=None, pooling="average", **kwargs):
+        super().__init__()
+        self.config = config or BertConfigLite()
+        if not hasattr(self.config, "pooling"):
+            self.config.pooling = pooling
+        self.embeddings = _Embeddings(self.config)
+        self.encoder = _Encoder(self.config)
+        self._packed = None          # (key, BertWeights struct, tensors kept alive)
+        self._ws = None
+
+    # ---- weights -> C-ABI struct (fused QKV), cached until a parameter changes ----
+    def _pack(self):
+        params = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._packed is not None and self._packed[0] == key:
+            return self._packed[1]
+        c = self.config
+        keep = []
+
+        def dev(t):
+            t = t.detach().contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        w = _lib.BertWeights()
+        w.n_layers, w.n_heads, w.hidden, w.intermediate = c.num_hidden_layers, c.num_attention_heads, c.hidden_size, c.intermediate_size
+        w.eps = float(c.layer_norm_eps)
+        e = self.embeddings
+        w.word_emb, w.pos_emb, w.type_emb = dev(e.word_embeddings.weight), dev(e.position_embeddings.weight), dev(e.token_type_embeddings.weight)
+        w.emb_ln_w, w.emb_ln_b = dev(e.LayerNorm.weight), dev(e.LayerNorm.bias)
+        for i, ly in enumerate(self.encoder.layer):
+            s = ly.attention.self
+            lw = w.layers[i]
+            lw.qkv_w = dev(torch.cat([s.query.weight, s.key.weight, s.value.weight], dim=0))
+            lw.qkv_b = dev(torch.cat([s.query.bias, s.key.bias, s.value.bias], dim=0))
+            lw.o_w, lw.o_b = dev(ly.attention.output.dense.weight), dev(ly.attention.output.dense.bias)
+            lw.ln1_w, lw.ln1_b = dev(ly.attention.output.LayerNorm.weight), dev(ly.attention.output.LayerNorm.bias)
+            lw.ff1_w, lw.ff1_b = dev(ly.intermediate.dense.weight), dev(ly.intermediate.dense.bias)
+            lw.ff2_w, lw.ff2_b = dev(ly.output.dense.weight), dev(ly.output.dense.bias)
+            lw.ln2_w, lw.ln2_b = dev(ly.output.LayerNorm.weight), dev(ly.output.LayerNorm.bias)
+        self._packed = (key, w, keep)
+        return w
+
+    def _check_accelerated(self):
+        p = self.embeddings.word_embeddings.weight
+        if p.dtype != torch.float16 or not p.is_cuda:
+            raise _lib.AtlasHipError(
+                "atlas_amd.Contriever runs the fp16 inference copy on an MI355X only (the copy Atlas.build_index makes with "
+                ".half().eval()); fp32/bf16 or training forward is not implemented here yet and there is no eager fallback"
+            )
+        if self.config.pooling != "average":
+            raise _lib.AtlasHipError(f"pooling={self.config.pooling!r} is not implemented (atlas uses 'average')")
+
+    @torch.no_grad()
+    def embed_into(self, out: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor, token_type_ids=None):
+        """Encode a batch and write the (n, 768) fp16 embeddings into `out` (contiguous rows; may be a slice of
+        the index slab, which fuses atlas.py:79 into the pooling epilogue)."""
+        self._check_accelerated()
+        L = _lib.lib()
+        n, seq = input_ids.shape
+        assert out.dtype == torch.float16 and out.is_contiguous() and tuple(out.shape) == (n, EMBEDDINGS_DIM)
+        ids = input_ids.to(torch.int64).contiguous()
+        mask = attention_mask.to(torch.int64).contiguous()
+        tt = token_type_ids.to(torch.int64).contiguous() if token_type_ids is not None else None
+        w = self._pack()
+        need = L.atlas_contriever_workspace_bytes(n, seq)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != ids.device:
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=ids.device)
+        stream = torch.cuda.current_stream(ids.device).cuda_stream
+        _lib.check(L.atlas_contriever_embed(ctypes.byref(w), ids.data_ptr(), mask.data_ptr(), tt.data_ptr() if tt is not None else None,
+                                            n, seq, out.data_ptr(), self._ws.data_ptr(), self._ws.numel(), stream),
+                   "atlas_contriever_embed")
+        return out
+
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
+                inputs_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None, output_attentions=None,
+                output_hidden_states=None, normalize=False):
+        """retrievers.py:22-60. Only the arguments atlas.py passes are supported (ids, mask, token_type_ids)."""
+        assert position_ids is None and head_mask is None and inputs_embeds is None and encoder_hidden_states is None
+        out = torch.empty((input_ids.shape[0], EMBEDDINGS_DIM), dtype=torch.float16, device=input_ids.device)
+        self.embed_into(out, input_ids, attention_mask, token_type_ids)
+        if normalize:
+            out = torch.nn.functional.normalize(out, dim=-1).clone()
+        return out
+
+    def gradient_checkpointing_enable(self):     # retrievers.py:81-87 calls these on children
+        pass
+
+    def gradient_checkpointing_disable(self):
+        pass
+
+    def __deepcopy__(self, memo):                # atlas.py:59 deep-copies the retriever: drop the packed cache
+        new = type(self).__new__(type(self))
+        memo[id(self)] = new
+        nn.Module.__init__(new)
+        for k, v in self.__dict__.items():
+            if k in ("_packed", "_ws"):
+                new.__dict__[k] = None
+            else:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
+
+class BaseRetriever(torch.nn.Module):
+    """A retriever needs to be able to embed queries and passages, and have a forward function (retrievers.py:63-87)"""
+
+    def __init__(self, *args, **kwargs):
+        super(BaseRetriever, self).__init__()
+
+    def embed_queries(self, *args, **kwargs):
+        raise NotImplementedError()
+
+    def embed_passages(self, *args, **kwargs):
+        raise NotImplementedError()
+
+    def forward(self, *args, is_passages=False, **kwargs):
+        if is_passages:
+            return self.embed_passages(*args, **kwargs)
+        else:
+            return self.embed_queries(*args, **kwargs)
+
+    def gradient_checkpointing_enable(self):
+        for m in self.children():
+            m.gradient_checkpointing_enable()
+
+    def gradient_checkpointing_disable(self):
+        for m in self.children():
+            m.gradient_checkpointing_disable()
+
+
+class DualEncoderRetriever(BaseRetriever):
+    """Wrapper for standard contriever, or other dual encoders that parameter-share (retrievers.py:90-105)"""
+
+    def __init__(self, opt, contriever):
+        super(DualEncoderRetriever, self).__init__()
+        self.opt = opt
+        self.contriever = contriever
+
+    def _embed(self, *args, **kwargs):
+        return self.contriever(*args, **kwargs)
+
+    def embed_queries(self, *args, **kwargs):
+        return self._embed(*args, **kwargs)
+
+    def embed_passages(self, *args, **kwargs):
+        return self._embed(*args, **kwargs)
+
+
+class UntiedDualEncoderRetriever(BaseRetriever):
+    """Like DualEncoderRetriever, but dedicated encoders for passage and query embedding (retrievers.py:108-135)"""
+
+    def __init__(self, opt, query_encoder, passage_encoder=None):
+        super(UntiedDualEncoderRetriever, self).__init__()
+        self.opt = opt
+        self.query_contriever = query_encoder
+        if passage_encoder is None:
+            passage_encoder = copy.deepcopy(query_encoder) if hasattr(query_encoder, "module") else query_encoder
+        self.passage_contriever = passage_encoder
+
+    def embed_queries(self, *args, **kwargs):
+        return self.query_contriever(*args, **kwargs)
+
+    def embed_passages(self, *args, **kwargs):
+        if self.opt.query_side_retriever_training:
+            is_train = self.passage_contriever.training
+            self.passage_contriever.eval()
+            with torch.no_grad():
+                passage_emb = self.passage_contriever(*args, **kwargs)
+            if is_train:
+                self.passage_contriever.train()
+        else:
+            passage_emb = self.passage_contriever(*args, **kwargs)
+        return passage_emb

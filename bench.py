@@ -66,11 +66,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # ATLAS_BENCH_BACKEND=gloo is a logic check only (ranks may then share one GPU); production = nccl (RCCL)
+    backend = os.environ.get("ATLAS_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     from atlas_amd import HipDistributedIndex, _lib
 
@@ -119,7 +125,13 @@ def main():
         if world > 1:
             rc = L.atlas_pack_candidates(out_s.data_ptr(), out_i.data_ptr(), B * k, world, rank, packed.data_ptr(), stream)
             assert rc == 0, rc
-            dist.all_gather_into_tensor(gathered, packed)
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gathered, packed)          # ONE collective: 8*B*k bytes per rank
+            else:                                                       # gloo logic check: stage through the host
+                hp = packed.cpu()
+                hg = torch.empty((world * B, k), dtype=torch.int64)
+                dist.all_gather_into_tensor(hg, hp)
+                gathered.copy_(hg)
             rc = L.atlas_merge_packed(gathered.data_ptr(), world, B, k, merged.data_ptr(), stream)
             assert rc == 0, rc
 
@@ -128,6 +140,11 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def reduce_max(x: float) -> float:
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     for _ in range(args.warmup):
         step()
@@ -138,21 +155,22 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = reduce_max(dt)
 
     # the timed steps must have produced certified results
     st = out_st.cpu().numpy()
     assert int(st[_lib.ST_FLAGS]) == 0, f"status flags {int(st[_lib.ST_FLAGS])} in the timed region"
     assert torch.equal(out_s, s0) and torch.equal(out_i, i0), "timed steps disagree with the checked call"
 
+    if world > 1:
+        from atlas_amd.index import merge_packed_host
+        want = merge_packed_host(gathered.view(world, B, k).cpu().numpy(), k)
+        assert np.array_equal(merged.cpu().numpy(), want), "device W*k merge disagrees with the host merge"
+
     scan_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     scan_ms_min = float(np.min([a.elapsed_time(b) for a, b in evs]))
     if world > 1:   # slowest rank's kernel
-        t = torch.tensor([scan_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        scan_ms = float(t.item())
+        scan_ms = reduce_max(scan_ms)
 
     # synchronous latency of the full product call (host sync + D2H of results + status check), for DESIGN.md
     torch.cuda.synchronize()

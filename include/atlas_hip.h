@@ -136,6 +136,33 @@ int atlas_merge_packed(const uint64_t* gathered, int W, int B, int k, uint64_t* 
 int atlas_pool_write(const void* hidden_f16, const int64_t* mask, void* slab_f16, int64_t N,
                      int64_t row_offset, int n, int L, int d, void* stream);
 
+/* ---- index refresh: Contriever passage encoder (replaces src/retrievers.py:22-60 + src/modeling_bert.py) -----
+ * The fp16 inference copy `copy.deepcopy(retriever).half().eval()` of Atlas.build_index (src/atlas.py:54-59,78):
+ * BERT-base encoder (12 x [QKV, attention with fp32 softmax, out-proj + residual + LayerNorm, FFN with exact-erf
+ * GELU + residual + LayerNorm]; the reference's NON-standard LayerNorm, modeling_bert.py:104-114) + masked mean
+ * pooling, every intermediate rounded to fp16 where the reference materialises an fp16 tensor.
+ * All weights are fp16 device pointers, Linear weights row-major [out][in] as in the HF state dict;
+ * qkv_w = rows of query.weight | key.weight | value.weight ([2304][768]), qkv_b likewise.
+ *   input_ids, attention_mask, token_type_ids (nullable): int64 [n x L] device tensors (HF tokenizer output)
+ *   out_f16: [n x 768] fp16 rows, contiguous; may point into the passage slab (slab + row_offset*768), which
+ *            makes the refresh write atlas.py:79 part of the pooling epilogue
+ * Supports hidden=768, heads=12, intermediate=3072, L <= 512 (BERT_MAX_SEQ_LENGTH, atlas.py:23); else UNSUPPORTED.
+ */
+#define ATLAS_BERT_MAX_LAYERS 24
+typedef struct {
+    const void *qkv_w, *qkv_b, *o_w, *o_b, *ln1_w, *ln1_b, *ff1_w, *ff1_b, *ff2_w, *ff2_b, *ln2_w, *ln2_b;
+} atlas_bert_layer;
+typedef struct {
+    int n_layers, n_heads, hidden, intermediate;
+    float eps;                                   /* config.layer_norm_eps */
+    const void *word_emb, *pos_emb, *type_emb, *emb_ln_w, *emb_ln_b;
+    atlas_bert_layer layers[ATLAS_BERT_MAX_LAYERS];
+} atlas_bert_weights;
+size_t atlas_contriever_workspace_bytes(int n, int L);
+int atlas_contriever_embed(const atlas_bert_weights* w /* host struct of device pointers */, const int64_t* input_ids,
+                           const int64_t* attention_mask, const int64_t* token_type_ids, int n, int L, void* out_f16,
+                           void* ws, size_t ws_bytes, void* stream);
+
 /* ---- slab statistics ------------------------------------------------------------
  * out_pmax (device float): max L2 norm over rows [0,N). One streaming pass; lets a caller
  * obtain a certified pmax_hint up front instead of via the violation/re-run protocol.
