@@ -110,33 +110,33 @@ ln_kernel(const uint16_t* __restrict__ in, int64_t M, const uint16_t* __restrict
 template <int EPI>
 __global__ void __launch_bounds__(256)
 gemm_bt_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const uint16_t* __restrict__ bias,
-               const uint16_t* __restrict__ R, uint16_t* __restrict__ C, int64_t M, int N, int K) {
+               const uint16_t* __restrict__ R, uint16_t* __restrict__ C, uint16_t* __restrict__ VT, int64_t M, int N, int K,
+               int L, int Lp) {
     __shared__ __attribute__((aligned(16))) uint4 sW[2][128 * 8];
     __shared__ __attribute__((aligned(16))) uint4 sA[2][128 * 8];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave >> 1, wj = wave & 1;
     const int n0 = blockIdx.x * 128;
     const int64_t m0 = (int64_t)blockIdx.y * 128;
     const int lr = lane & 15, lg = lane >> 4;
 
-    // staging: chunk idx = tid + 256*i -> row idx>>3, 16-B chunk idx&7
-    uint4 rw[4], ra[4];
-    auto gload = [&](int k0) {
+    // global -> LDS without registers (global_load_lds_dwordx4): one wave instruction writes 1 KiB of LDS,
+    // lane-linear, = 8 tile rows x 128 B. The bank-conflict swizzle therefore goes on the SOURCE address:
+    // LDS[row][c] receives global chunk c ^ (row & 7); fragment reads apply the same XOR (cdna guide rule 21).
+    auto stage = [&](const int buf, const int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 3, ch = idx & 7;
-            rw[i] = *(const uint4*)(W + (size_t)(n0 + row) * K + k0 + ch * 8);
+            const int rowbase = (wave * 4 + i) * 8;
+            const int row = rowbase + (lane >> 3), ch = (lane & 7) ^ (lane >> 3);
+            const uint16_t* gw = W + (size_t)(n0 + row) * K + k0 + ch * 8;
             int64_t ar = m0 + row;
             if (ar >= M) ar = M - 1;                                   // clamped: tail rows are never stored
-            ra[i] = *(const uint4*)(A + (size_t)ar * K + k0 + ch * 8);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 3, ch = idx & 7;
-            sW[buf][row * 8 + (ch ^ (row & 7))] = rw[i];
-            sA[buf][row * 8 + (ch ^ (row & 7))] = ra[i];
+            const uint16_t* ga = A + (size_t)ar * K + k0 + ch * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw,
+                                             (__attribute__((address_space(3))) void*)&sW[buf][rowbase * 8], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
+                                             (__attribute__((address_space(3))) void*)&sA[buf][rowbase * 8], 16, 0, 0);
         }
     };
 
@@ -146,13 +146,12 @@ gemm_bt_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    gload(0);
-    lstore(0);
-    __syncthreads();
+    stage(0, 0);
+    __syncthreads();                                   // (drains the LDS-DMA: hipcc puts vmcnt(0) in front of the barrier)
     const int nk = K / 64;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * 64);
+        if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * 64);   // next tile streams in while this one is multiplied
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             h8 fw[4], fa[4];
@@ -172,15 +171,17 @@ gemm_bt_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                 for (int b = 0; b < 4; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[a], fa[b], acc[a][b], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
 
     // epilogue: acc[a][b][r] = C[token m0+64wj+16b+lr][col n0+64wi+16a+4lg+r]
+    const bool v_part = (EPI == 3) && (n0 >= 2 * HID);      // QKV projection: the V columns are stored transposed
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int64_t tok = m0 + wj * 64 + b * 16 + lr;
         if (tok >= M) continue;
+        const int64_t pb = (EPI == 3) ? tok / L : 0;
+        const int pos = (EPI == 3) ? (int)(tok - pb * L) : 0;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int col = n0 + wi * 64 + a * 16 + lg * 4;
@@ -199,124 +200,114 @@ gemm_bt_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
                 if (EPI == 2) v = rh(v) + h2f(rr[r]);                           // + input_tensor, fp16 add
                 o[r] = f2h(v);
             }
-            *(uint2*)(C + (size_t)tok * N + col) = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+            if (EPI == 3) {
+                if (v_part) {
+                    // V^T[passage][h*64+d][key]: the PV product wants consecutive KEYS per lane (attention_kernel)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) VT[((size_t)pb * HID + (col - 2 * HID + r)) * Lp + pos] = o[r];
+                } else {
+                    *(uint2*)(C + (size_t)tok * (2 * HID) + col) = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+                }
+            } else {
+                *(uint2*)(C + (size_t)tok * N + col) = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+            }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// attention: one block (4 waves) per (passage, head); QKV is [M][3*768] with q | k | v column blocks.
+// attention: one block (4 waves) per (passage, head). QK is [M][1536] (q | k), VT is [n][768][Lp] (V transposed).
 //   scores = fp16(q.k^T) ; / 8 (exact) ; + fp16 mask (0 / -10000) ; softmax in fp32 ; P = fp16 ; ctx = fp16(P.v)
-// K rows feed the MFMA B operand straight from global memory (8 consecutive head dims per lane); V is staged
-// TRANSPOSED in LDS ([64 dims][Lp keys]) because the PV product needs 8 consecutive keys per lane; P goes through
-// LDS once to turn the C-fragment layout into A fragments. Each wave owns query fragments w, w+4, ...
-// L <= 512; Lp = L rounded up to 32.
+// Everything stays in registers:
+//   S^T = K.Q^T on the matrix cores (A = K rows, B = Q rows) leaves lane (lr, lg) with query column lr and keys
+//   16kf+4lg+r -- so a softmax row is spread over only 4 lanes (xor 16, 32), and the SAME registers are already the
+//   A operand of P.V if the contraction index of that MFMA is enumerated as key(ks,g,e) = 32ks + 16(e/4) + 4g + e%4;
+//   V^T then supplies the matching B operand with two 8-byte loads of consecutive keys. No LDS round trip for P, no
+//   transposition of V here (the QKV GEMM epilogue wrote V^T).
+// L <= 512; Lp = L rounded up to 32; MAXKF = compile-time bound on Lp/16.
 // ------------------------------------------------------------------------------------------
+template <int MAXKF>
 __global__ void __launch_bounds__(256)
-attention_kernel(const uint16_t* __restrict__ qkv, const int64_t* __restrict__ mask, int L, uint16_t* __restrict__ ctx) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int Lp = (L + 31) & ~31;
-    uint16_t* sVt = (uint16_t*)smem;                          // [64][Lp + 8]  (+8 halfs pad: staggers banks)
-    const int vstride = Lp + 8;
-    uint16_t* sP = sVt + 64 * vstride;                        // [4 waves][16][Lp + 8]
-    float* sMask = (float*)(sP + 4 * 16 * vstride);           // [Lp] additive mask as fp32 (0 or -10000), -inf beyond L
+attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ vt, const int64_t* __restrict__ mask, int L, int Lp,
+                 uint16_t* __restrict__ ctx) {
+    __shared__ __attribute__((aligned(16))) float sMask[512];   // additive mask as fp32 (0 / -10000), -inf beyond L
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     const int b = blockIdx.x / NHEAD, h = blockIdx.x % NHEAD;
-    const uint16_t* base = qkv + (size_t)b * L * (3 * HID);
-    const uint16_t* Qb = base + h * DHEAD;
-    const uint16_t* Kb = base + HID + h * DHEAD;
-    const uint16_t* Vb = base + 2 * HID + h * DHEAD;
-
+    const uint16_t* Qb = qk + (size_t)b * L * (2 * HID) + h * DHEAD;
+    const uint16_t* Kb = Qb + HID;
+    const uint16_t* Vt = vt + ((size_t)b * HID + h * DHEAD) * Lp;
     for (int j = tid; j < Lp; j += 256)
         sMask[j] = (j < L) ? ((mask[(size_t)b * L + j] != 0) ? 0.0f : -10000.0f) : -__builtin_inff();
-    // V^T into LDS: thread handles (key j, 8-dim chunk c)
-    for (int idx = tid; idx < Lp * 8; idx += 256) {
-        const int j = idx >> 3, c = idx & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (j < L) v = *(const uint4*)(Vb + (size_t)j * (3 * HID) + c * 8);
-        const uint16_t e[8] = {(uint16_t)(v.x & 0xffff), (uint16_t)(v.x >> 16), (uint16_t)(v.y & 0xffff), (uint16_t)(v.y >> 16),
-                               (uint16_t)(v.z & 0xffff), (uint16_t)(v.z >> 16), (uint16_t)(v.w & 0xffff), (uint16_t)(v.w >> 16)};
-#pragma unroll
-        for (int d = 0; d < 8; ++d) sVt[(c * 8 + d) * vstride + j] = e[d];
-    }
     __syncthreads();
-
-    const int nkf = Lp / 16;                                   // key fragments (<= 32)
-    uint16_t* myP = sP + wave * 16 * vstride;
+    const int nkf = Lp / 16;
     for (int qf = wave; qf * 16 < L; qf += 4) {
-        // Q fragment: lane (row lr, k-group lg), 2 k-steps of 32 dims
         int qrow = qf * 16 + lr; if (qrow >= L) qrow = L - 1;
-        const h8 q0 = __builtin_bit_cast(h8, *(const uint4*)(Qb + (size_t)qrow * (3 * HID) + lg * 8));
-        const h8 q1 = __builtin_bit_cast(h8, *(const uint4*)(Qb + (size_t)qrow * (3 * HID) + 32 + lg * 8));
-        // S = Q K^T : MFMA(A = Q rows, B = K rows) -> lane holds key col lr of fragment kf, query rows 4lg+r
-        f4 s[32];
+        const h8 q0 = __builtin_bit_cast(h8, *(const uint4*)(Qb + (size_t)qrow * (2 * HID) + lg * 8));
+        const h8 q1 = __builtin_bit_cast(h8, *(const uint4*)(Qb + (size_t)qrow * (2 * HID) + 32 + lg * 8));
+        f4 s[MAXKF];
 #pragma unroll
-        for (int kf = 0; kf < 32; ++kf) {
+        for (int kf = 0; kf < MAXKF; ++kf) {
             s[kf] = (f4){0.f, 0.f, 0.f, 0.f};
             if (kf < nkf) {
                 int krow = kf * 16 + lr; if (krow >= L) krow = L - 1;
-                const h8 k0 = __builtin_bit_cast(h8, *(const uint4*)(Kb + (size_t)krow * (3 * HID) + lg * 8));
-                const h8 k1 = __builtin_bit_cast(h8, *(const uint4*)(Kb + (size_t)krow * (3 * HID) + 32 + lg * 8));
-                s[kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(q0, k0, s[kf], 0, 0, 0);
-                s[kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(q1, k1, s[kf], 0, 0, 0);
+                const h8 k0 = __builtin_bit_cast(h8, *(const uint4*)(Kb + (size_t)krow * (2 * HID) + lg * 8));
+                const h8 k1 = __builtin_bit_cast(h8, *(const uint4*)(Kb + (size_t)krow * (2 * HID) + 32 + lg * 8));
+                s[kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, q0, s[kf], 0, 0, 0);
+                s[kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, q1, s[kf], 0, 0, 0);
             }
         }
-        // softmax over keys for each of this lane's 4 query rows; a row's keys live in the 16 lanes sharing lg
-        float mx[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        float mx = -__builtin_inff();
 #pragma unroll
-        for (int kf = 0; kf < 32; ++kf)
+        for (int kf = 0; kf < MAXKF; ++kf)
             if (kf < nkf) {
-                const float am = sMask[kf * 16 + lr];
+                const float4 am = *(const float4*)(sMask + kf * 16 + lg * 4);
+                const float a4[4] = {am.x, am.y, am.z, am.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     // fp16(q.k) / sqrt(64) is exact in fp16; + mask is an fp16 add (modeling_bert.py:346-349)
-                    const float v = rh(rh(s[kf][r]) * 0.125f + am);
+                    const float v = rh(rh(s[kf][r]) * 0.125f + a4[r]);
                     s[kf][r] = v;
-                    mx[r] = fmaxf(mx[r], v);
+                    mx = fmaxf(mx, v);
                 }
             }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o));
-        float sum[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kf = 0; kf < 32; ++kf)
+        for (int kf = 0; kf < MAXKF; ++kf)
             if (kf < nkf) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = __expf(s[kf][r] - mx[r]);          // exp(-inf) = 0 for padded key columns
+                    const float e = __expf(s[kf][r] - mx);            // exp(-inf) = 0 for padded keys
                     s[kf][r] = e;
-                    sum[r] += e;
+                    sum += e;
                 }
             }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) sum[r] += __shfl_xor(sum[r], o);
-            sum[r] = 1.0f / sum[r];
-        }
-        // P (fp16) -> LDS [query row][key]
-#pragma unroll
-        for (int kf = 0; kf < 32; ++kf)
-            if (kf < nkf) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) myP[(lg * 4 + r) * vstride + kf * 16 + lr] = f2h(s[kf][r] * sum[r]);
-            }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): this wave's P is in LDS (same-wave reads follow)
-        // ctx = P V : MFMA(A = P rows [16 x keys], B = V^T rows [dims x keys]) -> lane holds dim col lr of fragment df, query rows 4lg+r
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        // ctx = P V, P straight from the registers above
         f4 o[4];
 #pragma unroll
         for (int df = 0; df < 4; ++df) o[df] = (f4){0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < Lp / 32; ++ks) {
-            const h8 pa = __builtin_bit_cast(h8, *(const uint4*)(myP + lr * vstride + ks * 32 + lg * 8));
 #pragma unroll
-            for (int df = 0; df < 4; ++df) {
-                const h8 vb = __builtin_bit_cast(h8, *(const uint4*)(sVt + (df * 16 + lr) * vstride + ks * 32 + lg * 8));
-                o[df] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, vb, o[df], 0, 0, 0);
+        for (int ks = 0; ks < MAXKF / 2; ++ks)
+            if (2 * ks < nkf) {
+                h8 pa;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pa[e] = (_Float16)(s[2 * ks][e] * inv);             // softmax(...).type_as(fp16)
+                    pa[4 + e] = (_Float16)(s[2 * ks + 1][e] * inv);
+                }
+#pragma unroll
+                for (int df = 0; df < 4; ++df) {
+                    const uint16_t* vrow = Vt + (size_t)(df * 16 + lr) * Lp + ks * 32 + lg * 4;
+                    const uint2 v0 = *(const uint2*)vrow, v1 = *(const uint2*)(vrow + 16);
+                    const h8 vb = __builtin_bit_cast(h8, make_uint4(v0.x, v0.y, v1.x, v1.y));
+                    o[df] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, vb, o[df], 0, 0, 0);
+                }
             }
-        }
         // context_layer.permute(0,2,1,3).view(.., 768): [token][h*64 + dim]
 #pragma unroll
         for (int df = 0; df < 4; ++df)
@@ -339,9 +330,9 @@ extern "C" {
 
 size_t atlas_contriever_workspace_bytes(int n, int L) {
     if (n <= 0 || L <= 0) return 0;
-    const size_t M = (size_t)n * L;
-    // x, ctx, u : [M,768]; qkv : [M,2304]; h : [M,3072]; pooled input reuses x
-    return up256(M * HID * 2) * 3 + up256(M * 3 * HID * 2) + up256(M * 4 * HID * 2) + 256;
+    const size_t M = (size_t)n * L, Lp = (size_t)((L + 31) & ~31);
+    // x, ctx, u : [M,768]; qk : [M,1536]; vt : [n,768,Lp]; h : [M,3072]
+    return up256(M * HID * 2) * 3 + up256(M * 2 * HID * 2) + up256((size_t)n * HID * Lp * 2) + up256(M * 4 * HID * 2) + 256;
 }
 
 int atlas_contriever_embed(const atlas_bert_weights* w, const int64_t* input_ids, const int64_t* attention_mask,
@@ -355,34 +346,40 @@ int atlas_contriever_embed(const atlas_bert_weights* w, const int64_t* input_ids
     if (ws_bytes < atlas_contriever_workspace_bytes(n, L)) return ATLAS_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t M = (int64_t)n * L;
+    const int Lp = (L + 31) & ~31;
     unsigned char* p = (unsigned char*)ws;
     uint16_t* x = (uint16_t*)p;   p += up256((size_t)M * HID * 2);
     uint16_t* ctx = (uint16_t*)p; p += up256((size_t)M * HID * 2);
     uint16_t* u = (uint16_t*)p;   p += up256((size_t)M * HID * 2);
-    uint16_t* qkv = (uint16_t*)p; p += up256((size_t)M * 3 * HID * 2);
+    uint16_t* qk = (uint16_t*)p;  p += up256((size_t)M * 2 * HID * 2);
+    uint16_t* vt = (uint16_t*)p;  p += up256((size_t)n * HID * Lp * 2);
     uint16_t* hbuf = (uint16_t*)p;
 
     const unsigned tok_blocks = (unsigned)((M + 3) / 4);
-    const dim3 mt((unsigned)((M + 127) / 128));
+    const unsigned mt = (unsigned)((M + 127) / 128);
+    // V^T pad columns [L, Lp) are read (times P = 0) but never written: keep them finite
+    if (Lp != L) { hipError_t e = hipMemsetAsync(vt, 0, (size_t)n * HID * Lp * 2, stream); if (e != hipSuccess) return (int)e; }
     hipLaunchKernelGGL(embed_ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, input_ids, token_type_ids, L, M,
                        (const uint16_t*)w->word_emb, (const uint16_t*)w->pos_emb, (const uint16_t*)w->type_emb,
                        (const uint16_t*)w->emb_ln_w, (const uint16_t*)w->emb_ln_b, w->eps, x);
-    const int Lp = (L + 31) & ~31;
-    const size_t att_lds = (size_t)(64 + 4 * 16) * (Lp + 8) * 2 + (size_t)Lp * 4;
-    (void)hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (int l = 0; l < w->n_layers; ++l) {
         const atlas_bert_layer& ly = w->layers[l];
-        hipLaunchKernelGGL(gemm_bt_kernel<0>, dim3(3 * HID / 128, mt.x), dim3(256), 0, stream, x, (const uint16_t*)ly.qkv_w,
-                           (const uint16_t*)ly.qkv_b, (const uint16_t*)nullptr, qkv, M, 3 * HID, HID);
-        hipLaunchKernelGGL(attention_kernel, dim3((unsigned)n * NHEAD), dim3(256), att_lds, stream, qkv, attention_mask, L, ctx);
-        hipLaunchKernelGGL(gemm_bt_kernel<2>, dim3(HID / 128, mt.x), dim3(256), 0, stream, ctx, (const uint16_t*)ly.o_w,
-                           (const uint16_t*)ly.o_b, x, u, M, HID, HID);
+        hipLaunchKernelGGL(gemm_bt_kernel<3>, dim3(3 * HID / 128, mt), dim3(256), 0, stream, x, (const uint16_t*)ly.qkv_w,
+                           (const uint16_t*)ly.qkv_b, (const uint16_t*)nullptr, qk, vt, M, 3 * HID, HID, L, Lp);
+        if (Lp <= 128)
+            hipLaunchKernelGGL(attention_kernel<8>, dim3((unsigned)n * NHEAD), dim3(256), 0, stream, qk, vt, attention_mask, L, Lp, ctx);
+        else if (Lp <= 256)
+            hipLaunchKernelGGL(attention_kernel<16>, dim3((unsigned)n * NHEAD), dim3(256), 0, stream, qk, vt, attention_mask, L, Lp, ctx);
+        else
+            hipLaunchKernelGGL(attention_kernel<32>, dim3((unsigned)n * NHEAD), dim3(256), 0, stream, qk, vt, attention_mask, L, Lp, ctx);
+        hipLaunchKernelGGL(gemm_bt_kernel<2>, dim3(HID / 128, mt), dim3(256), 0, stream, ctx, (const uint16_t*)ly.o_w,
+                           (const uint16_t*)ly.o_b, x, u, (uint16_t*)nullptr, M, HID, HID, L, Lp);
         hipLaunchKernelGGL(ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, u, M, (const uint16_t*)ly.ln1_w,
                            (const uint16_t*)ly.ln1_b, w->eps, x);
-        hipLaunchKernelGGL(gemm_bt_kernel<1>, dim3(4 * HID / 128, mt.x), dim3(256), 0, stream, x, (const uint16_t*)ly.ff1_w,
-                           (const uint16_t*)ly.ff1_b, (const uint16_t*)nullptr, hbuf, M, 4 * HID, HID);
-        hipLaunchKernelGGL(gemm_bt_kernel<2>, dim3(HID / 128, mt.x), dim3(256), 0, stream, hbuf, (const uint16_t*)ly.ff2_w,
-                           (const uint16_t*)ly.ff2_b, x, u, M, HID, 4 * HID);
+        hipLaunchKernelGGL(gemm_bt_kernel<1>, dim3(4 * HID / 128, mt), dim3(256), 0, stream, x, (const uint16_t*)ly.ff1_w,
+                           (const uint16_t*)ly.ff1_b, (const uint16_t*)nullptr, hbuf, (uint16_t*)nullptr, M, 4 * HID, HID, L, Lp);
+        hipLaunchKernelGGL(gemm_bt_kernel<2>, dim3(HID / 128, mt), dim3(256), 0, stream, hbuf, (const uint16_t*)ly.ff2_w,
+                           (const uint16_t*)ly.ff2_b, x, u, (uint16_t*)nullptr, M, HID, 4 * HID, L, Lp);
         hipLaunchKernelGGL(ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, u, M, (const uint16_t*)ly.ln2_w,
                            (const uint16_t*)ly.ln2_b, w->eps, x);
     }
