@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 #include "common.h"
 #include "../../include/atlas_hip.h"
@@ -107,44 +108,52 @@ ln_kernel(const uint16_t* __restrict__ in, int64_t M, const uint16_t* __restrict
 //   EPI 2: C = fp16(fp16(acc + bias) + R)        (dense + residual of BertSelfOutput / BertOutput; LayerNorm follows)
 // Requires N % 128 == 0, K % 64 == 0 (768, 2304, 3072 all are); M arbitrary.
 // ------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ void __launch_bounds__(256)
+template <int EPI, int BCOL, int BTOK, int WC, int WT>
+__global__ void __launch_bounds__(WC * WT * 64)
 gemm_bt_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const uint16_t* __restrict__ bias,
                const uint16_t* __restrict__ R, uint16_t* __restrict__ C, uint16_t* __restrict__ VT, int64_t M, int N, int K,
                int L, int Lp) {
-    __shared__ __attribute__((aligned(16))) uint4 sW[2][128 * 8];
-    __shared__ __attribute__((aligned(16))) uint4 sA[2][128 * 8];
+    // tile: BCOL output columns x BTOK tokens x 64 (k); WC x WT waves, each (BCOL/WC) x (BTOK/WT) = FA x FB fragments
+    constexpr int NWV = WC * WT, FA = BCOL / WC / 16, FB = BTOK / WT / 16;
+    constexpr int W_U4 = BCOL * 8, A_U4 = BTOK * 8;                  // uint4 per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4* sW = (uint4*)smem_raw;                                      // [2][W_U4]
+    uint4* sA = sW + 2 * W_U4;                                         // [2][A_U4]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wi = wave >> 1, wj = wave & 1;
-    const int n0 = blockIdx.x * 128;
-    const int64_t m0 = (int64_t)blockIdx.y * 128;
+    const int wi = wave / WT, wj = wave % WT;
+    const int n0 = blockIdx.x * BCOL;
+    const int64_t m0 = (int64_t)blockIdx.y * BTOK;
     const int lr = lane & 15, lg = lane >> 4;
 
     // global -> LDS without registers (global_load_lds_dwordx4): one wave instruction writes 1 KiB of LDS,
     // lane-linear, = 8 tile rows x 128 B. The bank-conflict swizzle therefore goes on the SOURCE address:
     // LDS[row][c] receives global chunk c ^ (row & 7); fragment reads apply the same XOR (cdna guide rule 21).
     auto stage = [&](const int buf, const int k0) {
+        const int ch = (lane & 7) ^ (lane >> 3);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rowbase = (wave * 4 + i) * 8;
-            const int row = rowbase + (lane >> 3), ch = (lane & 7) ^ (lane >> 3);
-            const uint16_t* gw = W + (size_t)(n0 + row) * K + k0 + ch * 8;
-            int64_t ar = m0 + row;
+        for (int i = 0; i < BCOL / 8 / NWV; ++i) {
+            const int rowbase = (wave * (BCOL / 8 / NWV) + i) * 8;
+            const uint16_t* gw = W + (size_t)(n0 + rowbase + (lane >> 3)) * K + k0 + ch * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw,
+                                             (__attribute__((address_space(3))) void*)&sW[buf * W_U4 + rowbase * 8], 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BTOK / 8 / NWV; ++i) {
+            const int rowbase = (wave * (BTOK / 8 / NWV) + i) * 8;
+            int64_t ar = m0 + rowbase + (lane >> 3);
             if (ar >= M) ar = M - 1;                                   // clamped: tail rows are never stored
             const uint16_t* ga = A + (size_t)ar * K + k0 + ch * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw,
-                                             (__attribute__((address_space(3))) void*)&sW[buf][rowbase * 8], 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
-                                             (__attribute__((address_space(3))) void*)&sA[buf][rowbase * 8], 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)&sA[buf * A_U4 + rowbase * 8], 16, 0, 0);
         }
     };
 
-    f4 acc[4][4];
+    f4 acc[FA][FB];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < FA; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < FB; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
 
     stage(0, 0);
     __syncthreads();                                   // (drains the LDS-DMA: hipcc puts vmcnt(0) in front of the barrier)
@@ -154,37 +163,37 @@ gemm_bt_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
         if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * 64);   // next tile streams in while this one is multiplied
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            h8 fw[4], fa[4];
+            h8 fw[FA], fa[FB];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int row = wi * 64 + a * 16 + lr;
-                fw[a] = __builtin_bit_cast(h8, sW[buf][row * 8 + ((ks * 4 + lg) ^ (row & 7))]);
+            for (int a = 0; a < FA; ++a) {
+                const int row = wi * (FA * 16) + a * 16 + lr;
+                fw[a] = __builtin_bit_cast(h8, sW[buf * W_U4 + row * 8 + ((ks * 4 + lg) ^ (row & 7))]);
             }
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int row = wj * 64 + b * 16 + lr;
-                fa[b] = __builtin_bit_cast(h8, sA[buf][row * 8 + ((ks * 4 + lg) ^ (row & 7))]);
+            for (int b = 0; b < FB; ++b) {
+                const int row = wj * (FB * 16) + b * 16 + lr;
+                fa[b] = __builtin_bit_cast(h8, sA[buf * A_U4 + row * 8 + ((ks * 4 + lg) ^ (row & 7))]);
             }
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < FA; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < FB; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[a], fa[b], acc[a][b], 0, 0, 0);
         }
         __syncthreads();
     }
 
-    // epilogue: acc[a][b][r] = C[token m0+64wj+16b+lr][col n0+64wi+16a+4lg+r]
+    // epilogue: acc[a][b][r] = C[token m0 + wj*FB*16 + 16b + lr][col n0 + wi*FA*16 + 16a + 4lg + r]
     const bool v_part = (EPI == 3) && (n0 >= 2 * HID);      // QKV projection: the V columns are stored transposed
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int64_t tok = m0 + wj * 64 + b * 16 + lr;
+    for (int b = 0; b < FB; ++b) {
+        const int64_t tok = m0 + wj * (FB * 16) + b * 16 + lr;
         if (tok >= M) continue;
         const int64_t pb = (EPI == 3) ? tok / L : 0;
         const int pos = (EPI == 3) ? (int)(tok - pb * L) : 0;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int col = n0 + wi * 64 + a * 16 + lg * 4;
+        for (int a = 0; a < FA; ++a) {
+            const int col = n0 + wi * (FA * 16) + a * 16 + lg * 4;
             const uint2 bb = *(const uint2*)(bias + col);
             const uint16_t bh[4] = {(uint16_t)(bb.x & 0xffff), (uint16_t)(bb.x >> 16), (uint16_t)(bb.y & 0xffff), (uint16_t)(bb.y >> 16)};
             uint16_t o[4];
@@ -215,6 +224,22 @@ gemm_bt_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
     }
 }
 
+// tile configurations (ATLAS_GEMM_CFG selects at run time; tuning)
+template <int EPI>
+static void launch_gemm(int cfg, hipStream_t stream, const uint16_t* A, const uint16_t* W, const uint16_t* bias, const uint16_t* R,
+                        uint16_t* C, uint16_t* VT, int64_t M, int N, int K, int L, int Lp) {
+    auto go = [&](auto kern, int bcol, int btok, int nthreads) {
+        const size_t lds = (size_t)(bcol + btok) * 128 * 2;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(kern, dim3(N / bcol, (unsigned)((M + btok - 1) / btok)), dim3(nthreads), lds, stream, A, W, bias, R, C, VT,
+                           M, N, K, L, Lp);
+    };
+    if (cfg == 1) go(gemm_bt_kernel<EPI, 256, 128, 4, 2>, 256, 128, 512);
+    else if (cfg == 2) go(gemm_bt_kernel<EPI, 256, 256, 2, 4>, 256, 256, 512);
+    else if (cfg == 3) go(gemm_bt_kernel<EPI, 128, 256, 2, 4>, 128, 256, 512);
+    else go(gemm_bt_kernel<EPI, 128, 128, 2, 2>, 128, 128, 256);
+}
+
 // ------------------------------------------------------------------------------------------
 // attention: one block (4 waves) per (passage, head). QK is [M][1536] (q | k), VT is [n][768][Lp] (V transposed).
 //   scores = fp16(q.k^T) ; / 8 (exact) ; + fp16 mask (0 / -10000) ; softmax in fp32 ; P = fp16 ; ctx = fp16(P.v)
@@ -230,7 +255,15 @@ template <int MAXKF>
 __global__ void __launch_bounds__(256)
 attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ vt, const int64_t* __restrict__ mask, int L, int Lp,
                  uint16_t* __restrict__ ctx) {
-    __shared__ __attribute__((aligned(16))) float sMask[512];   // additive mask as fp32 (0 / -10000), -inf beyond L
+    // K (this head's [Lp][64] slice) and V^T ([64][Lp]) are staged in LDS ONCE per (passage, head) with coalesced
+    // loads; the query fragments then run entirely out of LDS + registers (re-reading K/V^T from L2 for each of the
+    // L/16 query fragments made the kernel latency-bound: 300 us -> see profiles). K chunks are XOR-swizzled by
+    // (key & 7) for the ds_read_b128 fragment reads; V^T rows are padded by 16 B so dims spread over the banks.
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4* sK = (uint4*)smem;                                  // [Lp][8]
+    const int vstride = Lp + 8;                                // halfs
+    uint16_t* sVt = (uint16_t*)(sK + (size_t)Lp * 8);          // [64][Lp + 8]
+    float* sMask = (float*)(sVt + 64 * vstride);               // [Lp] additive mask as fp32 (0 / -10000), -inf beyond L
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     const int b = blockIdx.x / NHEAD, h = blockIdx.x % NHEAD;
@@ -239,6 +272,17 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
     const uint16_t* Vt = vt + ((size_t)b * HID + h * DHEAD) * Lp;
     for (int j = tid; j < Lp; j += 256)
         sMask[j] = (j < L) ? ((mask[(size_t)b * L + j] != 0) ? 0.0f : -10000.0f) : -__builtin_inff();
+    for (int idx = tid; idx < Lp * 8; idx += 256) {
+        const int key = idx >> 3, ch = idx & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (key < L) v = *(const uint4*)(Kb + (size_t)key * (2 * HID) + ch * 8);
+        sK[key * 8 + (ch ^ (key & 7))] = v;
+    }
+    const int cpr = Lp / 8;                                    // 16-B chunks per V^T row
+    for (int idx = tid; idx < 64 * cpr; idx += 256) {
+        const int dim = idx / cpr, c = idx - dim * cpr;
+        *(uint4*)(sVt + dim * vstride + c * 8) = *(const uint4*)(Vt + (size_t)dim * Lp + c * 8);
+    }
     __syncthreads();
     const int nkf = Lp / 16;
     for (int qf = wave; qf * 16 < L; qf += 4) {
@@ -250,9 +294,9 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
         for (int kf = 0; kf < MAXKF; ++kf) {
             s[kf] = (f4){0.f, 0.f, 0.f, 0.f};
             if (kf < nkf) {
-                int krow = kf * 16 + lr; if (krow >= L) krow = L - 1;
-                const h8 k0 = __builtin_bit_cast(h8, *(const uint4*)(Kb + (size_t)krow * (2 * HID) + lg * 8));
-                const h8 k1 = __builtin_bit_cast(h8, *(const uint4*)(Kb + (size_t)krow * (2 * HID) + 32 + lg * 8));
+                const int krow = kf * 16 + lr;
+                const h8 k0 = __builtin_bit_cast(h8, sK[krow * 8 + (lg ^ (krow & 7))]);
+                const h8 k1 = __builtin_bit_cast(h8, sK[krow * 8 + ((4 + lg) ^ (krow & 7))]);
                 s[kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, q0, s[kf], 0, 0, 0);
                 s[kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, q1, s[kf], 0, 0, 0);
             }
@@ -302,7 +346,7 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
                 }
 #pragma unroll
                 for (int df = 0; df < 4; ++df) {
-                    const uint16_t* vrow = Vt + (size_t)(df * 16 + lr) * Lp + ks * 32 + lg * 4;
+                    const uint16_t* vrow = sVt + (df * 16 + lr) * vstride + ks * 32 + lg * 4;
                     const uint2 v0 = *(const uint2*)vrow, v1 = *(const uint2*)(vrow + 16);
                     const h8 vb = __builtin_bit_cast(h8, make_uint4(v0.x, v0.y, v1.x, v1.y));
                     o[df] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, vb, o[df], 0, 0, 0);
@@ -356,7 +400,12 @@ int atlas_contriever_embed(const atlas_bert_weights* w, const int64_t* input_ids
     uint16_t* hbuf = (uint16_t*)p;
 
     const unsigned tok_blocks = (unsigned)((M + 3) / 4);
-    const unsigned mt = (unsigned)((M + 127) / 128);
+    const char* cfg_env = getenv("ATLAS_GEMM_CFG");
+    const int cfg = cfg_env ? atoi(cfg_env) : 2;        // 256x256 tiles measured best (profiles/r01/e01)
+    const size_t att_lds = (size_t)Lp * 128 + (size_t)64 * (Lp + 8) * 2 + (size_t)Lp * 4;
+    (void)hipFuncSetAttribute((const void*)attention_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attention_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attention_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // V^T pad columns [L, Lp) are read (times P = 0) but never written: keep them finite
     if (Lp != L) { hipError_t e = hipMemsetAsync(vt, 0, (size_t)n * HID * Lp * 2, stream); if (e != hipSuccess) return (int)e; }
     hipLaunchKernelGGL(embed_ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, input_ids, token_type_ids, L, M,
@@ -364,22 +413,21 @@ int atlas_contriever_embed(const atlas_bert_weights* w, const int64_t* input_ids
                        (const uint16_t*)w->emb_ln_w, (const uint16_t*)w->emb_ln_b, w->eps, x);
     for (int l = 0; l < w->n_layers; ++l) {
         const atlas_bert_layer& ly = w->layers[l];
-        hipLaunchKernelGGL(gemm_bt_kernel<3>, dim3(3 * HID / 128, mt), dim3(256), 0, stream, x, (const uint16_t*)ly.qkv_w,
-                           (const uint16_t*)ly.qkv_b, (const uint16_t*)nullptr, qk, vt, M, 3 * HID, HID, L, Lp);
+        launch_gemm<3>(cfg, stream, x, (const uint16_t*)ly.qkv_w, (const uint16_t*)ly.qkv_b, (const uint16_t*)nullptr, qk, vt, M,
+                       3 * HID, HID, L, Lp);
         if (Lp <= 128)
-            hipLaunchKernelGGL(attention_kernel<8>, dim3((unsigned)n * NHEAD), dim3(256), 0, stream, qk, vt, attention_mask, L, Lp, ctx);
+            hipLaunchKernelGGL(attention_kernel<8>, dim3((unsigned)n * NHEAD), dim3(256), att_lds, stream, qk, vt, attention_mask, L, Lp, ctx);
         else if (Lp <= 256)
-            hipLaunchKernelGGL(attention_kernel<16>, dim3((unsigned)n * NHEAD), dim3(256), 0, stream, qk, vt, attention_mask, L, Lp, ctx);
+            hipLaunchKernelGGL(attention_kernel<16>, dim3((unsigned)n * NHEAD), dim3(256), att_lds, stream, qk, vt, attention_mask, L, Lp, ctx);
         else
-            hipLaunchKernelGGL(attention_kernel<32>, dim3((unsigned)n * NHEAD), dim3(256), 0, stream, qk, vt, attention_mask, L, Lp, ctx);
-        hipLaunchKernelGGL(gemm_bt_kernel<2>, dim3(HID / 128, mt), dim3(256), 0, stream, ctx, (const uint16_t*)ly.o_w,
-                           (const uint16_t*)ly.o_b, x, u, (uint16_t*)nullptr, M, HID, HID, L, Lp);
+            hipLaunchKernelGGL(attention_kernel<32>, dim3((unsigned)n * NHEAD), dim3(256), att_lds, stream, qk, vt, attention_mask, L, Lp, ctx);
+        launch_gemm<2>(cfg, stream, ctx, (const uint16_t*)ly.o_w, (const uint16_t*)ly.o_b, x, u, (uint16_t*)nullptr, M, HID, HID, L, Lp);
         hipLaunchKernelGGL(ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, u, M, (const uint16_t*)ly.ln1_w,
                            (const uint16_t*)ly.ln1_b, w->eps, x);
-        hipLaunchKernelGGL(gemm_bt_kernel<1>, dim3(4 * HID / 128, mt), dim3(256), 0, stream, x, (const uint16_t*)ly.ff1_w,
-                           (const uint16_t*)ly.ff1_b, (const uint16_t*)nullptr, hbuf, (uint16_t*)nullptr, M, 4 * HID, HID, L, Lp);
-        hipLaunchKernelGGL(gemm_bt_kernel<2>, dim3(HID / 128, mt), dim3(256), 0, stream, hbuf, (const uint16_t*)ly.ff2_w,
-                           (const uint16_t*)ly.ff2_b, x, u, (uint16_t*)nullptr, M, HID, 4 * HID, L, Lp);
+        launch_gemm<1>(cfg, stream, x, (const uint16_t*)ly.ff1_w, (const uint16_t*)ly.ff1_b, (const uint16_t*)nullptr, hbuf,
+                       (uint16_t*)nullptr, M, 4 * HID, HID, L, Lp);
+        launch_gemm<2>(cfg, stream, hbuf, (const uint16_t*)ly.ff2_w, (const uint16_t*)ly.ff2_b, x, u, (uint16_t*)nullptr, M, HID, 4 * HID,
+                       L, Lp);
         hipLaunchKernelGGL(ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, u, M, (const uint16_t*)ly.ln2_w,
                            (const uint16_t*)ly.ln2_b, w->eps, x);
     }

@@ -242,6 +242,11 @@ class HipDistributedIndex(object):
         B = q.shape[0]
         if q.device != self._slab.device:
             q = q.to(self._slab.device)
+        if B == 0:      # an empty batch (atlas.py:106 builds one; ranks with no queries still take part in the collectives)
+            s = torch.empty((0, k), dtype=torch.float16, device=q.device)
+            i = torch.empty((0, k), dtype=torch.int64, device=q.device)
+            self.last_search_stats = {"path": "empty"}
+            return s, i, s.cpu().numpy(), i.cpu().numpy()
         if d != _lib.D_FAST or k > _lib.K_FAST_MAX:
             if k > _lib.K_EXACT_MAX:
                 raise _lib.AtlasHipError(f"topk={k} exceeds the supported maximum {_lib.K_EXACT_MAX}")

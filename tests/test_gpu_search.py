@@ -179,6 +179,13 @@ def test_device_f64_to_f16_conversions(gpu_index_cls, oracle_mod):
     assert np.array_equal(got[:, 1], want), (np.argwhere(got[:, 1] != want)[:5], x[got[:, 1] != want][:5])
 
 
+def test_empty_query_batch(gpu_index_cls):
+    P = synth.passages_f16(1000, 768, 96)
+    idx = _index(gpu_index_cls, P)
+    docs, scores = idx.search_knn(torch.empty((0, 768), device="cuda"), 5)     # atlas.py:106
+    assert docs == [] and scores == []
+
+
 def test_pack_merge_kernels_match_host(gpu_index_cls):
     from atlas_amd import _lib, index as im
 
