@@ -122,8 +122,16 @@ gemm_bt_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave / WT, wj = wave % WT;
-    const int n0 = blockIdx.x * BCOL;
-    const int64_t m0 = (int64_t)blockIdx.y * BTOK;
+    // XCD-aware tile order (cdna guide T1): hardware block b runs on XCD b % 8, each XCD has its own L2. All column
+    // tiles of one token tile are given to ONE XCD (token tile t -> XCD t % 8), so the big activation tile
+    // (BTOK x K) is fetched into one L2 once instead of into up to 8; the weights (<= 4.7 MB) fit every L2.
+    const int ncol = N / BCOL;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int ctile = jj % ncol;
+    const int64_t ttile = (int64_t)(jj / ncol) * 8 + xcd;
+    if (ttile * BTOK >= M) return;
+    const int n0 = ctile * BCOL;
+    const int64_t m0 = ttile * BTOK;
     const int lr = lane & 15, lg = lane >> 4;
 
     // global -> LDS without registers (global_load_lds_dwordx4): one wave instruction writes 1 KiB of LDS,
@@ -231,7 +239,8 @@ static void launch_gemm(int cfg, hipStream_t stream, const uint16_t* A, const ui
     auto go = [&](auto kern, int bcol, int btok, int nthreads) {
         const size_t lds = (size_t)(bcol + btok) * 128 * 2;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(kern, dim3(N / bcol, (unsigned)((M + btok - 1) / btok)), dim3(nthreads), lds, stream, A, W, bias, R, C, VT,
+        const unsigned mtiles = (unsigned)((M + btok - 1) / btok);
+        hipLaunchKernelGGL(kern, dim3((mtiles + 7) / 8 * 8 * (N / bcol)), dim3(nthreads), lds, stream, A, W, bias, R, C, VT,
                            M, N, K, L, Lp);
     };
     if (cfg == 1) go(gemm_bt_kernel<EPI, 256, 128, 4, 2>, 256, 128, 512);

@@ -1,5 +1,5 @@
 #!/bin/bash
-OUT=gpurun_out/${1:-e02}; mkdir -p $OUT; export TMPDIR=/tmp
+OUT=gpurun_out/${1:-e03}; mkdir -p $OUT; export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_encoder.py -m gpu -q --no-header -x -p no:cacheprovider 2>&1 | tail -2
 for cfg in 2; do
   (cd /tmp && ATLAS_GEMM_CFG=$cfg rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/cfg$cfg -o t -- python $GRAFT_REPO_ROOT/bench.py --passages 1000000 --steps 3 --warmup 1 --cpu-seconds 0 > $GRAFT_REPO_ROOT/$OUT/cfg$cfg.log 2>&1)
