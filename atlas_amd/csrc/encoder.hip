@@ -8,13 +8,20 @@
 // steps of `weight * y + bias` in the NON-standard LayerNorm); softmax and LayerNorm statistics are fp32. What may
 // differ from a given torch backend is only the fp32 summation order inside GEMMs and reductions.
 //
+// Token packing: only tokens with attention_mask != 0 are computed. Masked keys get probability exactly 0 in the
+// reference (exp(-10000 + s - max) underflows to 0 in fp32) and masked tokens' hidden states are dropped by the
+// pooling (retrievers.py:50), so leaving them out changes no result; a batch of queries padded to 512 with ~20 real
+// tokens costs 20 tokens. The packing is done on the device (count_kernel + pack_kernel, no host sync): kernels are
+// launched for the worst case n*L tokens and blocks beyond the packed count T = cu[n] exit immediately.
+//
 // Kernels
+//   count_kernel / pack_kernel   per-passage real-token counts, exclusive scan cu[n+1], tokinfo[t] = (passage, position)
 //   embed_ln_kernel     word + type (+= position) in fp16, LayerNorm                    (one wave per token)
 //   gemm_bt_kernel      C[M,N] = A[M,K] . W[N,K]^T + bias, 128x128x64 tiles, MFMA 16x16x32 f16, LDS double buffer,
 //                       epilogues: plain | exact-erf GELU | + residual        (MFMA-bound: the refresh roofline)
 //   attention_kernel    per (passage, head): QK^T -> fp16 -> /8 + mask -> fp32 softmax -> fp16 P -> PV
 //   ln_kernel           the reference's LayerNorm on a [M,768] fp16 tensor          (one wave per token)
-//   (pooling + slab row write: pool_write_kernel in atlas_hip.hip)
+//   pool_packed_kernel  mean over a passage's tokens with the reference's two roundings, row written into the slab
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -62,16 +69,59 @@ static __device__ __forceinline__ void layer_norm_768(const float (&x)[12], cons
     }
 }
 
-// one wave per token: embeddings (modeling_bert.py:213-247)
+// ---- token packing ----
+// counts[b] = number of tokens with mask != 0 (one wave per passage)
 __global__ void __launch_bounds__(256)
-embed_ln_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ type_ids, int L, int64_t M,
+count_kernel(const int64_t* __restrict__ mask, int n, int L, int* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n) return;
+    int c = 0;
+    for (int l = lane; l < L; l += 64) c += (mask[(size_t)b * L + l] != 0);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (lane == 0) counts[b] = c;
+}
+
+// cu[b] = sum counts[0..b) (every wave sums its own prefix: n is a few thousand at most and counts is L2-resident),
+// tokinfo[cu[b] + rank] = (b, l) for the real tokens of passage b in position order
+__global__ void __launch_bounds__(256)
+pack_kernel(const int64_t* __restrict__ mask, int n, int L, const int* __restrict__ counts, int* __restrict__ cu,
+            int2* __restrict__ tokinfo) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n) return;
+    int base = 0;
+    for (int i = lane; i < b; i += 64) base += counts[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) base += __shfl_xor(base, o);
+    if (lane == 0) {
+        cu[b] = base;
+        if (b == n - 1) cu[n] = base + counts[b];
+    }
+    int run = base;
+    for (int l0 = 0; l0 < L; l0 += 64) {
+        const int l = l0 + lane;
+        const bool real = (l < L) && (mask[(size_t)b * L + l] != 0);
+        const unsigned long long bal = __ballot(real);
+        if (real) tokinfo[run + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(b, l);
+        run += __popcll(bal);
+    }
+}
+
+// one wave per packed token: embeddings (modeling_bert.py:213-247)
+__global__ void __launch_bounds__(256)
+embed_ln_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ type_ids, int L, const int* __restrict__ cu, int n,
+                const int2* __restrict__ tokinfo,
                 const uint16_t* __restrict__ word, const uint16_t* __restrict__ pos, const uint16_t* __restrict__ type,
                 const uint16_t* __restrict__ lnw, const uint16_t* __restrict__ lnb, float eps, uint16_t* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= M) return;
-    const int64_t id = ids[t], ty = type_ids ? type_ids[t] : 0;
-    const int p = (int)(t % L);
+    if (t >= cu[n]) return;
+    const int2 ti = tokinfo[t];
+    const size_t src = (size_t)ti.x * L + ti.y;
+    const int64_t id = ids[src], ty = type_ids ? type_ids[src] : 0;
+    const int p = ti.y;
     float x[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
@@ -84,11 +134,11 @@ embed_ln_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ typ
 
 // one wave per token: LayerNorm(x.float()).type_as(x) on an fp16 [M,768] tensor
 __global__ void __launch_bounds__(256)
-ln_kernel(const uint16_t* __restrict__ in, int64_t M, const uint16_t* __restrict__ lnw, const uint16_t* __restrict__ lnb,
+ln_kernel(const uint16_t* __restrict__ in, const int* __restrict__ Tdev, const uint16_t* __restrict__ lnw, const uint16_t* __restrict__ lnb,
           float eps, uint16_t* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= M) return;
+    if (t >= *Tdev) return;
     float x[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) x[i] = h2f(in[(size_t)t * HID + i * 64 + lane]);
@@ -111,8 +161,8 @@ ln_kernel(const uint16_t* __restrict__ in, int64_t M, const uint16_t* __restrict
 template <int EPI, int BCOL, int BTOK, int WC, int WT>
 __global__ void __launch_bounds__(WC * WT * 64)
 gemm_bt_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const uint16_t* __restrict__ bias,
-               const uint16_t* __restrict__ R, uint16_t* __restrict__ C, uint16_t* __restrict__ VT, int64_t M, int N, int K,
-               int L, int Lp) {
+               const uint16_t* __restrict__ R, uint16_t* __restrict__ C, uint16_t* __restrict__ VT, const int* __restrict__ cu, int n,
+               const int2* __restrict__ tokinfo, int N, int K, int Lp) {
     // tile: BCOL output columns x BTOK tokens x 64 (k); WC x WT waves, each (BCOL/WC) x (BTOK/WT) = FA x FB fragments
     constexpr int NWV = WC * WT, FA = BCOL / WC / 16, FB = BTOK / WT / 16;
     constexpr int W_U4 = BCOL * 8, A_U4 = BTOK * 8;                  // uint4 per stage
@@ -125,6 +175,7 @@ gemm_bt_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
     // XCD-aware tile order (cdna guide T1): hardware block b runs on XCD b % 8, each XCD has its own L2. All column
     // tiles of one token tile are given to ONE XCD (token tile t -> XCD t % 8), so the big activation tile
     // (BTOK x K) is fetched into one L2 once instead of into up to 8; the weights (<= 4.7 MB) fit every L2.
+    const int64_t M = cu[n];                                           // packed token count (grid covers n*L)
     const int ncol = N / BCOL;
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
     const int ctile = jj % ncol;
@@ -197,8 +248,9 @@ gemm_bt_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
     for (int b = 0; b < FB; ++b) {
         const int64_t tok = m0 + wj * (FB * 16) + b * 16 + lr;
         if (tok >= M) continue;
-        const int64_t pb = (EPI == 3) ? tok / L : 0;
-        const int pos = (EPI == 3) ? (int)(tok - pb * L) : 0;
+        int64_t pb = 0;
+        int pos = 0;                                             // rank of the token inside its passage = V^T column
+        if (EPI == 3 && v_part) { pb = tokinfo[tok].x; pos = (int)(tok - cu[pb]); }
 #pragma unroll
         for (int a = 0; a < FA; ++a) {
             const int col = n0 + wi * (FA * 16) + a * 16 + lg * 4;
@@ -235,13 +287,13 @@ gemm_bt_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
 // tile configurations (ATLAS_GEMM_CFG selects at run time; tuning)
 template <int EPI>
 static void launch_gemm(int cfg, hipStream_t stream, const uint16_t* A, const uint16_t* W, const uint16_t* bias, const uint16_t* R,
-                        uint16_t* C, uint16_t* VT, int64_t M, int N, int K, int L, int Lp) {
+                        uint16_t* C, uint16_t* VT, int64_t Mmax, const int* cu, int n, const int2* tokinfo, int N, int K, int Lp) {
     auto go = [&](auto kern, int bcol, int btok, int nthreads) {
         const size_t lds = (size_t)(bcol + btok) * 128 * 2;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        const unsigned mtiles = (unsigned)((M + btok - 1) / btok);
+        const unsigned mtiles = (unsigned)((Mmax + btok - 1) / btok);
         hipLaunchKernelGGL(kern, dim3((mtiles + 7) / 8 * 8 * (N / bcol)), dim3(nthreads), lds, stream, A, W, bias, R, C, VT,
-                           M, N, K, L, Lp);
+                           cu, n, tokinfo, N, K, Lp);
     };
     if (cfg == 1) go(gemm_bt_kernel<EPI, 256, 128, 4, 2>, 256, 128, 512);
     else if (cfg == 2) go(gemm_bt_kernel<EPI, 256, 256, 2, 4>, 256, 256, 512);
@@ -262,25 +314,29 @@ static void launch_gemm(int cfg, hipStream_t stream, const uint16_t* A, const ui
 // ------------------------------------------------------------------------------------------
 template <int MAXKF>
 __global__ void __launch_bounds__(256)
-attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ vt, const int64_t* __restrict__ mask, int L, int Lp,
+attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ vt, const int* __restrict__ cu, int LpMax,
                  uint16_t* __restrict__ ctx) {
     // K (this head's [Lp][64] slice) and V^T ([64][Lp]) are staged in LDS ONCE per (passage, head) with coalesced
     // loads; the query fragments then run entirely out of LDS + registers (re-reading K/V^T from L2 for each of the
     // L/16 query fragments made the kernel latency-bound: 300 us -> see profiles). K chunks are XOR-swizzled by
     // (key & 7) for the ds_read_b128 fragment reads; V^T rows are padded by 16 B so dims spread over the banks.
+    // L = this passage's packed length (all its keys are real), Lp = L rounded up to 32; keys in [L, Lp) are zero
+    // rows / zero V^T columns with an additive mask of -inf.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint4* sK = (uint4*)smem;                                  // [Lp][8]
-    const int vstride = Lp + 8;                                // halfs
-    uint16_t* sVt = (uint16_t*)(sK + (size_t)Lp * 8);          // [64][Lp + 8]
-    float* sMask = (float*)(sVt + 64 * vstride);               // [Lp] additive mask as fp32 (0 / -10000), -inf beyond L
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     const int b = blockIdx.x / NHEAD, h = blockIdx.x % NHEAD;
-    const uint16_t* Qb = qk + (size_t)b * L * (2 * HID) + h * DHEAD;
+    const int tb = cu[b], L = cu[b + 1] - tb;
+    if (L <= 0) return;
+    const int Lp = (L + 31) & ~31;
+    uint4* sK = (uint4*)smem;                                  // [Lp][8]
+    const int vstride = Lp + 8;                                // halfs
+    uint16_t* sVt = (uint16_t*)(sK + (size_t)Lp * 8);          // [64][Lp + 8]
+    float* sMask = (float*)(sVt + 64 * vstride);               // [Lp] 0 for keys < L, -inf beyond
+    const uint16_t* Qb = qk + (size_t)tb * (2 * HID) + h * DHEAD;
     const uint16_t* Kb = Qb + HID;
-    const uint16_t* Vt = vt + ((size_t)b * HID + h * DHEAD) * Lp;
-    for (int j = tid; j < Lp; j += 256)
-        sMask[j] = (j < L) ? ((mask[(size_t)b * L + j] != 0) ? 0.0f : -10000.0f) : -__builtin_inff();
+    const uint16_t* Vt = vt + ((size_t)b * HID + h * DHEAD) * LpMax;
+    for (int j = tid; j < Lp; j += 256) sMask[j] = (j < L) ? 0.0f : -__builtin_inff();
     for (int idx = tid; idx < Lp * 8; idx += 256) {
         const int key = idx >> 3, ch = idx & 7;
         uint4 v = make_uint4(0, 0, 0, 0);
@@ -290,7 +346,16 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
     const int cpr = Lp / 8;                                    // 16-B chunks per V^T row
     for (int idx = tid; idx < 64 * cpr; idx += 256) {
         const int dim = idx / cpr, c = idx - dim * cpr;
-        *(uint4*)(sVt + dim * vstride + c * 8) = *(const uint4*)(Vt + (size_t)dim * Lp + c * 8);
+        uint4 v = *(const uint4*)(Vt + (size_t)dim * LpMax + c * 8);
+        const int left = L - c * 8;                            // columns >= L were never written: force them to 0
+        if (left < 8) {
+            uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (e >= left) wv[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+            v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+        }
+        *(uint4*)(sVt + dim * vstride + c * 8) = v;
     }
     __syncthreads();
     const int nkf = Lp / 16;
@@ -367,9 +432,30 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = qf * 16 + lg * 4 + r;
-                if (row < L) ctx[((size_t)b * L + row) * HID + h * DHEAD + df * 16 + lr] = f2h(o[df][r]);
+                if (row < L) ctx[((size_t)tb + row) * HID + h * DHEAD + df * 16 + lr] = f2h(o[df][r]);
             }
     }
+}
+
+// masked mean pooling (retrievers.py:50-52) over the packed tokens of one passage, with the reference's two roundings:
+// fp16(sum) (the fp16 tensor .sum(dim=1) returns), then fp16(that / count); the row goes straight to out (= a slab row,
+// atlas.py:79). The sum itself is exact (fp16 addends in double), which no summation order of the reference beats.
+__global__ void __launch_bounds__(192)
+pool_packed_kernel(const uint16_t* __restrict__ x, const int* __restrict__ cu, uint16_t* __restrict__ out) {
+    const int b = blockIdx.x;
+    const int tb = cu[b], L = cu[b + 1] - tb;
+    const uint16_t* base = x + (size_t)tb * HID + threadIdx.x * 4;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int l = 0; l < L; ++l) {
+        const uint2 v = *(const uint2*)(base + (size_t)l * HID);
+        s[0] += f16_bits_to_f64((uint16_t)(v.x & 0xffff)); s[1] += f16_bits_to_f64((uint16_t)(v.x >> 16));
+        s[2] += f16_bits_to_f64((uint16_t)(v.y & 0xffff)); s[3] += f16_bits_to_f64((uint16_t)(v.y >> 16));
+    }
+    const float cnt = (float)L;                                   // attention_mask.sum(dim=1): 0 -> 0/0 = NaN as in torch
+    uint16_t o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = f32_to_f16_bits(f16_bits_to_f32(f64_to_f16_bits(s[r])) / cnt);
+    *(uint2*)(out + (size_t)b * HID + threadIdx.x * 4) = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
 }
 
 // ==========================================================================================
@@ -384,8 +470,9 @@ extern "C" {
 size_t atlas_contriever_workspace_bytes(int n, int L) {
     if (n <= 0 || L <= 0) return 0;
     const size_t M = (size_t)n * L, Lp = (size_t)((L + 31) & ~31);
-    // x, ctx, u : [M,768]; qk : [M,1536]; vt : [n,768,Lp]; h : [M,3072]
-    return up256(M * HID * 2) * 3 + up256(M * 2 * HID * 2) + up256((size_t)n * HID * Lp * 2) + up256(M * 4 * HID * 2) + 256;
+    // x, ctx, u : [M,768]; qk : [M,1536]; vt : [n,768,Lp]; h : [M,3072]; counts[n], cu[n+1], tokinfo[M]
+    return up256(M * HID * 2) * 3 + up256(M * 2 * HID * 2) + up256((size_t)n * HID * Lp * 2) + up256(M * 4 * HID * 2) +
+           up256((size_t)n * 4) + up256((size_t)(n + 1) * 4) + up256(M * 8) + 256;
 }
 
 int atlas_contriever_embed(const atlas_bert_weights* w, const int64_t* input_ids, const int64_t* attention_mask,
@@ -394,11 +481,11 @@ int atlas_contriever_embed(const atlas_bert_weights* w, const int64_t* input_ids
     if (!w || !input_ids || !attention_mask || !out_f16 || !ws) return ATLAS_E_BADARG;
     if (n <= 0 || L <= 0) return ATLAS_E_BADARG;
     if (L > 512 || w->hidden != HID || w->n_heads != NHEAD || w->intermediate != 4 * HID || w->n_layers < 1 ||
-        w->n_layers > ATLAS_BERT_MAX_LAYERS)
+        w->n_layers > ATLAS_BERT_MAX_LAYERS || (int64_t)n * L > 0x7fffffff)
         return ATLAS_E_UNSUPPORTED;
     if (ws_bytes < atlas_contriever_workspace_bytes(n, L)) return ATLAS_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
-    const int64_t M = (int64_t)n * L;
+    const int64_t M = (int64_t)n * L;                 // worst case; the packed count lives on the device (cu[n])
     const int Lp = (L + 31) & ~31;
     unsigned char* p = (unsigned char*)ws;
     uint16_t* x = (uint16_t*)p;   p += up256((size_t)M * HID * 2);
@@ -406,43 +493,47 @@ int atlas_contriever_embed(const atlas_bert_weights* w, const int64_t* input_ids
     uint16_t* u = (uint16_t*)p;   p += up256((size_t)M * HID * 2);
     uint16_t* qk = (uint16_t*)p;  p += up256((size_t)M * 2 * HID * 2);
     uint16_t* vt = (uint16_t*)p;  p += up256((size_t)n * HID * Lp * 2);
-    uint16_t* hbuf = (uint16_t*)p;
+    uint16_t* hbuf = (uint16_t*)p; p += up256((size_t)M * 4 * HID * 2);
+    int* counts = (int*)p;        p += up256((size_t)n * 4);
+    int* cu = (int*)p;            p += up256((size_t)(n + 1) * 4);
+    int2* tokinfo = (int2*)p;
 
-    const unsigned tok_blocks = (unsigned)((M + 3) / 4);
+    const unsigned tok_blocks = (unsigned)((M + 3) / 4), pas_blocks = (unsigned)((n + 3) / 4);
     const char* cfg_env = getenv("ATLAS_GEMM_CFG");
     const int cfg = cfg_env ? atoi(cfg_env) : 2;        // 256x256 tiles measured best (profiles/r01/e01)
     const size_t att_lds = (size_t)Lp * 128 + (size_t)64 * (Lp + 8) * 2 + (size_t)Lp * 4;
     (void)hipFuncSetAttribute((const void*)attention_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)attention_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)attention_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    // V^T pad columns [L, Lp) are read (times P = 0) but never written: keep them finite
-    if (Lp != L) { hipError_t e = hipMemsetAsync(vt, 0, (size_t)n * HID * Lp * 2, stream); if (e != hipSuccess) return (int)e; }
-    hipLaunchKernelGGL(embed_ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, input_ids, token_type_ids, L, M,
+    hipLaunchKernelGGL(count_kernel, dim3(pas_blocks), dim3(256), 0, stream, attention_mask, n, L, counts);
+    hipLaunchKernelGGL(pack_kernel, dim3(pas_blocks), dim3(256), 0, stream, attention_mask, n, L, counts, cu, tokinfo);
+    hipLaunchKernelGGL(embed_ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, input_ids, token_type_ids, L, cu, n, tokinfo,
                        (const uint16_t*)w->word_emb, (const uint16_t*)w->pos_emb, (const uint16_t*)w->type_emb,
                        (const uint16_t*)w->emb_ln_w, (const uint16_t*)w->emb_ln_b, w->eps, x);
     for (int l = 0; l < w->n_layers; ++l) {
         const atlas_bert_layer& ly = w->layers[l];
         launch_gemm<3>(cfg, stream, x, (const uint16_t*)ly.qkv_w, (const uint16_t*)ly.qkv_b, (const uint16_t*)nullptr, qk, vt, M,
-                       3 * HID, HID, L, Lp);
+                       cu, n, tokinfo, 3 * HID, HID, Lp);
         if (Lp <= 128)
-            hipLaunchKernelGGL(attention_kernel<8>, dim3((unsigned)n * NHEAD), dim3(256), att_lds, stream, qk, vt, attention_mask, L, Lp, ctx);
+            hipLaunchKernelGGL(attention_kernel<8>, dim3((unsigned)n * NHEAD), dim3(256), att_lds, stream, qk, vt, cu, Lp, ctx);
         else if (Lp <= 256)
-            hipLaunchKernelGGL(attention_kernel<16>, dim3((unsigned)n * NHEAD), dim3(256), att_lds, stream, qk, vt, attention_mask, L, Lp, ctx);
+            hipLaunchKernelGGL(attention_kernel<16>, dim3((unsigned)n * NHEAD), dim3(256), att_lds, stream, qk, vt, cu, Lp, ctx);
         else
-            hipLaunchKernelGGL(attention_kernel<32>, dim3((unsigned)n * NHEAD), dim3(256), att_lds, stream, qk, vt, attention_mask, L, Lp, ctx);
-        launch_gemm<2>(cfg, stream, ctx, (const uint16_t*)ly.o_w, (const uint16_t*)ly.o_b, x, u, (uint16_t*)nullptr, M, HID, HID, L, Lp);
-        hipLaunchKernelGGL(ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, u, M, (const uint16_t*)ly.ln1_w,
+            hipLaunchKernelGGL(attention_kernel<32>, dim3((unsigned)n * NHEAD), dim3(256), att_lds, stream, qk, vt, cu, Lp, ctx);
+        launch_gemm<2>(cfg, stream, ctx, (const uint16_t*)ly.o_w, (const uint16_t*)ly.o_b, x, u, (uint16_t*)nullptr, M, cu, n, tokinfo,
+                       HID, HID, Lp);
+        hipLaunchKernelGGL(ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, u, cu + n, (const uint16_t*)ly.ln1_w,
                            (const uint16_t*)ly.ln1_b, w->eps, x);
         launch_gemm<1>(cfg, stream, x, (const uint16_t*)ly.ff1_w, (const uint16_t*)ly.ff1_b, (const uint16_t*)nullptr, hbuf,
-                       (uint16_t*)nullptr, M, 4 * HID, HID, L, Lp);
-        launch_gemm<2>(cfg, stream, hbuf, (const uint16_t*)ly.ff2_w, (const uint16_t*)ly.ff2_b, x, u, (uint16_t*)nullptr, M, HID, 4 * HID,
-                       L, Lp);
-        hipLaunchKernelGGL(ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, u, M, (const uint16_t*)ly.ln2_w,
+                       (uint16_t*)nullptr, M, cu, n, tokinfo, 4 * HID, HID, Lp);
+        launch_gemm<2>(cfg, stream, hbuf, (const uint16_t*)ly.ff2_w, (const uint16_t*)ly.ff2_b, x, u, (uint16_t*)nullptr, M, cu, n,
+                       tokinfo, HID, 4 * HID, Lp);
+        hipLaunchKernelGGL(ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, u, cu + n, (const uint16_t*)ly.ln2_w,
                            (const uint16_t*)ly.ln2_b, w->eps, x);
     }
-    // masked mean pooling with the reference's double rounding, rows written contiguously at out_f16
-    // (out_f16 may point into the passage slab: slab + row_offset * 768)
-    return atlas_pool_write(x, attention_mask, out_f16, n, 0, n, L, HID, stream_);
+    // rows written contiguously at out_f16 (which may point into the passage slab: slab + row_offset * 768)
+    hipLaunchKernelGGL(pool_packed_kernel, dim3((unsigned)n), dim3(192), 0, stream, x, cu, (uint16_t*)out_f16);
+    return (int)hipGetLastError();
 }
 
 }  // extern "C"

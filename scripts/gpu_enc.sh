@@ -1,6 +1,7 @@
 #!/bin/bash
 OUT=gpurun_out/${1:-e03}; mkdir -p $OUT; export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_encoder.py -m gpu -q --no-header -x -p no:cacheprovider 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_gpu_encoder.py -m gpu -q --no-header -x -p no:cacheprovider 2>&1 | tail -5
+timeout 300 python tools/enc_time.py 2>&1 | tee $OUT/enc_time.log
 for cfg in 2; do
   (cd /tmp && ATLAS_GEMM_CFG=$cfg rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/cfg$cfg -o t -- python $GRAFT_REPO_ROOT/bench.py --passages 1000000 --steps 3 --warmup 1 --cpu-seconds 0 > $GRAFT_REPO_ROOT/$OUT/cfg$cfg.log 2>&1)
   python - <<PY
@@ -10,7 +11,7 @@ d=json.loads(lines[-1])["refresh"]
 print("cfg$cfg refresh", round(d["value"]), "passages/s", round(d["roofline"]["achieved"],1), "TF")
 for r in csv.DictReader(open("$OUT/cfg$cfg/t_kernel_stats.csv")):
     n=r["Name"]
-    if any(k in n for k in ("gemm","attention","ln_kernel","pool","embed_ln")):
+    if any(k in n for k in ("gemm","attention","ln_kernel","pool","embed_ln","count_k","pack_k")):
         print("   %-60s calls=%4s avg=%9.1f us"%(n[:60], r["Calls"], float(r["AverageNs"])/1e3))
 PY
 done

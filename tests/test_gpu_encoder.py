@@ -80,3 +80,49 @@ def test_deepcopy_half_eval_like_atlas(gpu_index_cls):
     assert (e.float() - want.float()).abs().max() / want.float().abs().max() <= 4e-3
     with pytest.raises(Exception, match="fp16 inference copy"):
         r(ids.cuda(), mask.cuda())                                                     # fp32 forward: not provided yet
+
+
+def test_masks_with_holes_and_query_like_padding(gpu_index_cls):
+    """attention masks are arbitrary 0/1 patterns for the module (not only prefixes); queries are tokenised with
+    padding='max_length' (src/atlas.py retriever_tokenize), i.e. ~20 real tokens in L = 512"""
+    ref, mine = _models(2)
+    g = torch.Generator().manual_seed(11)
+    n, L = 6, 96
+    ids = torch.randint(1000, 30522, (n, L), generator=g)
+    mask = (torch.rand((n, L), generator=g) < 0.6).long()
+    mask[:, 0] = 1
+    want = ref.cuda()(ids.cuda(), mask.cuda()).float().cpu()
+    got = mine(ids.cuda(), mask.cuda()).float().cpu()
+    assert (got - want).abs().max() / want.abs().max() <= 4e-3
+    ids, mask = _batch(4, 512, 12)
+    mask[:, 20:] = 0
+    mask[2, 5:] = 0
+    want = ref.cuda()(ids.cuda(), mask.cuda()).float().cpu()
+    got = mine(ids.cuda(), mask.cuda()).float().cpu()
+    assert (got - want).abs().max() / want.abs().max() <= 4e-3
+
+
+def test_padding_invariance_is_bit_exact(gpu_index_cls):
+    """only real tokens are computed (token packing), so a passage's embedding cannot depend on how far the batch is
+    padded or on its batch-mates' lengths. Ties the ragged path to the full-length one bit for bit."""
+    _, mine = _models(2)
+    ids, mask = _batch(9, 64, 21)
+    a = mine(ids.cuda(), mask.cuda())
+    ids2 = torch.zeros((9, 200), dtype=ids.dtype); ids2[:, :64] = ids
+    mask2 = torch.zeros((9, 200), dtype=mask.dtype); mask2[:, :64] = mask
+    b = mine(ids2.cuda(), mask2.cuda())
+    assert torch.equal(a, b)
+    one = mine(ids[3:4].cuda(), mask[3:4].cuda())
+    # (the GEMM tile a token lands in changes with the packing, the fp32 accumulation order per output does not)
+    assert torch.equal(one[0], a[3])
+
+
+def test_fully_masked_passage_gives_nan_like_torch(gpu_index_cls):
+    """retrievers.py:52 divides by mask.sum() = 0 -> NaN row; the other rows are unaffected"""
+    ref, mine = _models(2)
+    ids, mask = _batch(3, 16, 30)
+    mask[1] = 0
+    got = mine(ids.cuda(), mask.cuda()).float().cpu()
+    want = ref.cuda()(ids.cuda(), mask.cuda()).float().cpu()
+    assert torch.isnan(got[1]).all() and torch.isnan(want[1]).all()
+    assert (got[[0, 2]] - want[[0, 2]]).abs().max() / want[[0, 2]].abs().max() <= 4e-3
