@@ -33,16 +33,74 @@
 using namespace atlas;
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));   // 16-byte MFMA operand chunk (see the note on LDS reads in gemm_bt_kernel)
 
 #define HID 768
 #define NHEAD 12
 #define DHEAD 64
 
-static __device__ __forceinline__ float h2f(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
-static __device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }   // v_cvt_f16_f32, RNE
-static __device__ __forceinline__ float rh(float f) { return (float)(_Float16)f; }                               // round through fp16
+// ---- the three model precisions (opt.precision fp16 | bf16 | fp32; atlas.py / model_io.py cast the retriever) ----
+// ld/st: element <-> fp32; rnd: "this tensor is materialised in the model dtype here" (identity for fp32);
+// mma: one 16-byte operand chunk per lane pair -> v_mfma 16x16 (k = 32 halves / 32 bf16 / 4 x (k = 4) floats).
+struct F16 {
+    typedef uint16_t elem;
+    static constexpr int DT = ATLAS_DT_F16;
+    static __device__ __forceinline__ float ld(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+    static __device__ __forceinline__ uint16_t st(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }   // v_cvt_f16_f32, RNE
+    static __device__ __forceinline__ float rnd(float f) { return (float)(_Float16)f; }
+    static __device__ __forceinline__ f4 mma(const u4v& a, const u4v& b, f4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f4 mma(const uint4& a, const uint4& b, f4 c) { return mma(__builtin_bit_cast(u4v, a), __builtin_bit_cast(u4v, b), c); }
+};
+struct BF16 {
+    typedef uint16_t elem;
+    static constexpr int DT = ATLAS_DT_BF16;
+    static __device__ __forceinline__ float ld(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+    static __device__ __forceinline__ uint16_t st(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }     // v_cvt_pk_bf16_f32, RNE
+    static __device__ __forceinline__ float rnd(float f) { return ld(st(f)); }
+    static __device__ __forceinline__ f4 mma(const u4v& a, const u4v& b, f4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f4 mma(const uint4& a, const uint4& b, f4 c) { return mma(__builtin_bit_cast(u4v, a), __builtin_bit_cast(u4v, b), c); }
+};
+struct F32 {
+    typedef float elem;
+    static constexpr int DT = ATLAS_DT_F32;
+    static __device__ __forceinline__ float ld(float b) { return b; }
+    static __device__ __forceinline__ float st(float f) { return f; }
+    static __device__ __forceinline__ float rnd(float f) { return f; }
+    static __device__ __forceinline__ f4 mma(const uint4& a, const uint4& b, f4 c) { return mma(__builtin_bit_cast(u4v, a), __builtin_bit_cast(u4v, b), c); }
+    static __device__ __forceinline__ f4 mma(const u4v& a, const u4v& b, f4 c) {
+        // the contraction index of a chunk is enumerated (lane group, element): both operands use the same order.
+        // (elements are copied to scalars first: __builtin_bit_cast applied directly to an ext-vector element
+        // reads element 0 with this hipcc)
+        const uint32_t a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a0), __builtin_bit_cast(float, b0), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a1), __builtin_bit_cast(float, b1), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a2), __builtin_bit_cast(float, b2), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a3), __builtin_bit_cast(float, b3), c, 0, 0, 0);
+        return c;
+    }
+};
+// 4 consecutive elements <-> 4 floats
+template <class T> static __device__ __forceinline__ void load4(const typename T::elem* p, float (&v)[4]);
+template <> __device__ __forceinline__ void load4<F32>(const float* p, float (&v)[4]) {
+    const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <class T> static __device__ __forceinline__ void load4(const typename T::elem* p, float (&v)[4]) {
+    const uint2 t = *(const uint2*)p;
+    v[0] = T::ld((uint16_t)(t.x & 0xffff)); v[1] = T::ld((uint16_t)(t.x >> 16));
+    v[2] = T::ld((uint16_t)(t.y & 0xffff)); v[3] = T::ld((uint16_t)(t.y >> 16));
+}
+template <class T> static __device__ __forceinline__ void store4(typename T::elem* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void store4<F32>(float* p, const float (&v)[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+template <class T> static __device__ __forceinline__ void store4(typename T::elem* p, const float (&v)[4]) {
+    *(uint2*)p = make_uint2((uint32_t)T::st(v[0]) | ((uint32_t)T::st(v[1]) << 16), (uint32_t)T::st(v[2]) | ((uint32_t)T::st(v[3]) << 16));
+}
+
 static __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
@@ -50,11 +108,12 @@ static __device__ __forceinline__ float wave_sum(float x) {
 }
 
 // ---- the reference's LayerNorm on one 768-vector held 12 per lane (element 64*i + lane) ----
-// modeling_bert.py:104-114: mean and UNCENTRED second moment in fp32, y = fp16((x-mean)*rsqrt(E[x^2]+eps)),
-// out = fp16(fp16(w*y) + b)
-static __device__ __forceinline__ void layer_norm_768(const float (&x)[12], const uint16_t* __restrict__ w,
-                                                      const uint16_t* __restrict__ b, float eps, int lane,
-                                                      uint16_t* __restrict__ out) {
+// modeling_bert.py:104-114: mean and UNCENTRED second moment in fp32, y = dtype((x-mean)*rsqrt(E[x^2]+eps)),
+// out = dtype(dtype(w*y) + b): two separately rounded ops (no fma), in fp32 as well
+template <class T>
+static __device__ __forceinline__ void layer_norm_768(const float (&x)[12], const typename T::elem* __restrict__ w,
+                                                      const typename T::elem* __restrict__ b, float eps, int lane,
+                                                      typename T::elem* __restrict__ out) {
     float s = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 12; ++i) { s += x[i]; s2 += x[i] * x[i]; }
@@ -64,8 +123,8 @@ static __device__ __forceinline__ void layer_norm_768(const float (&x)[12], cons
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         const int c = i * 64 + lane;
-        const float y = rh((x[i] - mean) * rstd);
-        out[c] = f2h(rh(h2f(w[c]) * y) + h2f(b[c]));
+        const float y = T::rnd(__fmul_rn(x[i] - mean, rstd));
+        out[c] = T::st(__fadd_rn(T::rnd(__fmul_rn(T::ld(w[c]), y)), T::ld(b[c])));
     }
 }
 
@@ -110,11 +169,12 @@ pack_kernel(const int64_t* __restrict__ mask, int n, int L, const int* __restric
 }
 
 // one wave per packed token: embeddings (modeling_bert.py:213-247)
+template <class T>
 __global__ void __launch_bounds__(256)
 embed_ln_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ type_ids, int L, const int* __restrict__ cu, int n,
                 const int2* __restrict__ tokinfo,
-                const uint16_t* __restrict__ word, const uint16_t* __restrict__ pos, const uint16_t* __restrict__ type,
-                const uint16_t* __restrict__ lnw, const uint16_t* __restrict__ lnb, float eps, uint16_t* __restrict__ out) {
+                const typename T::elem* __restrict__ word, const typename T::elem* __restrict__ pos, const typename T::elem* __restrict__ type,
+                const typename T::elem* __restrict__ lnw, const typename T::elem* __restrict__ lnb, float eps, typename T::elem* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= cu[n]) return;
@@ -126,46 +186,48 @@ embed_ln_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ typ
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         const int c = i * 64 + lane;
-        const float e = rh(h2f(word[id * HID + c]) + h2f(type[ty * HID + c]));    // inputs_embeds + token_type_embeddings (fp16)
-        x[i] = rh(e + h2f(pos[(size_t)p * HID + c]));                              // embeddings += position_embeddings (fp16)
+        const float e = T::rnd(T::ld(word[id * HID + c]) + T::ld(type[ty * HID + c]));   // inputs_embeds + token_type_embeddings
+        x[i] = T::rnd(e + T::ld(pos[(size_t)p * HID + c]));                               // embeddings += position_embeddings
     }
-    layer_norm_768(x, lnw, lnb, eps, lane, out + (size_t)t * HID);
+    layer_norm_768<T>(x, lnw, lnb, eps, lane, out + (size_t)t * HID);
 }
 
-// one wave per token: LayerNorm(x.float()).type_as(x) on an fp16 [M,768] tensor
+// one wave per token: LayerNorm(x.float()).type_as(x) on a [T,768] tensor
+template <class T>
 __global__ void __launch_bounds__(256)
-ln_kernel(const uint16_t* __restrict__ in, const int* __restrict__ Tdev, const uint16_t* __restrict__ lnw, const uint16_t* __restrict__ lnb,
-          float eps, uint16_t* __restrict__ out) {
+ln_kernel(const typename T::elem* __restrict__ in, const int* __restrict__ Tdev, const typename T::elem* __restrict__ lnw,
+          const typename T::elem* __restrict__ lnb, float eps, typename T::elem* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= *Tdev) return;
     float x[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) x[i] = h2f(in[(size_t)t * HID + i * 64 + lane]);
-    layer_norm_768(x, lnw, lnb, eps, lane, out + (size_t)t * HID);
+    for (int i = 0; i < 12; ++i) x[i] = T::ld(in[(size_t)t * HID + i * 64 + lane]);
+    layer_norm_768<T>(x, lnw, lnb, eps, lane, out + (size_t)t * HID);
 }
 
 // ------------------------------------------------------------------------------------------
-// GEMM: C[M,N] (fp16) = A[M,K] (fp16, row-major) . W[N,K]^T (fp16, row-major) + bias[N], fp32 accumulate.
+// GEMM: C[M,N] = A[M,K] (row-major) . W[N,K]^T (row-major) + bias[N], fp32 accumulate, all tensors in the model dtype.
 // Computed transposed on the matrix cores (MFMA A operand = W rows, B operand = A rows) so that each lane ends up
-// with 4 consecutive OUTPUT COLUMNS of one token: the epilogue reads/writes 8 contiguous bytes per fragment.
-// 128 (cols) x 128 (tokens) x 64 tile, 4 waves as 2x2, each 64x64 = 4x4 fragments of v_mfma_f32_16x16x32_f16.
-// LDS: two 16 KB tiles per stage, 2 stages; 16-B chunks XOR-swizzled by (row & 7) so ds_read_b128 of 16 rows at one
-// k-chunk spreads over 8 bank groups. Global->LDS through registers; the next stage's loads are issued before the
-// current stage's MFMAs.
-//   EPI 0: C = fp16(acc + bias)                 (QKV projection, torch Linear)
-//   EPI 1: C = fp16(gelu_erf(fp16(acc + bias)))  (BertIntermediate)
-//   EPI 2: C = fp16(fp16(acc + bias) + R)        (dense + residual of BertSelfOutput / BertOutput; LayerNorm follows)
-// Requires N % 128 == 0, K % 64 == 0 (768, 2304, 3072 all are); M arbitrary.
+// with 4 consecutive OUTPUT COLUMNS of one token: the epilogue reads/writes 4 contiguous elements per fragment.
+// Tile = BCOL output columns x BTOK tokens x 128 BYTES of k (64 halves / 32 floats); WC x WT waves, each
+// (BCOL/WC) x (BTOK/WT) = FA x FB fragments of v_mfma 16x16. LDS: two stages of (BCOL + BTOK) x 128 B; the
+// 16-B chunks of a row are XOR-swizzled by (row & 7) so a fragment read of 16 rows at one k-chunk spreads over 8
+// bank groups. Global -> LDS by LDS-DMA (no registers); the next stage streams in under the current stage's MFMAs.
+//   EPI 1: C = dt(gelu_erf(dt(acc + bias)))    (BertIntermediate)
+//   EPI 2: C = dt(dt(acc + bias) + R)          (dense + residual of BertSelfOutput / BertOutput; LayerNorm follows)
+//   EPI 3: QKV projection: q | k columns to C [M,1536], v columns transposed to VT [n][768][Lp]
+// Requires N % BCOL == 0, K * sizeof(elem) % 128 == 0 (768, 2304, 3072 all are); M = cu[n] read from the device.
 // ------------------------------------------------------------------------------------------
-template <int EPI, int BCOL, int BTOK, int WC, int WT>
+template <class T, int EPI, int BCOL, int BTOK, int WC, int WT>
 __global__ void __launch_bounds__(WC * WT * 64)
-gemm_bt_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const uint16_t* __restrict__ bias,
-               const uint16_t* __restrict__ R, uint16_t* __restrict__ C, uint16_t* __restrict__ VT, const int* __restrict__ cu, int n,
-               const int2* __restrict__ tokinfo, int N, int K, int Lp) {
-    // tile: BCOL output columns x BTOK tokens x 64 (k); WC x WT waves, each (BCOL/WC) x (BTOK/WT) = FA x FB fragments
+gemm_bt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* __restrict__ W, const typename T::elem* __restrict__ bias,
+               const typename T::elem* __restrict__ R, typename T::elem* __restrict__ C, typename T::elem* __restrict__ VT,
+               const int* __restrict__ cu, int n, const int2* __restrict__ tokinfo, int N, int K, int Lp) {
+    typedef typename T::elem E;
     constexpr int NWV = WC * WT, FA = BCOL / WC / 16, FB = BTOK / WT / 16;
     constexpr int W_U4 = BCOL * 8, A_U4 = BTOK * 8;                  // uint4 per stage
+    constexpr int EPC = 16 / (int)sizeof(E);                           // elements per 16-B chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4* sW = (uint4*)smem_raw;                                      // [2][W_U4]
     uint4* sA = sW + 2 * W_U4;                                         // [2][A_U4]
@@ -174,8 +236,8 @@ gemm_bt_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
     const int wi = wave / WT, wj = wave % WT;
     // XCD-aware tile order (cdna guide T1): hardware block b runs on XCD b % 8, each XCD has its own L2. All column
     // tiles of one token tile are given to ONE XCD (token tile t -> XCD t % 8), so the big activation tile
-    // (BTOK x K) is fetched into one L2 once instead of into up to 8; the weights (<= 4.7 MB) fit every L2.
-    const int64_t M = cu[n];                                           // packed token count (grid covers n*L)
+    // (BTOK x K) is fetched into one L2 once instead of into up to 8; the weights (<= 9.4 MB) stay L2/MALL-resident.
+    const int64_t M = cu[n];                                           // packed token count (the grid covers n*L)
     const int ncol = N / BCOL;
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
     const int ctile = jj % ncol;
@@ -188,12 +250,13 @@ gemm_bt_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
     // global -> LDS without registers (global_load_lds_dwordx4): one wave instruction writes 1 KiB of LDS,
     // lane-linear, = 8 tile rows x 128 B. The bank-conflict swizzle therefore goes on the SOURCE address:
     // LDS[row][c] receives global chunk c ^ (row & 7); fragment reads apply the same XOR (cdna guide rule 21).
-    auto stage = [&](const int buf, const int k0) {
+    auto stage = [&](const int buf, const int kt) {
         const int ch = (lane & 7) ^ (lane >> 3);
+        const int k0 = kt * (8 * EPC) + ch * EPC;                      // element offset inside a row
 #pragma unroll
         for (int i = 0; i < BCOL / 8 / NWV; ++i) {
             const int rowbase = (wave * (BCOL / 8 / NWV) + i) * 8;
-            const uint16_t* gw = W + (size_t)(n0 + rowbase + (lane >> 3)) * K + k0 + ch * 8;
+            const E* gw = W + (size_t)(n0 + rowbase + (lane >> 3)) * K + k0;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw,
                                              (__attribute__((address_space(3))) void*)&sW[buf * W_U4 + rowbase * 8], 16, 0, 0);
         }
@@ -202,7 +265,7 @@ gemm_bt_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
             const int rowbase = (wave * (BTOK / 8 / NWV) + i) * 8;
             int64_t ar = m0 + rowbase + (lane >> 3);
             if (ar >= M) ar = M - 1;                                   // clamped: tail rows are never stored
-            const uint16_t* ga = A + (size_t)ar * K + k0 + ch * 8;
+            const E* ga = A + (size_t)ar * K + k0;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
                                              (__attribute__((address_space(3))) void*)&sA[buf * A_U4 + rowbase * 8], 16, 0, 0);
         }
@@ -214,31 +277,38 @@ gemm_bt_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
 #pragma unroll
         for (int b = 0; b < FB; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
 
+    // Per k-tile: (1) all fragments of the tile (both 64-B halves) are read into registers, (2) the LDS-DMA for the
+    // NEXT tile is issued into the other buffer, (3) the MFMAs run with that DMA in flight, (4) barrier.
+    // Order (1) -> (2) matters to hipcc: its waitcnt insertion drains vmcnt(0) in front of any LDS read that follows
+    // an in-flight LDS-DMA write it cannot prove disjoint, so a prefetch issued BEFORE the reads is drained at once
+    // and nothing overlaps (measured: -14 %). Issued after them, the only drain is the one __syncthreads needs anyway.
     stage(0, 0);
-    __syncthreads();                                   // (drains the LDS-DMA: hipcc puts vmcnt(0) in front of the barrier)
-    const int nk = K / 64;
+    __syncthreads();                                   // (vmcnt(0) + barrier: every wave's DMA has landed)
+    const int nk = K / (8 * EPC);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * 64);   // next tile streams in while this one is multiplied
+        uint4 fw[2][FA], fa[2][FB];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            h8 fw[FA], fa[FB];
 #pragma unroll
             for (int a = 0; a < FA; ++a) {
                 const int row = wi * (FA * 16) + a * 16 + lr;
-                fw[a] = __builtin_bit_cast(h8, sW[buf * W_U4 + row * 8 + ((ks * 4 + lg) ^ (row & 7))]);
+                fw[ks][a] = sW[buf * W_U4 + row * 8 + ((ks * 4 + lg) ^ (row & 7))];
             }
 #pragma unroll
             for (int b = 0; b < FB; ++b) {
                 const int row = wj * (FB * 16) + b * 16 + lr;
-                fa[b] = __builtin_bit_cast(h8, sA[buf * A_U4 + row * 8 + ((ks * 4 + lg) ^ (row & 7))]);
+                fa[ks][b] = sA[buf * A_U4 + row * 8 + ((ks * 4 + lg) ^ (row & 7))];
             }
+        }
+        if (kt + 1 < nk) stage(buf ^ 1, kt + 1);       // streams in while this tile is multiplied
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int a = 0; a < FA; ++a)
 #pragma unroll
-                for (int b = 0; b < FB; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[a], fa[b], acc[a][b], 0, 0, 0);
-        }
+                for (int b = 0; b < FB; ++b) acc[a][b] = T::mma(fw[ks][a], fa[ks][b], acc[a][b]);
+        __builtin_amdgcn_sched_barrier(0);             // keep the drain + barrier BEHIND the MFMAs (hipcc hoists it otherwise)
         __syncthreads();
     }
 
@@ -254,40 +324,36 @@ gemm_bt_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, c
 #pragma unroll
         for (int a = 0; a < FA; ++a) {
             const int col = n0 + wi * (FA * 16) + a * 16 + lg * 4;
-            const uint2 bb = *(const uint2*)(bias + col);
-            const uint16_t bh[4] = {(uint16_t)(bb.x & 0xffff), (uint16_t)(bb.x >> 16), (uint16_t)(bb.y & 0xffff), (uint16_t)(bb.y >> 16)};
-            uint16_t o[4];
-            uint16_t rr[4] = {0, 0, 0, 0};
-            if (EPI == 2) {
-                const uint2 rv = *(const uint2*)(R + (size_t)tok * N + col);
-                rr[0] = (uint16_t)(rv.x & 0xffff); rr[1] = (uint16_t)(rv.x >> 16); rr[2] = (uint16_t)(rv.y & 0xffff); rr[3] = (uint16_t)(rv.y >> 16);
-            }
+            float bv[4], rr[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+            load4<T>(bias + col, bv);
+            if (EPI == 2) load4<T>(R + (size_t)tok * N + col, rr);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = rh(acc[a][b][r] + h2f(bh[r]));                      // Linear output in fp16
+                float v = T::rnd(acc[a][b][r] + bv[r]);                                 // Linear output in the model dtype
                 if (EPI == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));   // exact-erf GELU in fp32
-                if (EPI == 2) v = rh(v) + h2f(rr[r]);                           // + input_tensor, fp16 add
-                o[r] = f2h(v);
+                if (EPI == 2) v = v + rr[r];                                            // + input_tensor
+                o[r] = v;                                                               // (rounded by the store)
             }
             if (EPI == 3) {
                 if (v_part) {
-                    // V^T[passage][h*64+d][key]: the PV product wants consecutive KEYS per lane (attention_kernel)
+                    // V^T[passage][h*64+d][key]: the PV product wants consecutive KEYS per lane (attention kernels)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) VT[((size_t)pb * HID + (col - 2 * HID + r)) * Lp + pos] = o[r];
+                    for (int r = 0; r < 4; ++r) VT[((size_t)pb * HID + (col - 2 * HID + r)) * Lp + pos] = T::st(o[r]);
                 } else {
-                    *(uint2*)(C + (size_t)tok * (2 * HID) + col) = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+                    store4<T>(C + (size_t)tok * (2 * HID) + col, o);
                 }
             } else {
-                *(uint2*)(C + (size_t)tok * N + col) = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+                store4<T>(C + (size_t)tok * N + col, o);
             }
         }
     }
 }
 
-// tile configurations (ATLAS_GEMM_CFG selects at run time; tuning)
-template <int EPI>
-static void launch_gemm(int cfg, hipStream_t stream, const uint16_t* A, const uint16_t* W, const uint16_t* bias, const uint16_t* R,
-                        uint16_t* C, uint16_t* VT, int64_t Mmax, const int* cu, int n, const int2* tokinfo, int N, int K, int Lp) {
+// tile configurations (ATLAS_GEMM_CFG overrides; tuning)
+template <class T, int EPI>
+static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, const typename T::elem* W, const typename T::elem* bias,
+                        const typename T::elem* R, typename T::elem* C, typename T::elem* VT, int64_t Mmax, const int* cu, int n,
+                        const int2* tokinfo, int N, int K, int Lp) {
     auto go = [&](auto kern, int bcol, int btok, int nthreads) {
         const size_t lds = (size_t)(bcol + btok) * 128 * 2;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -295,10 +361,9 @@ static void launch_gemm(int cfg, hipStream_t stream, const uint16_t* A, const ui
         hipLaunchKernelGGL(kern, dim3((mtiles + 7) / 8 * 8 * (N / bcol)), dim3(nthreads), lds, stream, A, W, bias, R, C, VT,
                            cu, n, tokinfo, N, K, Lp);
     };
-    if (cfg == 1) go(gemm_bt_kernel<EPI, 256, 128, 4, 2>, 256, 128, 512);
-    else if (cfg == 2) go(gemm_bt_kernel<EPI, 256, 256, 2, 4>, 256, 256, 512);
-    else if (cfg == 3) go(gemm_bt_kernel<EPI, 128, 256, 2, 4>, 128, 256, 512);
-    else go(gemm_bt_kernel<EPI, 128, 128, 2, 2>, 128, 128, 256);
+    if (cfg == 2) go(gemm_bt_kernel<T, EPI, 256, 256, 2, 4>, 256, 256, 512);
+    else if (cfg == 3) go(gemm_bt_kernel<T, EPI, 64, 64, 2, 2>, 64, 64, 256);
+    else go(gemm_bt_kernel<T, EPI, 128, 128, 2, 2>, 128, 128, 256);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -312,7 +377,7 @@ static void launch_gemm(int cfg, hipStream_t stream, const uint16_t* A, const ui
 //   transposition of V here (the QKV GEMM epilogue wrote V^T).
 // L <= 512; Lp = L rounded up to 32; MAXKF = compile-time bound on Lp/16.
 // ------------------------------------------------------------------------------------------
-template <int MAXKF>
+template <class T, int MAXKF>
 __global__ void __launch_bounds__(256)
 attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ vt, const int* __restrict__ cu, int LpMax,
                  uint16_t* __restrict__ ctx) {
@@ -361,18 +426,18 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
     const int nkf = Lp / 16;
     for (int qf = wave; qf * 16 < L; qf += 4) {
         int qrow = qf * 16 + lr; if (qrow >= L) qrow = L - 1;
-        const h8 q0 = __builtin_bit_cast(h8, *(const uint4*)(Qb + (size_t)qrow * (2 * HID) + lg * 8));
-        const h8 q1 = __builtin_bit_cast(h8, *(const uint4*)(Qb + (size_t)qrow * (2 * HID) + 32 + lg * 8));
+        const uint4 q0 = *(const uint4*)(Qb + (size_t)qrow * (2 * HID) + lg * 8);
+        const uint4 q1 = *(const uint4*)(Qb + (size_t)qrow * (2 * HID) + 32 + lg * 8);
         f4 s[MAXKF];
 #pragma unroll
         for (int kf = 0; kf < MAXKF; ++kf) {
             s[kf] = (f4){0.f, 0.f, 0.f, 0.f};
             if (kf < nkf) {
                 const int krow = kf * 16 + lr;
-                const h8 k0 = __builtin_bit_cast(h8, sK[krow * 8 + (lg ^ (krow & 7))]);
-                const h8 k1 = __builtin_bit_cast(h8, sK[krow * 8 + ((4 + lg) ^ (krow & 7))]);
-                s[kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, q0, s[kf], 0, 0, 0);
-                s[kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, q1, s[kf], 0, 0, 0);
+                const uint4 k0 = sK[krow * 8 + (lg ^ (krow & 7))];
+                const uint4 k1 = sK[krow * 8 + ((4 + lg) ^ (krow & 7))];
+                s[kf] = T::mma(k0, q0, s[kf]);
+                s[kf] = T::mma(k1, q1, s[kf]);
             }
         }
         float mx = -__builtin_inff();
@@ -383,8 +448,8 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
                 const float a4[4] = {am.x, am.y, am.z, am.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    // fp16(q.k) / sqrt(64) is exact in fp16; + mask is an fp16 add (modeling_bert.py:346-349)
-                    const float v = rh(rh(s[kf][r]) * 0.125f + a4[r]);
+                    // dt(q.k) / sqrt(64) is exact in fp16/bf16; + mask is an add in the model dtype (modeling_bert.py:346-349)
+                    const float v = T::rnd(T::rnd(s[kf][r]) * 0.125f + a4[r]);
                     s[kf][r] = v;
                     mx = fmaxf(mx, v);
                 }
@@ -412,18 +477,18 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
 #pragma unroll
         for (int ks = 0; ks < MAXKF / 2; ++ks)
             if (2 * ks < nkf) {
-                h8 pa;
+                uint32_t pw[4];                                         // softmax(...).type_as(model dtype)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    pa[e] = (_Float16)(s[2 * ks][e] * inv);             // softmax(...).type_as(fp16)
-                    pa[4 + e] = (_Float16)(s[2 * ks + 1][e] * inv);
+                for (int e = 0; e < 2; ++e) {
+                    pw[e] = (uint32_t)T::st(s[2 * ks][2 * e] * inv) | ((uint32_t)T::st(s[2 * ks][2 * e + 1] * inv) << 16);
+                    pw[2 + e] = (uint32_t)T::st(s[2 * ks + 1][2 * e] * inv) | ((uint32_t)T::st(s[2 * ks + 1][2 * e + 1] * inv) << 16);
                 }
+                const uint4 pa = make_uint4(pw[0], pw[1], pw[2], pw[3]);
 #pragma unroll
                 for (int df = 0; df < 4; ++df) {
                     const uint16_t* vrow = sVt + (df * 16 + lr) * vstride + ks * 32 + lg * 4;
                     const uint2 v0 = *(const uint2*)vrow, v1 = *(const uint2*)(vrow + 16);
-                    const h8 vb = __builtin_bit_cast(h8, make_uint4(v0.x, v0.y, v1.x, v1.y));
-                    o[df] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, vb, o[df], 0, 0, 0);
+                    o[df] = T::mma(pa, make_uint4(v0.x, v0.y, v1.x, v1.y), o[df]);
                 }
             }
         // context_layer.permute(0,2,1,3).view(.., 768): [token][h*64 + dim]
@@ -432,30 +497,127 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = qf * 16 + lg * 4 + r;
-                if (row < L) ctx[((size_t)tb + row) * HID + h * DHEAD + df * 16 + lr] = f2h(o[df][r]);
+                if (row < L) ctx[((size_t)tb + row) * HID + h * DHEAD + df * 16 + lr] = T::st(o[df][r]);
+            }
+    }
+}
+
+// fp32 model precision (query embedding with --precision fp32, atlas.py:104): same S^T trick with v_mfma 16x16x4 f32.
+// After S^T = K.Q^T lane (lr, lg) holds query lr x keys 16kf+4lg+r; taking the contraction index of P.V step (kf, r)
+// as lane group lg <-> key 16kf+4lg+r makes those registers the A operand as they are, and the B operand
+// V^T[dim][16kf+4lg .. +3] one 16-byte load. Operands come straight from global memory / L2: this path serves query
+// batches (tens of tokens each after packing), not the bulk refresh. L <= 512.
+template <int MAXKF>
+__global__ void __launch_bounds__(256)
+attention_f32_kernel(const float* __restrict__ qk, const float* __restrict__ vt, const int* __restrict__ cu, int LpMax,
+                     float* __restrict__ ctx) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int b = blockIdx.x / NHEAD, h = blockIdx.x % NHEAD;
+    const int tb = cu[b], L = cu[b + 1] - tb;
+    if (L <= 0) return;
+    const int nkf = (L + 15) >> 4;
+    const float* Qb = qk + (size_t)tb * (2 * HID) + h * DHEAD;
+    const float* Kb = Qb + HID;
+    const float* Vt = vt + ((size_t)b * HID + h * DHEAD) * LpMax;
+    for (int qf = wave; qf * 16 < L; qf += 4) {
+        int qrow = qf * 16 + lr; if (qrow >= L) qrow = L - 1;
+        uint4 q[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[c] = *(const uint4*)(Qb + (size_t)qrow * (2 * HID) + c * 16 + lg * 4);
+        f4 s[MAXKF];
+#pragma unroll
+        for (int kf = 0; kf < MAXKF; ++kf) {
+            s[kf] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (kf < nkf) {
+                int krow = kf * 16 + lr; if (krow >= L) krow = L - 1;      // (masked below)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s[kf] = F32::mma(*(const uint4*)(Kb + (size_t)krow * (2 * HID) + c * 16 + lg * 4), q[c], s[kf]);
+            }
+        }
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int kf = 0; kf < MAXKF; ++kf)
+            if (kf < nkf) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = (kf * 16 + lg * 4 + r < L) ? s[kf][r] * 0.125f : -__builtin_inff();   // / sqrt(64), + 0 mask
+                    s[kf][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kf = 0; kf < MAXKF; ++kf)
+            if (kf < nkf) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = expf(s[kf][r] - mx);
+                    s[kf][r] = e;
+                    sum += e;
+                }
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        f4 o[4];
+#pragma unroll
+        for (int df = 0; df < 4; ++df) o[df] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kf = 0; kf < MAXKF; ++kf)
+            if (kf < nkf) {
+                const int key0 = kf * 16 + lg * 4;
+                const uint4 pa = make_uint4(__builtin_bit_cast(uint32_t, s[kf][0] / sum), __builtin_bit_cast(uint32_t, s[kf][1] / sum),
+                                            __builtin_bit_cast(uint32_t, s[kf][2] / sum), __builtin_bit_cast(uint32_t, s[kf][3] / sum));
+#pragma unroll
+                for (int df = 0; df < 4; ++df) {
+                    uint4 vv = *(const uint4*)(Vt + (size_t)(df * 16 + lr) * LpMax + key0);
+                    if (key0 + 0 >= L) vv.x = 0u;                          // columns >= L were never written
+                    if (key0 + 1 >= L) vv.y = 0u;
+                    if (key0 + 2 >= L) vv.z = 0u;
+                    if (key0 + 3 >= L) vv.w = 0u;
+                    o[df] = F32::mma(pa, vv, o[df]);
+                }
+            }
+#pragma unroll
+        for (int df = 0; df < 4; ++df)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = qf * 16 + lg * 4 + r;
+                if (row < L) ctx[((size_t)tb + row) * HID + h * DHEAD + df * 16 + lr] = o[df][r];
             }
     }
 }
 
 // masked mean pooling (retrievers.py:50-52) over the packed tokens of one passage, with the reference's two roundings:
-// fp16(sum) (the fp16 tensor .sum(dim=1) returns), then fp16(that / count); the row goes straight to out (= a slab row,
-// atlas.py:79). The sum itself is exact (fp16 addends in double), which no summation order of the reference beats.
+// dt(sum) (the tensor .sum(dim=1) returns), then dt(that / count); the row goes straight to out (= a slab row,
+// atlas.py:79). The sum is accumulated in double (exact for fp16/bf16 addends), which no summation order of the
+// reference beats.
+template <class T>
 __global__ void __launch_bounds__(192)
-pool_packed_kernel(const uint16_t* __restrict__ x, const int* __restrict__ cu, uint16_t* __restrict__ out) {
+pool_packed_kernel(const typename T::elem* __restrict__ x, const int* __restrict__ cu, typename T::elem* __restrict__ out) {
     const int b = blockIdx.x;
     const int tb = cu[b], L = cu[b + 1] - tb;
-    const uint16_t* base = x + (size_t)tb * HID + threadIdx.x * 4;
+    const typename T::elem* base = x + (size_t)tb * HID + threadIdx.x * 4;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     for (int l = 0; l < L; ++l) {
-        const uint2 v = *(const uint2*)(base + (size_t)l * HID);
-        s[0] += f16_bits_to_f64((uint16_t)(v.x & 0xffff)); s[1] += f16_bits_to_f64((uint16_t)(v.x >> 16));
-        s[2] += f16_bits_to_f64((uint16_t)(v.y & 0xffff)); s[3] += f16_bits_to_f64((uint16_t)(v.y >> 16));
+        float v[4];
+        load4<T>(base + (size_t)l * HID, v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] += (double)v[r];
     }
     const float cnt = (float)L;                                   // attention_mask.sum(dim=1): 0 -> 0/0 = NaN as in torch
-    uint16_t o[4];
+    float o[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = f32_to_f16_bits(f16_bits_to_f32(f64_to_f16_bits(s[r])) / cnt);
-    *(uint2*)(out + (size_t)b * HID + threadIdx.x * 4) = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+    for (int r = 0; r < 4; ++r) {
+        float sum;
+        if (T::DT == ATLAS_DT_F16) sum = f16_bits_to_f32(f64_to_f16_bits(s[r]));     // single rounding double -> fp16
+        else if (T::DT == ATLAS_DT_BF16) sum = T::rnd((float)s[r]);                  // (double -> float -> bf16: the float step is
+        else sum = (float)s[r];                                                       //  exact unless > 24 significant bits are live)
+        o[r] = sum / cnt;
+    }
+    store4<T>(out + (size_t)b * HID + threadIdx.x * 4, o);
 }
 
 // ==========================================================================================
@@ -463,77 +625,95 @@ pool_packed_kernel(const uint16_t* __restrict__ x, const int* __restrict__ cu, u
 // ==========================================================================================
 namespace {
 inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
-}
+inline size_t esize(int dt) { return dt == ATLAS_DT_F32 ? 4 : 2; }
 
-extern "C" {
-
-size_t atlas_contriever_workspace_bytes(int n, int L) {
-    if (n <= 0 || L <= 0) return 0;
-    const size_t M = (size_t)n * L, Lp = (size_t)((L + 31) & ~31);
-    // x, ctx, u : [M,768]; qk : [M,1536]; vt : [n,768,Lp]; h : [M,3072]; counts[n], cu[n+1], tokinfo[M]
-    return up256(M * HID * 2) * 3 + up256(M * 2 * HID * 2) + up256((size_t)n * HID * Lp * 2) + up256(M * 4 * HID * 2) +
-           up256((size_t)n * 4) + up256((size_t)(n + 1) * 4) + up256(M * 8) + 256;
-}
-
-int atlas_contriever_embed(const atlas_bert_weights* w, const int64_t* input_ids, const int64_t* attention_mask,
-                           const int64_t* token_type_ids, int n, int L, void* out_f16, void* ws, size_t ws_bytes,
-                           void* stream_) {
-    if (!w || !input_ids || !attention_mask || !out_f16 || !ws) return ATLAS_E_BADARG;
-    if (n <= 0 || L <= 0) return ATLAS_E_BADARG;
-    if (L > 512 || w->hidden != HID || w->n_heads != NHEAD || w->intermediate != 4 * HID || w->n_layers < 1 ||
-        w->n_layers > ATLAS_BERT_MAX_LAYERS || (int64_t)n * L > 0x7fffffff)
-        return ATLAS_E_UNSUPPORTED;
-    if (ws_bytes < atlas_contriever_workspace_bytes(n, L)) return ATLAS_E_WORKSPACE;
-    hipStream_t stream = (hipStream_t)stream_;
+template <class T>
+int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids,
+                int n, int L, void* out, void* ws, hipStream_t stream) {
+    typedef typename T::elem E;
+    const size_t es = sizeof(E);
     const int64_t M = (int64_t)n * L;                 // worst case; the packed count lives on the device (cu[n])
     const int Lp = (L + 31) & ~31;
     unsigned char* p = (unsigned char*)ws;
-    uint16_t* x = (uint16_t*)p;   p += up256((size_t)M * HID * 2);
-    uint16_t* ctx = (uint16_t*)p; p += up256((size_t)M * HID * 2);
-    uint16_t* u = (uint16_t*)p;   p += up256((size_t)M * HID * 2);
-    uint16_t* qk = (uint16_t*)p;  p += up256((size_t)M * 2 * HID * 2);
-    uint16_t* vt = (uint16_t*)p;  p += up256((size_t)n * HID * Lp * 2);
-    uint16_t* hbuf = (uint16_t*)p; p += up256((size_t)M * 4 * HID * 2);
+    E* x = (E*)p;    p += up256((size_t)M * HID * es);
+    E* ctx = (E*)p;  p += up256((size_t)M * HID * es);
+    E* u = (E*)p;    p += up256((size_t)M * HID * es);
+    E* qk = (E*)p;   p += up256((size_t)M * 2 * HID * es);
+    E* vt = (E*)p;   p += up256((size_t)n * HID * Lp * es);
+    E* hbuf = (E*)p; p += up256((size_t)M * 4 * HID * es);
     int* counts = (int*)p;        p += up256((size_t)n * 4);
     int* cu = (int*)p;            p += up256((size_t)(n + 1) * 4);
     int2* tokinfo = (int2*)p;
 
     const unsigned tok_blocks = (unsigned)((M + 3) / 4), pas_blocks = (unsigned)((n + 3) / 4);
+    // 256x256 tiles measured best for the bulk refresh (profiles/r01/e01); small batches (queries) need more,
+    // smaller tiles to cover the 256 CUs: 64 queries x ~20 tokens are 21 x 12 tiles of 64x64 for a 768-wide GEMM
     const char* cfg_env = getenv("ATLAS_GEMM_CFG");
-    const int cfg = cfg_env ? atoi(cfg_env) : 2;        // 256x256 tiles measured best (profiles/r01/e01)
-    const size_t att_lds = (size_t)Lp * 128 + (size_t)64 * (Lp + 8) * 2 + (size_t)Lp * 4;
-    (void)hipFuncSetAttribute((const void*)attention_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)attention_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)attention_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int cfg = cfg_env ? atoi(cfg_env) : (M > 16384 ? 2 : (M > 4096 ? 0 : 3));
     hipLaunchKernelGGL(count_kernel, dim3(pas_blocks), dim3(256), 0, stream, attention_mask, n, L, counts);
     hipLaunchKernelGGL(pack_kernel, dim3(pas_blocks), dim3(256), 0, stream, attention_mask, n, L, counts, cu, tokinfo);
-    hipLaunchKernelGGL(embed_ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, input_ids, token_type_ids, L, cu, n, tokinfo,
-                       (const uint16_t*)w->word_emb, (const uint16_t*)w->pos_emb, (const uint16_t*)w->type_emb,
-                       (const uint16_t*)w->emb_ln_w, (const uint16_t*)w->emb_ln_b, w->eps, x);
+    hipLaunchKernelGGL(embed_ln_kernel<T>, dim3(tok_blocks), dim3(256), 0, stream, input_ids, token_type_ids, L, cu, n, tokinfo,
+                       (const E*)w->word_emb, (const E*)w->pos_emb, (const E*)w->type_emb, (const E*)w->emb_ln_w,
+                       (const E*)w->emb_ln_b, w->eps, x);
     for (int l = 0; l < w->n_layers; ++l) {
         const atlas_bert_layer& ly = w->layers[l];
-        launch_gemm<3>(cfg, stream, x, (const uint16_t*)ly.qkv_w, (const uint16_t*)ly.qkv_b, (const uint16_t*)nullptr, qk, vt, M,
-                       cu, n, tokinfo, 3 * HID, HID, Lp);
-        if (Lp <= 128)
-            hipLaunchKernelGGL(attention_kernel<8>, dim3((unsigned)n * NHEAD), dim3(256), att_lds, stream, qk, vt, cu, Lp, ctx);
-        else if (Lp <= 256)
-            hipLaunchKernelGGL(attention_kernel<16>, dim3((unsigned)n * NHEAD), dim3(256), att_lds, stream, qk, vt, cu, Lp, ctx);
-        else
-            hipLaunchKernelGGL(attention_kernel<32>, dim3((unsigned)n * NHEAD), dim3(256), att_lds, stream, qk, vt, cu, Lp, ctx);
-        launch_gemm<2>(cfg, stream, ctx, (const uint16_t*)ly.o_w, (const uint16_t*)ly.o_b, x, u, (uint16_t*)nullptr, M, cu, n, tokinfo,
-                       HID, HID, Lp);
-        hipLaunchKernelGGL(ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, u, cu + n, (const uint16_t*)ly.ln1_w,
-                           (const uint16_t*)ly.ln1_b, w->eps, x);
-        launch_gemm<1>(cfg, stream, x, (const uint16_t*)ly.ff1_w, (const uint16_t*)ly.ff1_b, (const uint16_t*)nullptr, hbuf,
-                       (uint16_t*)nullptr, M, cu, n, tokinfo, 4 * HID, HID, Lp);
-        launch_gemm<2>(cfg, stream, hbuf, (const uint16_t*)ly.ff2_w, (const uint16_t*)ly.ff2_b, x, u, (uint16_t*)nullptr, M, cu, n,
-                       tokinfo, HID, 4 * HID, Lp);
-        hipLaunchKernelGGL(ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, u, cu + n, (const uint16_t*)ly.ln2_w,
-                           (const uint16_t*)ly.ln2_b, w->eps, x);
+        launch_gemm<T, 3>(cfg, stream, x, (const E*)ly.qkv_w, (const E*)ly.qkv_b, (const E*)nullptr, qk, vt, M, cu, n, tokinfo,
+                          3 * HID, HID, Lp);
+        if constexpr (T::DT == ATLAS_DT_F32) {
+            if (Lp <= 128)
+                hipLaunchKernelGGL(attention_f32_kernel<8>, dim3((unsigned)n * NHEAD), dim3(256), 0, stream, qk, vt, cu, Lp, ctx);
+            else
+                hipLaunchKernelGGL(attention_f32_kernel<32>, dim3((unsigned)n * NHEAD), dim3(256), 0, stream, qk, vt, cu, Lp, ctx);
+        } else {
+            const size_t att_lds = (size_t)Lp * 128 + (size_t)64 * (Lp + 8) * 2 + (size_t)Lp * 4;
+            auto att = [&](auto kern) {
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipLaunchKernelGGL(kern, dim3((unsigned)n * NHEAD), dim3(256), att_lds, stream, qk, vt, cu, Lp, ctx);
+            };
+            if (Lp <= 128) att(attention_kernel<T, 8>);
+            else if (Lp <= 256) att(attention_kernel<T, 16>);
+            else att(attention_kernel<T, 32>);
+        }
+        launch_gemm<T, 2>(cfg, stream, ctx, (const E*)ly.o_w, (const E*)ly.o_b, x, u, (E*)nullptr, M, cu, n, tokinfo, HID, HID, Lp);
+        hipLaunchKernelGGL(ln_kernel<T>, dim3(tok_blocks), dim3(256), 0, stream, u, cu + n, (const E*)ly.ln1_w, (const E*)ly.ln1_b,
+                           w->eps, x);
+        launch_gemm<T, 1>(cfg, stream, x, (const E*)ly.ff1_w, (const E*)ly.ff1_b, (const E*)nullptr, hbuf, (E*)nullptr, M, cu, n,
+                          tokinfo, 4 * HID, HID, Lp);
+        launch_gemm<T, 2>(cfg, stream, hbuf, (const E*)ly.ff2_w, (const E*)ly.ff2_b, x, u, (E*)nullptr, M, cu, n, tokinfo, HID,
+                          4 * HID, Lp);
+        hipLaunchKernelGGL(ln_kernel<T>, dim3(tok_blocks), dim3(256), 0, stream, u, cu + n, (const E*)ly.ln2_w, (const E*)ly.ln2_b,
+                           w->eps, x);
     }
-    // rows written contiguously at out_f16 (which may point into the passage slab: slab + row_offset * 768)
-    hipLaunchKernelGGL(pool_packed_kernel, dim3((unsigned)n), dim3(192), 0, stream, x, cu, (uint16_t*)out_f16);
+    // rows written contiguously at out (which may point into the passage slab: slab + row_offset * 768)
+    hipLaunchKernelGGL(pool_packed_kernel<T>, dim3((unsigned)n), dim3(192), 0, stream, x, cu, (E*)out);
     return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" {
+
+size_t atlas_contriever_workspace_bytes(int n, int L, int dtype) {
+    if (n <= 0 || L <= 0) return 0;
+    const size_t M = (size_t)n * L, Lp = (size_t)((L + 31) & ~31), es = esize(dtype);
+    // x, ctx, u : [M,768]; qk : [M,1536]; vt : [n,768,Lp]; h : [M,3072]; counts[n], cu[n+1], tokinfo[M]
+    return up256(M * HID * es) * 3 + up256(M * 2 * HID * es) + up256((size_t)n * HID * Lp * es) + up256(M * 4 * HID * es) +
+           up256((size_t)n * 4) + up256((size_t)(n + 1) * 4) + up256(M * 8) + 256;
+}
+
+int atlas_contriever_embed(const atlas_bert_weights* w, const int64_t* input_ids, const int64_t* attention_mask,
+                           const int64_t* token_type_ids, int n, int L, void* out, void* ws, size_t ws_bytes,
+                           void* stream_) {
+    if (!w || !input_ids || !attention_mask || !out || !ws) return ATLAS_E_BADARG;
+    if (n <= 0 || L <= 0) return ATLAS_E_BADARG;
+    if (L > 512 || w->hidden != HID || w->n_heads != NHEAD || w->intermediate != 4 * HID || w->n_layers < 1 ||
+        w->n_layers > ATLAS_BERT_MAX_LAYERS || (int64_t)n * L > 0x7fffffff)
+        return ATLAS_E_UNSUPPORTED;
+    if (w->dtype != ATLAS_DT_F16 && w->dtype != ATLAS_DT_BF16 && w->dtype != ATLAS_DT_F32) return ATLAS_E_UNSUPPORTED;
+    if (ws_bytes < atlas_contriever_workspace_bytes(n, L, w->dtype)) return ATLAS_E_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (w->dtype == ATLAS_DT_F16) return run_encoder<F16>(w, input_ids, attention_mask, token_type_ids, n, L, out, ws, stream);
+    if (w->dtype == ATLAS_DT_BF16) return run_encoder<BF16>(w, input_ids, attention_mask, token_type_ids, n, L, out, ws, stream);
+    return run_encoder<F32>(w, input_ids, attention_mask, token_type_ids, n, L, out, ws, stream);
 }
 
 }  // extern "C"

@@ -7,14 +7,15 @@ What is mirrored (same names, argument meaning, state-dict keys):
                                          `retriever.contriever.*` load unchanged, model_io.py:62-71)
     BaseRetriever / DualEncoderRetriever / UntiedDualEncoderRetriever   retrievers.py:63-135
 
-What runs on the GPU: the fp16 inference copy that `Atlas.build_index` / `retrieve_with_rerank` create with
-`copy.deepcopy(retriever).half().eval()` (atlas.py:54-59, 78, 168) — i.e. every passage embedding of an index
-refresh — goes through the C-ABI `atlas_contriever_embed` (hand-written MFMA GEMMs, fused attention, the
-reference's non-standard LayerNorm, pooling). There is no eager-PyTorch fallback for that path.
+What runs on the GPU: every inference forward of the module goes through the C-ABI `atlas_contriever_embed`
+(hand-written MFMA GEMMs, fused attention, the reference's non-standard LayerNorm, pooling; token packing so that
+padding costs nothing) in the dtype of its parameters:
+    fp16   the inference copy `copy.deepcopy(retriever).half().eval()` of `Atlas.build_index` /
+           `retrieve_with_rerank` (atlas.py:54-59, 78, 168): every passage embedding of an index refresh
+    fp32 / bf16 / fp16   query embedding in model precision (`--precision`, atlas.py:104)
+There is no eager-PyTorch fallback.
 
-Not provided yet (raises AtlasHipError): forward in fp32/bf16 or with autograd (query embedding in model
-precision and retriever training, atlas.py:104, 457-465) — SURVEY.md §8 "next"; the reference module keeps
-serving those until a fp32 HIP encoder exists.
+Not provided (raises AtlasHipError): forward with autograd (retriever training, atlas.py:457-465); CPU tensors.
 """
 import copy
 import ctypes
@@ -124,6 +125,7 @@ class Contriever(nn.Module):
         w = _lib.BertWeights()
         w.n_layers, w.n_heads, w.hidden, w.intermediate = c.num_hidden_layers, c.num_attention_heads, c.hidden_size, c.intermediate_size
         w.eps = float(c.layer_norm_eps)
+        w.dtype = _lib.torch_dtype_code(self.embeddings.word_embeddings.weight.dtype)
         e = self.embeddings
         w.word_emb, w.pos_emb, w.type_emb = dev(e.word_embeddings.weight), dev(e.position_embeddings.weight), dev(e.token_type_embeddings.weight)
         w.emb_ln_w, w.emb_ln_b = dev(e.LayerNorm.weight), dev(e.LayerNorm.bias)
@@ -141,29 +143,47 @@ class Contriever(nn.Module):
         return w
 
     def _check_accelerated(self):
-        p = self.embeddings.word_embeddings.weight
-        if p.dtype != torch.float16 or not p.is_cuda:
+        params = list(self.parameters())
+        p = params[0]
+        if not p.is_cuda:
+            raise _lib.AtlasHipError("atlas_amd.Contriever runs on an MI355X only; there is no CPU / eager fallback")
+        if p.dtype not in (torch.float16, torch.bfloat16, torch.float32) or any(q.dtype != p.dtype for q in params):
+            raise _lib.AtlasHipError(f"unsupported / mixed parameter dtype {p.dtype}")
+        if torch.is_grad_enabled() and any(q.requires_grad for q in params):
             raise _lib.AtlasHipError(
-                "atlas_amd.Contriever runs the fp16 inference copy on an MI355X only (the copy Atlas.build_index makes with "
-                ".half().eval()); fp32/bf16 or training forward is not implemented here yet and there is no eager fallback"
+                "atlas_amd.Contriever is an inference encoder (index refresh, query embedding under torch.no_grad()); "
+                "a forward that needs autograd (retriever training) is not implemented and there is no eager fallback"
             )
         if self.config.pooling != "average":
             raise _lib.AtlasHipError(f"pooling={self.config.pooling!r} is not implemented (atlas uses 'average')")
+        return p.dtype
 
-    @torch.no_grad()
-    def embed_into(self, out: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor, token_type_ids=None):
-        """Encode a batch and write the (n, 768) fp16 embeddings into `out` (contiguous rows; may be a slice of
-        the index slab, which fuses atlas.py:79 into the pooling epilogue)."""
-        self._check_accelerated()
+    def embed_into(self, out: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor, token_type_ids=None,
+                   trim_padding=False):
+        """Encode a batch and write the (n, 768) embeddings (model dtype) into `out` (contiguous rows; for the
+        fp16 copy it may be a slice of the index slab, which fuses atlas.py:79 into the pooling epilogue).
+
+        Only unmasked tokens are computed (packed on the device, no host sync). trim_padding=True additionally cuts
+        the all-padding tail columns first (one host sync): the launch grids and the GEMM tile shape are sized by
+        n*L, which for queries tokenised with padding='max_length' is ~20x the real token count."""
+        dtype = self._check_accelerated()
         L = _lib.lib()
         n, seq = input_ids.shape
-        assert out.dtype == torch.float16 and out.is_contiguous() and tuple(out.shape) == (n, EMBEDDINGS_DIM)
+        assert out.dtype == dtype and out.is_contiguous() and tuple(out.shape) == (n, EMBEDDINGS_DIM)
+        if n == 0:
+            return out
+        if trim_padding:
+            used = (attention_mask != 0).any(dim=0).nonzero()
+            seq = int(used.max()) + 1 if used.numel() else 1
+            input_ids, attention_mask = input_ids[:, :seq], attention_mask[:, :seq]
+            token_type_ids = token_type_ids[:, :seq] if token_type_ids is not None else None
         ids = input_ids.to(torch.int64).contiguous()
         mask = attention_mask.to(torch.int64).contiguous()
         tt = token_type_ids.to(torch.int64).contiguous() if token_type_ids is not None else None
         w = self._pack()
-        need = L.atlas_contriever_workspace_bytes(n, seq)
+        need = L.atlas_contriever_workspace_bytes(n, seq, w.dtype)
         if self._ws is None or self._ws.numel() < need or self._ws.device != ids.device:
+            self._ws = None
             self._ws = torch.empty(int(need), dtype=torch.uint8, device=ids.device)
         stream = torch.cuda.current_stream(ids.device).cuda_stream
         _lib.check(L.atlas_contriever_embed(ctypes.byref(w), ids.data_ptr(), mask.data_ptr(), tt.data_ptr() if tt is not None else None,
@@ -173,11 +193,12 @@ class Contriever(nn.Module):
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
                 inputs_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None, output_attentions=None,
-                output_hidden_states=None, normalize=False):
+                output_hidden_states=None, normalize=False, trim_padding=False):
         """retrievers.py:22-60. Only the arguments atlas.py passes are supported (ids, mask, token_type_ids)."""
         assert position_ids is None and head_mask is None and inputs_embeds is None and encoder_hidden_states is None
-        out = torch.empty((input_ids.shape[0], EMBEDDINGS_DIM), dtype=torch.float16, device=input_ids.device)
-        self.embed_into(out, input_ids, attention_mask, token_type_ids)
+        dtype = self.embeddings.word_embeddings.weight.dtype
+        out = torch.empty((input_ids.shape[0], EMBEDDINGS_DIM), dtype=dtype, device=input_ids.device)
+        self.embed_into(out, input_ids, attention_mask, token_type_ids, trim_padding=trim_padding)
         if normalize:
             out = torch.nn.functional.normalize(out, dim=-1).clone()
         return out
@@ -239,6 +260,9 @@ class DualEncoderRetriever(BaseRetriever):
         return self.contriever(*args, **kwargs)
 
     def embed_queries(self, *args, **kwargs):
+        # queries are tokenised with padding="max_length" (atlas.py retriever_tokenize): cut the all-padding tail
+        if isinstance(self.contriever, Contriever):
+            kwargs.setdefault("trim_padding", True)
         return self._embed(*args, **kwargs)
 
     def embed_passages(self, *args, **kwargs):
@@ -257,6 +281,8 @@ class UntiedDualEncoderRetriever(BaseRetriever):
         self.passage_contriever = passage_encoder
 
     def embed_queries(self, *args, **kwargs):
+        if isinstance(self.query_contriever, Contriever):
+            kwargs.setdefault("trim_padding", True)
         return self.query_contriever(*args, **kwargs)
 
     def embed_passages(self, *args, **kwargs):

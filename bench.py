@@ -189,7 +189,7 @@ def main():
         from atlas_amd import retrievers
 
         torch.manual_seed(99)
-        enc = retrievers.Contriever(retrievers.BertConfigLite()).half().eval().to(dev)
+        enc = retrievers.Contriever(retrievers.BertConfigLite()).half().eval().to(dev).requires_grad_(False)
         Lr, nb = args.refresh_len, 512
         g = torch.Generator(device=dev).manual_seed(4321 + rank)
         ids = torch.randint(1000, 30522, (nb, Lr), generator=g, device=dev)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ATLAS_ABI_VERSION 1
+#define ATLAS_ABI_VERSION 2
 
 /* negative return codes */
 #define ATLAS_E_BADARG     (-1)  /* null pointer, B<=0, k<=0, d unsupported ...        */
@@ -136,17 +136,22 @@ int atlas_merge_packed(const uint64_t* gathered, int W, int B, int k, uint64_t* 
 int atlas_pool_write(const void* hidden_f16, const int64_t* mask, void* slab_f16, int64_t N,
                      int64_t row_offset, int n, int L, int d, void* stream);
 
-/* ---- index refresh: Contriever passage encoder (replaces src/retrievers.py:22-60 + src/modeling_bert.py) -----
- * The fp16 inference copy `copy.deepcopy(retriever).half().eval()` of Atlas.build_index (src/atlas.py:54-59,78):
- * BERT-base encoder (12 x [QKV, attention with fp32 softmax, out-proj + residual + LayerNorm, FFN with exact-erf
- * GELU + residual + LayerNorm]; the reference's NON-standard LayerNorm, modeling_bert.py:104-114) + masked mean
- * pooling, every intermediate rounded to fp16 where the reference materialises an fp16 tensor.
- * All weights are fp16 device pointers, Linear weights row-major [out][in] as in the HF state dict;
- * qkv_w = rows of query.weight | key.weight | value.weight ([2304][768]), qkv_b likewise.
- *   input_ids, attention_mask, token_type_ids (nullable): int64 [n x L] device tensors (HF tokenizer output)
- *   out_f16: [n x 768] fp16 rows, contiguous; may point into the passage slab (slab + row_offset*768), which
- *            makes the refresh write atlas.py:79 part of the pooling epilogue
- * Supports hidden=768, heads=12, intermediate=3072, L <= 512 (BERT_MAX_SEQ_LENGTH, atlas.py:23); else UNSUPPORTED.
+/* ---- Contriever encoder (replaces src/retrievers.py:22-60 + src/modeling_bert.py) ---------------------------
+ * Index refresh: the fp16 inference copy `copy.deepcopy(retriever).half().eval()` of Atlas.build_index
+ * (src/atlas.py:54-59,78). Query embedding: the retriever in model precision (src/atlas.py:104; --precision
+ * fp32 | fp16 | bf16). BERT-base encoder (12 x [QKV, attention with fp32 softmax, out-proj + residual + LayerNorm,
+ * FFN with exact-erf GELU + residual + LayerNorm]; the reference's NON-standard LayerNorm, modeling_bert.py:104-114)
+ * + masked mean pooling, every intermediate rounded to the model dtype where the reference materialises a tensor
+ * of that dtype. Inference only (no autograd).
+ * All weights are device pointers of dtype `dtype` (ATLAS_DT_*), Linear weights row-major [out][in] as in the HF
+ * state dict; qkv_w = rows of query.weight | key.weight | value.weight ([2304][768]), qkv_b likewise.
+ *   input_ids, attention_mask, token_type_ids (nullable): int64 [n x L] device tensors (HF tokenizer output);
+ *            attention_mask is any 0/1 pattern. Only tokens with mask != 0 are computed (packed on the device, no
+ *            host sync): cost follows the real token count, results do not depend on the padding.
+ *   out:     [n x 768] rows of `dtype`, contiguous; for fp16 it may point into the passage slab
+ *            (slab + row_offset*768), which makes the refresh write atlas.py:79 part of the pooling epilogue.
+ *            A row whose mask is all zero is NaN (0/0), as in the reference.
+ *   L <= 512, hidden 768, 12 heads, intermediate 3072 (ATLAS_E_UNSUPPORTED otherwise).
  */
 #define ATLAS_BERT_MAX_LAYERS 24
 typedef struct {
@@ -155,12 +160,13 @@ typedef struct {
 typedef struct {
     int n_layers, n_heads, hidden, intermediate;
     float eps;                                   /* config.layer_norm_eps */
+    int dtype;                                   /* ATLAS_DT_F16 | ATLAS_DT_BF16 | ATLAS_DT_F32: weights, activations, output */
     const void *word_emb, *pos_emb, *type_emb, *emb_ln_w, *emb_ln_b;
     atlas_bert_layer layers[ATLAS_BERT_MAX_LAYERS];
 } atlas_bert_weights;
-size_t atlas_contriever_workspace_bytes(int n, int L);
+size_t atlas_contriever_workspace_bytes(int n, int L, int dtype);
 int atlas_contriever_embed(const atlas_bert_weights* w /* host struct of device pointers */, const int64_t* input_ids,
-                           const int64_t* attention_mask, const int64_t* token_type_ids, int n, int L, void* out_f16,
+                           const int64_t* attention_mask, const int64_t* token_type_ids, int n, int L, void* out,
                            void* ws, size_t ws_bytes, void* stream);
 
 /* ---- slab statistics ------------------------------------------------------------

@@ -21,7 +21,7 @@ def _models(layers=12, seed=3):
     mine = retrievers.Contriever(retrievers.BertConfigLite(num_hidden_layers=layers))
     missing = mine.load_state_dict(ref.state_dict(), strict=True)      # HF parameter names on both sides
     assert not missing.missing_keys and not missing.unexpected_keys
-    return ref, mine.half().eval().cuda()
+    return ref, mine.half().eval().cuda().requires_grad_(False)     # (atlas.py calls it under torch.no_grad())
 
 
 def _batch(n, L, seed):
@@ -72,14 +72,49 @@ def test_deepcopy_half_eval_like_atlas(gpu_index_cls):
     from atlas_amd import retrievers
 
     ref, mine = _models(2)
-    r = retrievers.DualEncoderRetriever(types.SimpleNamespace(), mine.float())
-    r16 = copy.deepcopy(r).half().eval()
+    r = retrievers.DualEncoderRetriever(types.SimpleNamespace(), mine.float().requires_grad_(True))
     ids, mask = _batch(4, 16, 9)
-    e = r16(input_ids=ids.cuda(), attention_mask=mask.cuda(), is_passages=True)       # atlas.py:78 passes **batch_enc
+    with torch.no_grad():
+        r16 = copy.deepcopy(r).half().eval()
+        e = r16(input_ids=ids.cuda(), attention_mask=mask.cuda(), is_passages=True)   # atlas.py:78 passes **batch_enc
     want = ref.cuda()(ids.cuda(), mask.cuda())
     assert (e.float() - want.float()).abs().max() / want.float().abs().max() <= 4e-3
-    with pytest.raises(Exception, match="fp16 inference copy"):
-        r(ids.cuda(), mask.cuda())                                                     # fp32 forward: not provided yet
+    with pytest.raises(Exception, match="autograd"):
+        r(ids.cuda(), mask.cuda())                              # training forward (needs grad): not provided, and says so
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("n,L,layers", [(6, 40, 12), (3, 200, 2), (64, 512, 2)])
+def test_query_embedding_in_model_precision(dtype, tol, n, L, layers, gpu_index_cls):
+    """atlas.py:104: the query side runs the retriever in --precision (fp32 default, bf16 for the large models).
+    Oracle = the torch restatement in that dtype on the same device (fp32: also against torch CPU).
+    Tolerance: fp32 differs by accumulation order only (2e-5 of max|e|); bf16 has 8 significant bits and every one
+    of the ~100 rounding points can flip, measured ~1e-2 -> 3e-2, cosine >= 0.9995."""
+    from atlas_amd import retrievers
+    from oracle.contriever_ref import BertConfigLite, ContrieverRef
+
+    ref = ContrieverRef(BertConfigLite(num_hidden_layers=layers), seed=5).randomize_affine().to(dtype).eval()
+    mine = retrievers.Contriever(retrievers.BertConfigLite(num_hidden_layers=layers))
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine = mine.to(dtype).eval().cuda().requires_grad_(False)
+    ids, mask = _batch(n, L, seed=77 + n)
+    if L == 512:
+        mask[:, 24:] = 0                        # padding="max_length" queries
+        ids = ids * mask
+    r = retrievers.DualEncoderRetriever(None, mine)
+    got = r(ids.cuda(), mask.cuda(), is_passages=False)
+    assert got.dtype == dtype
+    got = got.float().cpu()
+    wants = {"gpu-torch": ref.cuda()(ids.cuda(), mask.cuda()).float().cpu()}
+    if dtype == torch.float32 and layers <= 2:
+        wants["cpu"] = ref.cpu()(ids, mask).float()
+    for name, want in wants.items():
+        err = (got - want).abs().max() / want.abs().max()
+        cos = torch.nn.functional.cosine_similarity(got, want, dim=1).min()
+        print(f"{dtype} n={n} L={L} layers={layers} vs {name}: max|d|/max|e| = {err:.2e}, min cos = {cos:.7f}")
+        assert err <= tol and cos >= (0.9995 if dtype == torch.bfloat16 else 0.999999), (name, float(err), float(cos))
+    # the passage-side call (no trimming) gives the same bits: trimming only changes launch geometry
+    assert torch.equal(r(ids.cuda(), mask.cuda(), is_passages=True).float().cpu(), got)
 
 
 def test_masks_with_holes_and_query_like_padding(gpu_index_cls):

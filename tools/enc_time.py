@@ -4,8 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from atlas_amd import retrievers
 
-dtype = torch.float32 if (len(sys.argv) > 1 and sys.argv[1] == "fp32") else torch.float16
-m = retrievers.Contriever(retrievers.BertConfigLite()).to(dtype).eval().cuda()
+dtype = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[sys.argv[1] if len(sys.argv) > 1 else "fp16"]
+trim = len(sys.argv) > 2 and sys.argv[2] == "trim"
+m = retrievers.Contriever(retrievers.BertConfigLite()).to(dtype).eval().cuda().requires_grad_(False)
+print("dtype", dtype, "trim", trim)
 g = torch.Generator().manual_seed(1)
 
 
@@ -15,12 +17,12 @@ def run(name, n, L, lens):
     ids, mask = ids.cuda(), mask.cuda()
     out = torch.empty((n, 768), dtype=dtype, device="cuda")
     for _ in range(2):
-        m.embed_into(out, ids, mask)
+        m.embed_into(out, ids, mask, trim_padding=trim)
     torch.cuda.synchronize()
     t = time.perf_counter()
     reps = 5
     for _ in range(reps):
-        m.embed_into(out, ids, mask)
+        m.embed_into(out, ids, mask, trim_padding=trim)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / reps
     real = int(lens.clamp(max=L).sum())
