@@ -206,6 +206,48 @@ ln_kernel(const typename T::elem* __restrict__ in, const int* __restrict__ Tdev,
     layer_norm_768<T>(x, lnw, lnb, eps, lane, out + (size_t)t * HID);
 }
 
+// epilogue shared by the GEMM kernels: acc[a][b][r] = C[token m0 + wj*FB*16 + 16b + lr][col n0 + wi*FA*16 + 16a + 4lg + r]
+template <class T, int EPI, int FA, int FB>
+static __device__ __forceinline__ void gemm_epilogue(f4 (&acc)[FA][FB], int64_t m0, int n0, int wi, int wj, int lr, int lg, int64_t M, int N,
+                                                     const typename T::elem* __restrict__ bias, const typename T::elem* __restrict__ R,
+                                                     typename T::elem* __restrict__ C, typename T::elem* __restrict__ VT,
+                                                     const int* __restrict__ cu, const int2* __restrict__ tokinfo, int Lp) {
+    const bool v_part = (EPI == 3) && (n0 >= 2 * HID);      // QKV projection: the V columns are stored transposed
+#pragma unroll
+    for (int b = 0; b < FB; ++b) {
+        const int64_t tok = m0 + wj * (FB * 16) + b * 16 + lr;
+        if (tok >= M) continue;
+        int64_t pb = 0;
+        int pos = 0;                                             // rank of the token inside its passage = V^T column
+        if (EPI == 3 && v_part) { pb = tokinfo[tok].x; pos = (int)(tok - cu[pb]); }
+#pragma unroll
+        for (int a = 0; a < FA; ++a) {
+            const int col = n0 + wi * (FA * 16) + a * 16 + lg * 4;
+            float bv[4], rr[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+            load4<T>(bias + col, bv);
+            if (EPI == 2) load4<T>(R + (size_t)tok * N + col, rr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = T::rnd(acc[a][b][r] + bv[r]);                                 // Linear output in the model dtype
+                if (EPI == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));   // exact-erf GELU in fp32
+                if (EPI == 2) v = v + rr[r];                                            // + input_tensor
+                o[r] = v;                                                               // (rounded by the store)
+            }
+            if (EPI == 3) {
+                if (v_part) {
+                    // V^T[passage][h*64+d][key]: the PV product wants consecutive KEYS per lane (attention kernels)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) VT[((size_t)pb * HID + (col - 2 * HID + r)) * Lp + pos] = T::st(o[r]);
+                } else {
+                    store4<T>(C + (size_t)tok * (2 * HID) + col, o);
+                }
+            } else {
+                store4<T>(C + (size_t)tok * N + col, o);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // GEMM: C[M,N] = A[M,K] (row-major) . W[N,K]^T (row-major) + bias[N], fp32 accumulate, all tensors in the model dtype.
 // Computed transposed on the matrix cores (MFMA A operand = W rows, B operand = A rows) so that each lane ends up
@@ -312,44 +354,236 @@ gemm_bt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         __syncthreads();
     }
 
-    // epilogue: acc[a][b][r] = C[token m0 + wj*FB*16 + 16b + lr][col n0 + wi*FA*16 + 16a + 4lg + r]
-    const bool v_part = (EPI == 3) && (n0 >= 2 * HID);      // QKV projection: the V columns are stored transposed
+    gemm_epilogue<T, EPI, FA, FB>(acc, m0, n0, wi, wj, lr, lg, M, N, bias, R, C, VT, cu, tokinfo, Lp);
+}
+
+// Epilogue of the 256 x 256 kernel for the 16-bit dtypes: the C tile goes through LDS (free after the k-loop; 128 KiB)
+// so that global memory sees whole 512-byte rows (16 B per lane) instead of the fragment layout's 32-byte pieces, and
+// V^T sees 64 consecutive tokens per store. Rounding points are those of gemm_epilogue (dt(acc + bias) [gelu] is what
+// is parked in LDS; the residual is added on the way out). LDS tile [token][col], 8-byte granules XOR-ed with
+// (token & 15) << 2: conflict-free fragment writes and row reads.
+template <class T, int EPI>
+static __device__ __forceinline__ void gemm_epilogue_lds(f4 (&acc)[8][4], unsigned char* __restrict__ smem, int64_t m0, int n0, int wave,
+                                                         int lane, int64_t M, int N, const uint16_t* __restrict__ bias,
+                                                         const uint16_t* __restrict__ R, uint16_t* __restrict__ C,
+                                                         uint16_t* __restrict__ VT, const int* __restrict__ cu,
+                                                         const int2* __restrict__ tokinfo, int Lp) {
+    const int wi = wave >> 2, wj = wave & 3, lr = lane & 15, lg = lane >> 4;
 #pragma unroll
-    for (int b = 0; b < FB; ++b) {
-        const int64_t tok = m0 + wj * (FB * 16) + b * 16 + lr;
-        if (tok >= M) continue;
-        int64_t pb = 0;
-        int pos = 0;                                             // rank of the token inside its passage = V^T column
-        if (EPI == 3 && v_part) { pb = tokinfo[tok].x; pos = (int)(tok - cu[pb]); }
+    for (int a = 0; a < 8; ++a) {
+        const int col = wi * 128 + a * 16 + lg * 4;
+        float bv[4];
+        load4<T>(bias + n0 + col, bv);
 #pragma unroll
-        for (int a = 0; a < FA; ++a) {
-            const int col = n0 + wi * (FA * 16) + a * 16 + lg * 4;
-            float bv[4], rr[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
-            load4<T>(bias + col, bv);
-            if (EPI == 2) load4<T>(R + (size_t)tok * N + col, rr);
+        for (int b = 0; b < 4; ++b) {
+            const int t = wj * 64 + b * 16 + lr;
+            uint16_t o[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = T::rnd(acc[a][b][r] + bv[r]);                                 // Linear output in the model dtype
                 if (EPI == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));   // exact-erf GELU in fp32
-                if (EPI == 2) v = v + rr[r];                                            // + input_tensor
-                o[r] = v;                                                               // (rounded by the store)
+                o[r] = T::st(v);
             }
-            if (EPI == 3) {
-                if (v_part) {
-                    // V^T[passage][h*64+d][key]: the PV product wants consecutive KEYS per lane (attention kernels)
+            const int gr = (col >> 2) ^ ((t & 15) << 2);
+            *(uint2*)(smem + t * 512 + gr * 8) = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+        }
+    }
+    __syncthreads();
+    if (!(EPI == 3 && n0 >= 2 * HID)) {
+        const int ldc = (EPI == 3) ? 2 * HID : N;
+        const int j = lane & 31;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int t = wave * 32 + it * 2 + (lane >> 5);
+            const int64_t tok = m0 + t;
+            if (tok >= M) continue;
+            uint4 v = *(const uint4*)(smem + t * 512 + (((2 * j) ^ ((t & 15) << 2)) * 8));
+            if (EPI == 2) {
+                const uint4 rv = *(const uint4*)(R + (size_t)tok * N + n0 + 8 * j);
+                const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w};
+                uint32_t ow[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) VT[((size_t)pb * HID + (col - 2 * HID + r)) * Lp + pos] = T::st(o[r]);
-                } else {
-                    store4<T>(C + (size_t)tok * (2 * HID) + col, o);
+                for (int e = 0; e < 4; ++e) {
+                    const uint16_t lo = T::st(T::ld((uint16_t)(vw[e] & 0xffff)) + T::ld((uint16_t)(rw[e] & 0xffff)));   // + input_tensor
+                    const uint16_t hi = T::st(T::ld((uint16_t)(vw[e] >> 16)) + T::ld((uint16_t)(rw[e] >> 16)));
+                    ow[e] = (uint32_t)lo | ((uint32_t)hi << 16);
                 }
-            } else {
-                store4<T>(C + (size_t)tok * N + col, o);
+                v = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            }
+            *(uint4*)(C + (size_t)tok * ldc + n0 + 8 * j) = v;
+        }
+    } else {
+        // V columns: V^T[passage][h*64+d][rank in passage] -- lanes run along tokens, so a store covers 64 consecutive keys
+#pragma unroll 1
+        for (int tc = 0; tc < 4; ++tc) {
+            const int t = tc * 64 + lane;
+            const int64_t tok = m0 + t;
+            const bool valid = tok < M;
+            int64_t pb = 0;
+            int pos = 0;
+            if (valid) { pb = tokinfo[tok].x; pos = (int)(tok - cu[pb]); }
+            uint16_t* dst = VT + ((size_t)pb * HID + (n0 - 2 * HID) + wave * 32) * Lp + pos;
+            const unsigned char* src = smem + t * 512;
+            const int sw = (t & 15) << 2;
+#pragma unroll 8
+            for (int c = 0; c < 32; ++c) {
+                const int cc = wave * 32 + c;
+                const uint16_t v = *(const uint16_t*)(src + (((cc >> 2) ^ sw) * 8) + (cc & 3) * 2);
+                if (valid) dst[(size_t)c * Lp] = v;
             }
         }
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same GEMM for the bulk refresh (256 x 256 x 128-byte tiles, 8 waves as 2 x 4, wave tile 128 x 64), with the two
+// waves of every SIMD in opposite phases ("ping-pong"): while one does its LDS fragment reads and issues the LDS-DMA
+// for a later k-tile, the other runs its 64 MFMAs, so the matrix pipe of the SIMD is fed from one of them all the
+// time. In gemm_bt_kernel all 8 waves read, then all multiply (one barrier per k-tile): PMC showed the MFMA pipe busy
+// 39 % there (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMD x GRBM_GUI_ACTIVE), profiles/r01/encoder_pmc.txt).
+//
+// Phases are separated by s_barrier (all 8 waves). Group A = waves 0-3, group B = waves 4-7 (wave w and w+4 share a SIMD):
+//     phase 2k   : A reads tile k  (+ issues DMA k+1)        | B multiplies tile k-1 (+ issues DMA k+1 first)
+//     phase 2k+1 : A multiplies tile k                       | B reads tile k
+// DMA(k+1) is issued by BOTH groups in phase 2k into the buffer of tile k-1, which A read in phase 2k-2 and B in phase
+// 2k-1; each wave waits vmcnt(0) for its own pieces at the end of phase 2k+1, so everything has landed before A's reads
+// in phase 2k+2. Two LDS buffers suffice, and every DMA has more than a full phase of MFMAs to land.
+// The fragment reads are inline asm: hipcc's waitcnt insertion would drain vmcnt(0) in front of any ds_read it sees
+// after an LDS-DMA it cannot prove disjoint, which serialises exactly what this schedule overlaps.
+// Measured (profiles/r01/gemm_phases.txt, s_memtime stamps): k-tile period ~3.6k cycles vs 2.2k of pure MFMA issue; the
+// rest is LDS-DMA issue (~65 cycles per 1 KiB piece and wave), the pieces' ~2.6k-cycle landing time and barrier skew.
+// LDS-DMA alone sustains ~45 B/clk/CU (tools/dma_bench.hip), i.e. >= 1.4k cycles per 64 KiB k-tile.
+// ------------------------------------------------------------------------------------------
+template <class T, int EPI>
+__global__ void __launch_bounds__(512)
+gemm_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem* __restrict__ W, const typename T::elem* __restrict__ bias,
+               const typename T::elem* __restrict__ R, typename T::elem* __restrict__ C, typename T::elem* __restrict__ VT,
+               const int* __restrict__ cu, int n, const int2* __restrict__ tokinfo, int N, int K, int Lp,
+               unsigned long long* __restrict__ dbg /* tuning only: cycle stamps of block 0; null in production */) {
+    typedef typename T::elem E;
+    constexpr int BCOL = 256, BTOK = 256, WT = 4, FA = 8, FB = 4;
+    constexpr int EPC = 16 / (int)sizeof(E);
+    constexpr uint32_t STG = 256 * 128;                              // bytes per operand stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // W0 | W1 | A0 | A1, 32 KiB each
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave / WT, wj = wave % WT;
+    const bool grpB = wave >= 4;
+    const int64_t M = cu[n];
+    const int ncol = N / BCOL;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int ctile = jj % ncol;
+    const int64_t ttile = (int64_t)(jj / ncol) * 8 + xcd;
+    if (ttile * BTOK >= M) return;
+    const int n0 = ctile * BCOL;
+    const int64_t m0 = ttile * BTOK;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    const int nk = K / (8 * EPC);
+    // this wave's DMA pieces: 4 x 8 rows of W and 4 x 8 rows of the activations per k-tile (8 rows x 128 B each,
+    // source-side XOR swizzle as in gemm_bt_kernel)
+    const int ch = (lane & 7) ^ (lane >> 3);
+    const E* gw = W + (size_t)(n0 + wave * 32 + (lane >> 3)) * K + ch * EPC;       // piece i: + i * 8 rows
+    const E* ga[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int64_t ar = m0 + wave * 32 + i * 8 + (lane >> 3);
+        if (ar >= M) ar = M - 1;                                   // clamped: tail rows are never stored
+        ga[i] = A + (size_t)ar * K + ch * EPC;
+    }
+    auto stage = [&](const int buf, const int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + (size_t)i * 8 * K + kt * (8 * EPC)),
+                                             (__attribute__((address_space(3))) void*)(smem_raw + buf * STG + (wave * 32 + i * 8) * 128), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + kt * (8 * EPC)),
+                                             (__attribute__((address_space(3))) void*)(smem_raw + 2 * STG + buf * STG + (wave * 32 + i * 8) * 128), 16, 0, 0);
+    };
+
+    // LDS byte addresses of this lane's fragment chunks (fragment a / b adds a * 2048: rows 16 apart keep row & 7)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+    const uint32_t aw0 = lds0 + (wi * 128 + lr) * 128 + ((0 + lg) ^ (lr & 7)) * 16;
+    const uint32_t aw1 = lds0 + (wi * 128 + lr) * 128 + ((4 + lg) ^ (lr & 7)) * 16;
+    const uint32_t aa0 = lds0 + 2 * STG + (wj * 64 + lr) * 128 + ((0 + lg) ^ (lr & 7)) * 16;
+    const uint32_t aa1 = lds0 + 2 * STG + (wj * 64 + lr) * 128 + ((4 + lg) ^ (lr & 7)) * 16;
+
+    f4 acc[FA][FB];
+#pragma unroll
+    for (int a = 0; a < FA; ++a)
+#pragma unroll
+        for (int b = 0; b < FB; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    stage(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's pieces of tile 0 have landed
+    __builtin_amdgcn_s_barrier();
+    if (grpB) {                                        // B's phase 0: nothing to multiply yet
+        if (nk > 1) stage(1, 1);
+        __builtin_amdgcn_s_barrier();
+    }
+    const bool stamp = dbg != nullptr && blockIdx.x == 0 && lane == 0;
+#define PP_STAMP(i) do { if (stamp && kt < 16) dbg[(wave * 16 + kt) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        PP_STAMP(0);
+        PP_STAMP(1);
+        // ---- read phase: all 24 fragments of tile kt, then lgkmcnt(0), in one asm block ----
+        u4v fw0[FA], fa0[FB], fw1[FA], fa1[FB];
+        {
+            const uint32_t w0 = aw0 + buf * STG, w1 = aw1 + buf * STG, a0 = aa0 + buf * STG, a1 = aa1 + buf * STG;
+            asm volatile(
+                "ds_read_b128 %0, %24\n ds_read_b128 %1, %24 offset:2048\n ds_read_b128 %2, %24 offset:4096\n ds_read_b128 %3, %24 offset:6144\n"
+                "ds_read_b128 %4, %24 offset:8192\n ds_read_b128 %5, %24 offset:10240\n ds_read_b128 %6, %24 offset:12288\n ds_read_b128 %7, %24 offset:14336\n"
+                "ds_read_b128 %8, %25\n ds_read_b128 %9, %25 offset:2048\n ds_read_b128 %10, %25 offset:4096\n ds_read_b128 %11, %25 offset:6144\n"
+                "ds_read_b128 %12, %26\n ds_read_b128 %13, %26 offset:2048\n ds_read_b128 %14, %26 offset:4096\n ds_read_b128 %15, %26 offset:6144\n"
+                "ds_read_b128 %16, %26 offset:8192\n ds_read_b128 %17, %26 offset:10240\n ds_read_b128 %18, %26 offset:12288\n ds_read_b128 %19, %26 offset:14336\n"
+                "ds_read_b128 %20, %27\n ds_read_b128 %21, %27 offset:2048\n ds_read_b128 %22, %27 offset:4096\n ds_read_b128 %23, %27 offset:6144\n"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(fw0[0]), "=&v"(fw0[1]), "=&v"(fw0[2]), "=&v"(fw0[3]), "=&v"(fw0[4]), "=&v"(fw0[5]), "=&v"(fw0[6]), "=&v"(fw0[7]),
+                  "=&v"(fa0[0]), "=&v"(fa0[1]), "=&v"(fa0[2]), "=&v"(fa0[3]),
+                  "=&v"(fw1[0]), "=&v"(fw1[1]), "=&v"(fw1[2]), "=&v"(fw1[3]), "=&v"(fw1[4]), "=&v"(fw1[5]), "=&v"(fw1[6]), "=&v"(fw1[7]),
+                  "=&v"(fa1[0]), "=&v"(fa1[1]), "=&v"(fa1[2]), "=&v"(fa1[3])
+                : "v"(w0), "v"(a0), "v"(w1), "v"(a1)
+                : "memory");
+        }
+        if (!grpB) { if (kt + 1 < nk) stage(buf ^ 1, kt + 1); }   // after the reads: issued first, the DMA competes with them (measured -4 %)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);       // B: its pieces of tile kt+1 (issued a phase ago) have landed
+        PP_STAMP(2);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        PP_STAMP(3);
+        // ---- multiply phase ----
+        if (grpB && kt + 2 < nk) stage(buf, kt + 2);   // into the buffer both groups have finished reading
+        PP_STAMP(4);
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+#pragma unroll
+            for (int b = 0; b < FB; ++b) acc[a][b] = T::mma(fw0[a], fa0[b], acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+#pragma unroll
+            for (int b = 0; b < FB; ++b) acc[a][b] = T::mma(fw1[a], fa1[b], acc[a][b]);
+        __builtin_amdgcn_sched_barrier(0);
+        PP_STAMP(5);
+        if (!grpB) __builtin_amdgcn_s_waitcnt(0x0F70); // A: its pieces of tile kt+1 have landed
+        PP_STAMP(6);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        PP_STAMP(7);
+    }
+#undef PP_STAMP
+    if (!grpB) __builtin_amdgcn_s_barrier();           // A matches B's extra barrier: every wave is past its last LDS read
+    if constexpr (sizeof(E) == 2)
+        gemm_epilogue_lds<T, EPI>(acc, smem_raw, m0, n0, wave, lane, M, N, bias, R, C, VT, cu, tokinfo, Lp);
+    else
+        gemm_epilogue<T, EPI, FA, FB>(acc, m0, n0, wi, wj, lr, lg, M, N, bias, R, C, VT, cu, tokinfo, Lp);
+}
+
 // tile configurations (ATLAS_GEMM_CFG overrides; tuning)
+unsigned long long* g_gemm_dbg = nullptr;    // tuning hook (atlas_dbg_set_gemm_stamps); never set in production
+
 template <class T, int EPI>
 static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, const typename T::elem* W, const typename T::elem* bias,
                         const typename T::elem* R, typename T::elem* C, typename T::elem* VT, int64_t Mmax, const int* cu, int n,
@@ -361,7 +595,13 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
         hipLaunchKernelGGL(kern, dim3((mtiles + 7) / 8 * 8 * (N / bcol)), dim3(nthreads), lds, stream, A, W, bias, R, C, VT,
                            cu, n, tokinfo, N, K, Lp);
     };
-    if (cfg == 2) go(gemm_bt_kernel<T, EPI, 256, 256, 2, 4>, 256, 256, 512);
+    if (cfg == 4) {
+        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const unsigned mtiles = (unsigned)((Mmax + 255) / 256);
+        hipLaunchKernelGGL((gemm_pp_kernel<T, EPI>), dim3((mtiles + 7) / 8 * 8 * (N / 256)), dim3(512), 128 * 1024, stream, A, W, bias, R, C,
+                           VT, cu, n, tokinfo, N, K, Lp, g_gemm_dbg);
+    }
+    else if (cfg == 2) go(gemm_bt_kernel<T, EPI, 256, 256, 2, 4>, 256, 256, 512);
     else if (cfg == 3) go(gemm_bt_kernel<T, EPI, 64, 64, 2, 2>, 64, 64, 256);
     else go(gemm_bt_kernel<T, EPI, 128, 128, 2, 2>, 128, 128, 256);
 }
@@ -646,10 +886,10 @@ int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int
     int2* tokinfo = (int2*)p;
 
     const unsigned tok_blocks = (unsigned)((M + 3) / 4), pas_blocks = (unsigned)((n + 3) / 4);
-    // 256x256 tiles measured best for the bulk refresh (profiles/r01/e01); small batches (queries) need more,
-    // smaller tiles to cover the 256 CUs: 64 queries x ~20 tokens are 21 x 12 tiles of 64x64 for a 768-wide GEMM
+    // bulk refresh: the 256x256 ping-pong kernel (cfg 4; cfg 2 = gemm_bt_kernel 256x256, the single-phase version kept for A/B runs). Small batches (queries) need more, smaller tiles to cover the 256 CUs: 64 queries
+    // x ~20 tokens are 21 x 12 tiles of 64x64 for a 768-wide GEMM
     const char* cfg_env = getenv("ATLAS_GEMM_CFG");
-    const int cfg = cfg_env ? atoi(cfg_env) : (M > 16384 ? 2 : (M > 4096 ? 0 : 3));
+    const int cfg = cfg_env ? atoi(cfg_env) : (M > 16384 ? 4 : (M > 4096 ? 0 : 3));
     hipLaunchKernelGGL(count_kernel, dim3(pas_blocks), dim3(256), 0, stream, attention_mask, n, L, counts);
     hipLaunchKernelGGL(pack_kernel, dim3(pas_blocks), dim3(256), 0, stream, attention_mask, n, L, counts, cu, tokinfo);
     hipLaunchKernelGGL(embed_ln_kernel<T>, dim3(tok_blocks), dim3(256), 0, stream, input_ids, token_type_ids, L, cu, n, tokinfo,
@@ -691,6 +931,8 @@ int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int
 }  // namespace
 
 extern "C" {
+
+void atlas_dbg_set_gemm_stamps(unsigned long long* p) { g_gemm_dbg = p; }   // tuning hook, not part of include/atlas_hip.h
 
 size_t atlas_contriever_workspace_bytes(int n, int L, int dtype) {
     if (n <= 0 || L <= 0) return 0;

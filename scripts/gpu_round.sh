@@ -14,7 +14,7 @@ timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err;
 cat $OUT/bench_default.json | tee -a $OUT/summary.log
 echo "== rocprofv3 --kernel-trace --stats of the same command (fewer steps)" | tee -a $OUT/summary.log
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_default -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --cpu-seconds 0 > $GRAFT_REPO_ROOT/$OUT/prof_default.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/summary.log
-grep -i "atlas::\|merge_rescore\|prep_queries\|gemm_bt\|attention_kernel\|ln_kernel\|pool_write\|embed_ln\|Name" $OUT/prof_default/trace_kernel_stats.csv | cut -c1-170 | tee -a $OUT/summary.log
+grep -i "atlas::\|merge_rescore\|prep_queries\|gemm_\|attention_\|ln_kernel\|pool_\|embed_ln\|Name" $OUT/prof_default/trace_kernel_stats.csv | cut -c1-170 | tee -a $OUT/summary.log
 for n in 4000000 1000000; do
   echo "== bench $n" | tee -a $OUT/summary.log
   timeout 600 python bench.py --passages $n --steps 50 --warmup 5 --cpu-seconds 0 --refresh-batches 0 > $OUT/bench_$n.json 2> $OUT/bench_$n.err; cat $OUT/bench_$n.json | cut -c1-900 | tee -a $OUT/summary.log

@@ -1,0 +1,68 @@
+// LDS-DMA / load throughput microbenchmark (dev tool): every CU streams the same L2-resident 64 KiB "k-tiles" into LDS
+// (or registers) in the GEMM's access pattern; reports bytes / clock / CU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+// mode 0: global_load_lds_dwordx4 (8 waves x 8 pieces per tile)   mode 1: same with 4 waves issuing 16 pieces
+// mode 2: global_load_dwordx4 to registers + ds_write_b128         mode 3: global_load_dwordx4 to registers only
+template <int MODE>
+__global__ void __launch_bounds__(512) dma_kernel(const unsigned char* __restrict__ src, int K_bytes, int tiles, int reps, unsigned* out,
+                                                   unsigned long long* cyc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // 512 rows of K_bytes; k-tile t = bytes [t*128, t*128+128) of every row; piece = 8 rows x 128 B
+    const unsigned char* base = src + (size_t)(blockIdx.x & 7) * 0;     // all blocks read the same rows: L2-resident
+    uint4 accv = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int r = 0; r < reps; ++r)
+        for (int t = 0; t < tiles; ++t) {
+            const int buf = t & 1;
+            if (MODE == 0 || MODE == 1) {
+                const int npieces = (MODE == 0) ? 8 : 16;
+                if (MODE == 0 || wave < 4) {
+#pragma unroll
+                    for (int i = 0; i < npieces; ++i) {
+                        const int row = ((MODE == 0 ? wave * 8 : wave * 16) + i) * 8 + (lane >> 3);
+                        const unsigned char* g = base + (size_t)row * K_bytes + t * 128 + (lane & 7) * 16;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                         (__attribute__((address_space(3))) void*)(smem + buf * 65536 + ((MODE == 0 ? wave * 8 : wave * 16) + i) * 1024), 16, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                __builtin_amdgcn_s_barrier();
+            } else {
+                uint4 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = (wave * 8 + i) * 8 + (lane >> 3);
+                    v[i] = *(const uint4*)(base + (size_t)row * K_bytes + t * 128 + (lane & 7) * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (MODE == 2) *(uint4*)(smem + buf * 65536 + (wave * 8 + i) * 1024 + lane * 16) = v[i];
+                    else { accv.x ^= v[i].x; accv.y ^= v[i].y; accv.z ^= v[i].z; accv.w ^= v[i].w; }
+                }
+                if (MODE == 2) __syncthreads();
+            }
+        }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (tid == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+    if (MODE >= 2) { unsigned x = accv.x ^ accv.y ^ accv.z ^ accv.w ^ ((unsigned*)smem)[tid]; if (x == 0x12345) out[0] = x; }
+    else if (((unsigned*)smem)[tid] == 0x12345) out[0] = 1;
+}
+
+extern "C" float dma_bench(int mode, const void* src, int K_bytes, int tiles, int reps, int blocks, void* out, void* cyc) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto launch = [&]() {
+        if (mode == 0) { hipFuncSetAttribute((const void*)dma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); hipLaunchKernelGGL(dma_kernel<0>, dim3(blocks), dim3(512), 131072, 0, (const unsigned char*)src, K_bytes, tiles, reps, (unsigned*)out, (unsigned long long*)cyc); }
+        if (mode == 1) { hipFuncSetAttribute((const void*)dma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); hipLaunchKernelGGL(dma_kernel<1>, dim3(blocks), dim3(512), 131072, 0, (const unsigned char*)src, K_bytes, tiles, reps, (unsigned*)out, (unsigned long long*)cyc); }
+        if (mode == 2) { hipFuncSetAttribute((const void*)dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); hipLaunchKernelGGL(dma_kernel<2>, dim3(blocks), dim3(512), 131072, 0, (const unsigned char*)src, K_bytes, tiles, reps, (unsigned*)out, (unsigned long long*)cyc); }
+        if (mode == 3) { hipFuncSetAttribute((const void*)dma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); hipLaunchKernelGGL(dma_kernel<3>, dim3(blocks), dim3(512), 131072, 0, (const unsigned char*)src, K_bytes, tiles, reps, (unsigned*)out, (unsigned long long*)cyc); }
+    };
+    launch(); hipDeviceSynchronize();
+    hipEventRecord(e0, 0); launch(); hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    return ms;
+}

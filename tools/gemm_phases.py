@@ -1,0 +1,26 @@
+"""cycle stamps of block 0 of the ping-pong GEMM (dev tool): one 2-layer encoder pass, stamps from the LAST GEMM launched"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import torch
+from atlas_amd import retrievers, _lib
+os.environ["ATLAS_GEMM_CFG"] = "4"
+L = _lib.lib()
+L.atlas_dbg_set_gemm_stamps.argtypes = [ctypes.c_void_p]
+m = retrievers.Contriever(retrievers.BertConfigLite(num_hidden_layers=1)).half().eval().cuda().requires_grad_(False)
+g = torch.Generator().manual_seed(1)
+ids = torch.randint(1000, 30522, (512, 128), generator=g).cuda()
+mask = torch.ones((512, 128), dtype=torch.int64).cuda()
+out = torch.empty((512, 768), dtype=torch.float16, device="cuda")
+m.embed_into(out, ids, mask); torch.cuda.synchronize()
+dbg = torch.zeros(8 * 16 * 8, dtype=torch.int64, device="cuda")
+L.atlas_dbg_set_gemm_stamps(dbg.data_ptr())
+m.embed_into(out, ids, mask); torch.cuda.synchronize()        # last GEMM = FF2 (K = 3072, 48 k-tiles; first 16 stamped)
+L.atlas_dbg_set_gemm_stamps(None)
+t = dbg.cpu().view(8, 16, 8)
+t0 = int(t[:, 0, 0].min())
+names = ["dma", "reads", "bar1", "-", "mfma", "vmw", "bar2"]
+for w in (0, 1, 4, 5):
+    print("wave", w)
+    for kt in range(2, 8):
+        r = t[w, kt]
+        print("  kt %2d start %7d  " % (kt, int(r[0]) - t0) + "  ".join("%s %5d" % (names[i], int(r[i + 1] - r[i])) for i in range(7)) + "   iter %5d" % int(t[w, kt + 1, 0] - r[0]))
