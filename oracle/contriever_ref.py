@@ -1,10 +1,13 @@
 """Torch restatement of the reference's Contriever encoder. TEST INFRASTRUCTURE ONLY.
 
-The reference module (src/retrievers.py + src/modeling_bert.py) cannot be imported here: it needs
-transformers==4.18 symbols (apply_chunking_to_forward, find_pruneable_heads_and_indices, get_head_mask with the
-4.18 signature, ...) that the installed transformers 5.x removed. This file follows it op by
-op, with the same tensor dtypes at every step, so that running it on fp16 weights reproduces what
-`copy.deepcopy(retriever).half().eval()` computes in `Atlas.build_index` (src/atlas.py:54-59, 78):
+PINNED: tests/test_encoder_golden.py checks this file against outputs of the reference's OWN module
+(src/retrievers.py + src/modeling_bert.py run unmodified by tests/golden/make_golden_encoder.py, which supplies the
+three transformers==4.18 helpers the installed transformers 5.x no longer has); on the generating machine the
+restatement is bit-identical to the reference in fp32 and in fp16 (`.half()`), for 2- and 12-layer models, ragged
+masks, masks with holes. The reference itself cannot travel to the GPU box (and needs those shims), so the GPU parity
+tests use this restatement plus the committed fixtures. It follows the reference op by op, with the same tensor dtypes
+at every step, so that running it on fp16 weights reproduces what `copy.deepcopy(retriever).half().eval()` computes in
+`Atlas.build_index` (src/atlas.py:54-59, 78):
 
     BertEmbeddings.forward        modeling_bert.py:213-247   word + token_type (+= position), LayerNorm(x.float()).type_as
     BertLayerNorm.forward         modeling_bert.py:104-114   NON-standard: (x - mean) * rsqrt(mean(x^2) + eps), fp32 stats,

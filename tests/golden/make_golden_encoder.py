@@ -1,0 +1,100 @@
+"""Generate golden encoder fixtures by running the REFERENCE's own Contriever (src/retrievers.py over
+src/modeling_bert.py) on CPU.   Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden_encoder.py
+
+The reference modules are imported UNMODIFIED. They were written against transformers==4.18 (the reference's pinned
+dependency); the installed transformers 5.x lacks two things they touch, which this script supplies in memory:
+  * `transformers.modeling_utils.{apply_chunking_to_forward, prune_linear_layer}` moved to `transformers.pytorch_utils`
+    (re-exported here); `find_pruneable_heads_and_indices` was removed (only used by `prune_heads`, never called: stub);
+  * `PreTrainedModel.get_extended_attention_mask`: 4.18 computes `(1.0 - mask[:, None, None, :].to(dtype)) * -10000.0`
+    (transformers 4.18 modeling_utils.py, `get_extended_attention_mask`), 5.x uses finfo.min and another signature.
+    The 4.18 body is restated below and bound to the reference model (third-party dependency, pinned version 4.18.0);
+  * `PreTrainedModel.get_head_mask` was removed: 4.18 returns `[None] * num_hidden_layers` for `head_mask=None`
+    (the only way atlas calls it).
+Everything else that executes — BertEmbeddings, BertLayerNorm (the non-standard one), BertSelfAttention, BertSelfOutput,
+BertIntermediate, BertOutput, BertEncoder, BertModel.forward, Contriever.forward — is the reference's code.
+
+Weights and inputs are regenerated from integers (tests/synth_encoder.py), so the fixtures only hold the reference's
+OUTPUTS: tests/golden/enc_<case>.npz = embeddings of the fp32 model and of `.half()` (the inference copy of
+Atlas.build_index, src/atlas.py:54-59), both computed on CPU, plus a checksum of the generated state dict.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import synth_encoder  # noqa: E402
+
+REF = "/root/reference"
+
+
+def import_reference_contriever():
+    import transformers.modeling_utils as mu
+    import transformers.pytorch_utils as pu
+
+    mu.apply_chunking_to_forward = pu.apply_chunking_to_forward
+    mu.prune_linear_layer = pu.prune_linear_layer
+
+    def find_pruneable_heads_and_indices(*a, **k):
+        raise NotImplementedError("head pruning is not part of the retrieval path")
+
+    mu.find_pruneable_heads_and_indices = find_pruneable_heads_and_indices
+    sys.path.insert(0, REF)
+    import src.retrievers as ref_retrievers  # noqa: E402  (the reference module, unmodified)
+
+    return ref_retrievers
+
+
+def ext_mask_4_18(self, attention_mask, input_shape=None, device=None, dtype=None):
+    # transformers==4.18.0 modeling_utils.get_extended_attention_mask, encoder (non-decoder) branch, 2-D mask
+    extended_attention_mask = attention_mask[:, None, None, :]
+    extended_attention_mask = extended_attention_mask.to(dtype=self.dtype)
+    extended_attention_mask = (1.0 - extended_attention_mask) * -10000.0
+    return extended_attention_mask
+
+
+def head_mask_4_18(self, head_mask, num_hidden_layers, is_attention_chunked=False):
+    assert head_mask is None
+    return [None] * num_hidden_layers
+
+
+def bind_4_18(model):
+    model.get_extended_attention_mask = types.MethodType(ext_mask_4_18, model)
+    model.get_head_mask = types.MethodType(head_mask_4_18, model)
+    return model
+
+
+def main():
+    ref = import_reference_contriever()
+    from transformers.models.bert.configuration_bert import BertConfig
+
+    for case in synth_encoder.CASES:
+        cfg = synth_encoder.config_dict(case)
+        config = BertConfig(**cfg)
+        torch.manual_seed(0)
+        model = ref.Contriever(config)
+        bind_4_18(model)
+        sd = synth_encoder.state_dict(case)
+        missing = model.load_state_dict(sd, strict=False)
+        assert not missing.unexpected_keys, missing
+        assert all("position_ids" in k for k in missing.missing_keys), missing      # (a registered buffer, not a parameter)
+        model.eval()
+        ids, mask = synth_encoder.inputs(case)
+        with torch.no_grad():
+            e32 = model(input_ids=ids, attention_mask=mask).float().numpy()
+            m16 = model.half()
+            bind_4_18(m16)
+            e16 = m16(input_ids=ids, attention_mask=mask).numpy()
+        out = os.path.join(HERE, f"enc_{case['name']}.npz")
+        np.savez_compressed(out, emb_fp32=e32, emb_fp16=e16, state_sha=np.frombuffer(synth_encoder.state_sha(sd).encode(), dtype=np.uint8),
+                            torch_version=np.frombuffer(torch.__version__.encode(), dtype=np.uint8))
+        print(case["name"], "fp32", e32.shape, float(np.abs(e32).max()), "fp16 max|d| vs fp32", float(np.abs(e16.astype(np.float32) - e32).max()), "->", out)
+
+
+if __name__ == "__main__":
+    main()

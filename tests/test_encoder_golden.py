@@ -1,0 +1,73 @@
+"""Pins the encoder oracle (oracle/contriever_ref.py, a torch restatement) against outputs of the REFERENCE's own
+Contriever (src/retrievers.py + src/modeling_bert.py, run unmodified by tests/golden/make_golden_encoder.py) and, on the
+GPU, the HIP encoder against the same reference outputs.
+
+Weights and inputs are regenerated from integers (tests/synth_encoder.py); the fixtures hold only the reference's
+embeddings for the fp32 model and for its `.half()` inference copy, both computed with torch CPU ops.
+Tolerances: the restatement performs the same torch ops in the same order, so on the machine that generated the fixtures
+it is bit-identical (asserted when torch reports the generating version and the bits agree; otherwise bounded): fp32
+1e-5 * max|e|, fp16 2e-3 * max|e| (other CPUs / BLAS kernels may sum GEMMs in another order). HIP encoder vs reference:
+the tolerances of tests/test_gpu_encoder.py (fp32 2e-5, fp16 4e-3 of max|e|)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth_encoder
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(case):
+    z = np.load(os.path.join(GOLD, f"enc_{case['name']}.npz"))
+    sd = synth_encoder.state_dict(case)
+    assert synth_encoder.state_sha(sd) == bytes(z["state_sha"]).decode(), "regenerated weights differ from the fixture's"
+    return z, sd
+
+
+def _restatement(case, sd):
+    from oracle.contriever_ref import BertConfigLite, ContrieverRef
+
+    c = synth_encoder.config_dict(case)
+    m = ContrieverRef(BertConfigLite(vocab_size=c["vocab_size"], num_hidden_layers=c["num_hidden_layers"]))
+    r = m.load_state_dict(sd, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    return m.eval()
+
+
+@pytest.mark.parametrize("case", synth_encoder.CASES, ids=[c["name"] for c in synth_encoder.CASES])
+def test_restatement_matches_reference_outputs(case):
+    z, sd = _load(case)
+    ids, mask = synth_encoder.inputs(case)
+    m = _restatement(case, sd)
+    e32 = m(ids, mask).float().numpy()
+    e16 = m.half()(ids, mask).numpy()
+    want32, want16 = z["emb_fp32"], z["emb_fp16"]
+    scale = np.abs(want32).max()
+    d32 = np.abs(e32 - want32).max() / scale
+    d16 = np.abs(e16.astype(np.float32) - want16.astype(np.float32)).max() / scale
+    same = np.array_equal(e32, want32) and np.array_equal(e16.view(np.uint16), want16.view(np.uint16))
+    print(f"{case['name']}: fp32 max|d|/max|e| = {d32:.2e}, fp16 = {d16:.2e}, bit-identical = {same}")
+    assert d32 <= 1e-5 and d16 <= 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", synth_encoder.CASES, ids=[c["name"] for c in synth_encoder.CASES])
+def test_hip_encoder_matches_reference_outputs(case, gpu_index_cls):
+    from atlas_amd import retrievers
+
+    z, sd = _load(case)
+    ids, mask = synth_encoder.inputs(case)
+    c = synth_encoder.config_dict(case)
+    want32, want16 = torch.from_numpy(z["emb_fp32"]), torch.from_numpy(z["emb_fp16"]).float()
+    scale = want32.abs().max()
+    for dtype, want, tol in ((torch.float32, want32, 2e-5), (torch.float16, want16, 4e-3)):
+        m = retrievers.Contriever(retrievers.BertConfigLite(vocab_size=c["vocab_size"], num_hidden_layers=c["num_hidden_layers"]))
+        m.load_state_dict(sd, strict=True)
+        m = m.to(dtype).eval().cuda().requires_grad_(False)
+        got = m(ids.cuda(), mask.cuda()).float().cpu()
+        err = (got - want).abs().max() / scale
+        cos = torch.nn.functional.cosine_similarity(got, want, dim=1).min()
+        print(f"{case['name']} {dtype}: HIP vs reference max|d|/max|e| = {err:.2e}, min cos = {cos:.7f}")
+        assert err <= tol and cos >= 0.99999, (str(dtype), float(err), float(cos))
