@@ -86,7 +86,15 @@ class HipDistributedIndex(object):
         self._gid_mode = "round_robin"  # how local rows map to global passage ids
         self._gid_offset = 0
         self._gid_bounds = None         # contiguous mode: cumulative shard sizes of all ranks
+        self._passage_store = None      # optional node-local PassageStore (attach_passage_store)
         self.last_search_stats = {}
+
+    def attach_passage_store(self, store) -> None:
+        """Resolve the winners' passages from a node-local `passage_store.PassageStore` (keyed by global passage id)
+        instead of exchanging them between ranks: search_knn then has no text collective.
+        The store must have been built in this index's global-id order: `PassageStore.iter_jsonl` for passages loaded
+        round-robin by `index_io.load_passages`, `PassageStore.iter_saved_index` for an index loaded with `load_index`."""
+        self._passage_store = store
 
     # ------------------------------------------------------------------ storage
     def _device(self):
@@ -338,6 +346,12 @@ class HipDistributedIndex(object):
         gathered = dist_utils.all_gather_packed(packed)                                  # (W, B, k): ONE collective
         merged = self._merge(gathered, topk)                                             # (B, k) numpy, W*k -> k per query
         m_scores, m_gid = unpack_candidates_host(merged)
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        if self._passage_store is not None:
+            # node-local passage store: ids resolve locally, no text collective at all
+            docs = [[self._passage_store.get(int(g)) for g in m_gid[b] if g >= 0] for b in range(lo, hi)]
+            out_scores = [[float(s) for s, g in zip(m_scores[b], m_gid[b]) if g >= 0] for b in range(lo, hi)]
+            return docs, out_scores
         owner, local = self._gid_owner(np.maximum(m_gid, 0))
         # passage text: each rank contributes the winners it owns (k per query, not W*k)
         mine = (owner == rank) & (m_gid >= 0)
@@ -345,7 +359,6 @@ class HipDistributedIndex(object):
         table = {}
         for part in dist_utils.all_gather_object(contrib):
             table.update(part)
-        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
         docs = [[table[int(g)] for g in m_gid[b] if g >= 0] for b in range(lo, hi)]
         out_scores = [[float(s) for s, g in zip(m_scores[b], m_gid[b]) if g >= 0] for b in range(lo, hi)]
         return docs, out_scores

@@ -9,6 +9,7 @@ import logging
 
 from . import dist_utils
 from .index import HipDistributedIndex
+from .passage_store import PassageStore
 
 logger = logging.getLogger(__name__)
 
@@ -60,5 +61,15 @@ def load_or_initialize_index(opt):
         if not opt.use_file_passages:
             passages = load_passages(opt.passages, opt.max_passages)
             index.init_embeddings(passages)
+
+    # optional, not a reference option: `opt.passage_store_path` = where the node-local passage store lives (e.g. under
+    # /dev/shm). With it search_knn resolves the winners' text locally instead of exchanging it.
+    store_path = getattr(opt, "passage_store_path", None)
+    if store_path:
+        if opt.load_index_path is not None:
+            make = lambda: PassageStore.iter_saved_index(opt.load_index_path, opt.save_index_n_shards)   # noqa: E731
+        else:
+            make = lambda: PassageStore.iter_jsonl(opt.passages, opt.max_passages)                        # noqa: E731
+        index.attach_passage_store(PassageStore.open_shared(store_path, make))
 
     return index, passages

@@ -51,6 +51,21 @@ def _worker(rank, W, port, N, batches, k, out_dir, mode):
         idx.load_index(out_dir, 2 * W)
     for rep in range(2):                                    # search_knn is a collective: call it twice
         docs, scores = idx.search_knn(Q, k)
+    # the same search with a node-local passage store attached: no text collective, same documents
+    from atlas_amd.passage_store import PassageStore
+    spath = os.path.join(out_dir, "store_" + mode)
+    if mode == "round_robin":
+        store = PassageStore.open_shared(spath, lambda: ({"id": str(g), "text": f"p{g}"} for g in range(N)))
+    else:
+        store = PassageStore.open_shared(spath, lambda: PassageStore.iter_saved_index(out_dir, 2 * W))
+    assert len(store) == N
+    idx.attach_passage_store(store)
+    import atlas_amd.dist_utils as du2
+    real_gather = du2.all_gather_object
+    du2.all_gather_object = lambda obj: (_ for _ in ()).throw(AssertionError("text collective used despite the passage store"))
+    docs2, scores2 = idx.search_knn(Q, k)
+    du2.all_gather_object = real_gather
+    assert docs2 == docs and scores2 == scores
     ids = np.array([[int(d["id"]) for d in row] for row in docs], dtype=np.int64).reshape(len(docs), k)
     assert all(d["text"] == f"p{d['id']}" for row in docs for d in row)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), ids=ids, scores=np.array(scores, dtype=np.float32).reshape(len(docs), k))

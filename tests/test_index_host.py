@@ -154,3 +154,23 @@ def test_index_io_factory(tmp_path):
     opt.index_mode = "faiss"
     with pytest.raises(ValueError, match="unsupported index mode"):
         load_or_initialize_index(opt)
+
+
+def test_passage_store_roundtrip(tmp_path):
+    """jsonl -> store -> get: same parsing as load_passages (title/section join, None for blank lines), unicode, atomics"""
+    import json
+    from atlas_amd.passage_store import PassageStore
+
+    f = tmp_path / "p.jsonl"
+    items = [{"id": "0", "title": "A", "section": "s", "text": "x"}, None, {"id": "2", "title": "B", "section": "", "text": "é ü 漢"},
+             {"id": "3", "text": "last"}]
+    f.write_text("\n".join("" if it is None else json.dumps(it) for it in items) + "\n")
+    path = str(tmp_path / "store")
+    st = PassageStore.open_shared(path, lambda: PassageStore.iter_jsonl([str(f)]))
+    assert len(st) == 4
+    assert st.get(0)["title"] == "A: s" and st.get(1) is None and st.get(2)["text"] == "é ü 漢" and st[3] == {"id": "3", "text": "last"}
+    st2 = PassageStore.open_shared(path, lambda: (_ for _ in ()).throw(AssertionError("must not rebuild an existing store")))
+    assert st2.get(3) == st.get(3)
+    st3_path = str(tmp_path / "store_max")
+    st3 = PassageStore.open_shared(st3_path, lambda: PassageStore.iter_jsonl([str(f)], maxload=2))
+    assert len(st3) == 2
