@@ -229,7 +229,7 @@ static __device__ __forceinline__ void gemm_epilogue(f4 (&acc)[FA][FB], int64_t 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = T::rnd(acc[a][b][r] + bv[r]);                                 // Linear output in the model dtype
-                if (EPI == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));   // exact-erf GELU in fp32
+                if (EPI == 1) v = (sizeof(typename T::elem) == 2) ? gelu_erf_poly(v) : 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));   // erf GELU in fp32 (common.h)
                 if (EPI == 2) v = v + rr[r];                                            // + input_tensor
                 o[r] = v;                                                               // (rounded by the store)
             }
@@ -381,7 +381,7 @@ static __device__ __forceinline__ void gemm_epilogue_lds(f4 (&acc)[8][4], unsign
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = T::rnd(acc[a][b][r] + bv[r]);                                 // Linear output in the model dtype
-                if (EPI == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));   // exact-erf GELU in fp32
+                if (EPI == 1) v = gelu_erf_poly(v);                                     // erf GELU in fp32 (common.h)
                 o[r] = T::st(v);
             }
             const int gr = (col >> 2) ^ ((t & 15) << 2);

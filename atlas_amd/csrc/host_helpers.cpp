@@ -7,6 +7,7 @@ double h_f16_to_f64(uint16_t h) { return f16_bits_to_f64(h); }
 uint16_t h_f64_to_f16(double x) { return f64_to_f16_bits(x); }
 uint16_t h_f32_to_f16(float x) { return f32_to_f16_bits(x); }
 uint16_t h_f64_to_f16_rto(double x) { return f64_to_f16_bits_rto(x); }
+float h_gelu_erf_poly(float v) { return gelu_erf_poly(v); }
 uint16_t h_bf16_to_f16(uint16_t b) { return bf16_bits_to_f16_bits(b); }
 uint16_t h_f16_order_key(uint16_t h) { return f16_order_key(h); }
 uint16_t h_f16_from_order_key(uint16_t k) { return f16_from_order_key(k); }

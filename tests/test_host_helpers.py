@@ -135,3 +135,34 @@ def test_prune_threshold_is_safe(H):
             assert f16(np.float32(th) + eps) < f16(min(T, 65520.0) - eps), (T, eps)
     assert H.h_prune_threshold(float("-inf"), 0.1) == float("-inf")
     assert H.h_prune_threshold(float("nan"), 0.1) == float("-inf")
+
+
+def test_gelu_poly(H):
+    """the encoder's GELU (common.h::gelu_erf_poly, the same source the kernels compile) over EVERY finite fp16 input:
+    its fp16-rounded result is within 1 ulp of the correctly rounded exact-erf GELU, and at least as often exactly right as
+    the reference's fp32 formula 0.5*v*(1+erf(v/sqrt2)) evaluated with an ideal fp32 erf"""
+    import ctypes
+    from scipy import special
+
+    H.h_gelu_erf_poly.restype = ctypes.c_float
+    H.h_gelu_erf_poly.argtypes = [ctypes.c_float]
+    v = np.arange(65536, dtype=np.uint16).view(np.float16).astype(np.float32)
+    v = v[np.isfinite(v)]
+    got = np.array([H.h_gelu_erf_poly(float(x)) for x in v], dtype=np.float32)
+    exact = 0.5 * v.astype(np.float64) * (1 + special.erf(v.astype(np.float64) / np.sqrt(2)))
+    erf32 = special.erf((v * np.float32(0.70710678118654752)).astype(np.float64)).astype(np.float32)
+    formula = ((np.float32(0.5) * v) * (np.float32(1) + erf32)).astype(np.float32)
+
+    def ordinal(a):
+        i = a.astype(np.float16).view(np.int16).astype(np.int32)
+        return np.where(i < 0, -(i & 0x7FFF), i)
+
+    d_poly = np.abs(ordinal(got) - ordinal(exact))
+    d_formula = np.abs(ordinal(formula) - ordinal(exact))
+    print("gelu fp16: poly wrong on", int((d_poly > 0).sum()), "max", int(d_poly.max()), "ulp; fp32 formula wrong on", int((d_formula > 0).sum()),
+          "max", int(d_formula.max()), "ulp; max |poly - exact| =", float(np.abs(got - exact)[np.abs(v) <= 8].max()))
+    assert d_poly.max() <= 1 and (d_poly > 0).sum() <= (d_formula > 0).sum()
+    assert np.abs(got - exact)[np.abs(v) <= 8].max() <= 4e-7
+    assert np.isnan(H.h_gelu_erf_poly(float("nan"))) and H.h_gelu_erf_poly(0.0) == 0.0
+    assert H.h_gelu_erf_poly(-65504.0) == 0.0 and H.h_gelu_erf_poly(65504.0) == 65504.0
+    assert H.h_gelu_erf_poly(-3.0e38) == 0.0 and H.h_gelu_erf_poly(3.0e38) == np.float32(3.0e38)     # bf16 range
