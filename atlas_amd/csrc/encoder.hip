@@ -1,12 +1,14 @@
-// encoder.hip — Contriever (BERT-base) passage encoder for the index-refresh path, gfx950.
+// encoder.hip — Contriever (BERT-base) encoder for the index-refresh path and for query embedding, gfx950.
 //
-// Replaces what `copy.deepcopy(retriever).half().eval()` runs inside Atlas.build_index (src/atlas.py:54-59, 78):
-// src/retrievers.py:22-60 on top of src/modeling_bert.py (BertEmbeddings :213-247, BertSelfAttention :290-366,
-// BertSelfOutput :382-387, BertIntermediate :448-451, BertOutput :461-466, BertLayerNorm :104-114).
-// Numerics follow the fp16 copy op by op: every tensor the reference materialises in fp16 is rounded to fp16 here at
-// the same place (GEMM outputs after the fp32 bias add, the residual sums, softmax probabilities, GELU outputs, both
-// steps of `weight * y + bias` in the NON-standard LayerNorm); softmax and LayerNorm statistics are fp32. What may
-// differ from a given torch backend is only the fp32 summation order inside GEMMs and reductions.
+// Replaces src/retrievers.py:22-60 on top of src/modeling_bert.py (BertEmbeddings :213-247, BertSelfAttention :290-366,
+// BertSelfOutput :382-387, BertIntermediate :448-451, BertOutput :461-466, BertLayerNorm :104-114) for inference:
+//   fp16  the copy `copy.deepcopy(retriever).half().eval()` of Atlas.build_index / retrieve_with_rerank (src/atlas.py:54-59, 78, 168)
+//   fp32 / bf16 / fp16  query embedding in --precision (src/atlas.py:104)
+// Numerics follow the model dtype op by op: every tensor the reference materialises in that dtype is rounded to it here
+// at the same place (GEMM outputs after the fp32 bias add, the residual sums, scores, softmax probabilities, GELU
+// outputs, both steps of `weight * y + bias` in the NON-standard LayerNorm, the two roundings of the pooling); softmax
+// and LayerNorm statistics are fp32; the erf GELU is evaluated in fp32 (16-bit dtypes: common.h::gelu_erf_poly, fp32:
+// erff). What may differ from a given torch backend is only the fp32 summation order inside GEMMs and reductions.
 //
 // Token packing: only tokens with attention_mask != 0 are computed. Masked keys get probability exactly 0 in the
 // reference (exp(-10000 + s - max) underflows to 0 in fp32) and masked tokens' hidden states are dropped by the
@@ -14,14 +16,17 @@
 // tokens costs 20 tokens. The packing is done on the device (count_kernel + pack_kernel, no host sync): kernels are
 // launched for the worst case n*L tokens and blocks beyond the packed count T = cu[n] exit immediately.
 //
-// Kernels
+// Kernels (T = F16 | BF16 | F32 traits)
 //   count_kernel / pack_kernel   per-passage real-token counts, exclusive scan cu[n+1], tokinfo[t] = (passage, position)
-//   embed_ln_kernel     word + type (+= position) in fp16, LayerNorm                    (one wave per token)
-//   gemm_bt_kernel      C[M,N] = A[M,K] . W[N,K]^T + bias, 128x128x64 tiles, MFMA 16x16x32 f16, LDS double buffer,
-//                       epilogues: plain | exact-erf GELU | + residual        (MFMA-bound: the refresh roofline)
-//   attention_kernel    per (passage, head): QK^T -> fp16 -> /8 + mask -> fp32 softmax -> fp16 P -> PV
-//   ln_kernel           the reference's LayerNorm on a [M,768] fp16 tensor          (one wave per token)
-//   pool_packed_kernel  mean over a passage's tokens with the reference's two roundings, row written into the slab
+//   embed_ln_kernel<T>   word + type (+= position) embeddings, LayerNorm                     (one wave per token)
+//   gemm_pp_kernel<T,EPI>   C[M,N] = A[M,K] . W[N,K]^T + bias on the matrix cores, 256 x 256 tiles, LDS-DMA staging, the
+//                        two waves of a SIMD in opposite read / multiply phases; epilogues: QKV split + V^T | erf GELU |
+//                        + residual, written out through LDS in whole rows        (MFMA-bound: the refresh roofline)
+//   gemm_bt_kernel<T,EPI,..>  the single-phase version; 128 x 128 and 64 x 64 tiles serve small (query) batches
+//   attention_kernel<T,MAXKF>  per (passage, head): S^T = K.Q^T -> dtype -> /8 -> fp32 softmax -> dtype P -> P.V, P in registers
+//   attention_f32_kernel the same on v_mfma_f32_16x16x4_f32 for the fp32 model
+//   ln_kernel<T>         the reference's LayerNorm on a [T,768] tensor                     (one wave per token)
+//   pool_packed_kernel<T>  mean over a passage's tokens with the reference's two roundings, row written into the slab
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
