@@ -161,3 +161,34 @@ def test_fully_masked_passage_gives_nan_like_torch(gpu_index_cls):
     want = ref.cuda()(ids.cuda(), mask.cuda()).float().cpu()
     assert torch.isnan(got[1]).all() and torch.isnan(want[1]).all()
     assert (got[[0, 2]] - want[[0, 2]]).abs().max() / want[[0, 2]].abs().max() <= 4e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+def test_bulk_gemm_kernels_agree_bit_for_bit(dtype, gpu_index_cls, monkeypatch):
+    """Batches above 16k tokens (the index refresh) run the 256x256 ping-pong GEMM (cfg 4); the other tile shapes serve
+    smaller batches. Every configuration adds the k-products of an output element in the same order, so all of them
+    must give the same bits — which also screens the ping-pong schedule's barriers / DMA waits for races (run twice).
+    One configuration is compared with the torch restatement; ragged lengths make the packed token count end inside a
+    tile."""
+    from atlas_amd import retrievers
+    from oracle.contriever_ref import BertConfigLite, ContrieverRef
+
+    ref = ContrieverRef(BertConfigLite(num_hidden_layers=2), seed=8).randomize_affine().to(dtype).eval()
+    mine = retrievers.Contriever(retrievers.BertConfigLite(num_hidden_layers=2))
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine = mine.to(dtype).eval().cuda().requires_grad_(False)
+    ids, mask = _batch(150, 128, seed=31)                    # 19 200 slots -> default configuration = cfg 4
+    assert int(mask.sum()) % 256 != 0
+    ids, mask = ids.cuda(), mask.cuda()
+    monkeypatch.delenv("ATLAS_GEMM_CFG", raising=False)
+    base = mine(ids, mask)
+    assert torch.equal(mine(ids, mask), base)
+    for cfg in ("4", "2", "0", "3"):
+        monkeypatch.setenv("ATLAS_GEMM_CFG", cfg)
+        assert torch.equal(mine(ids, mask), base), f"cfg {cfg} differs from the default configuration"
+    monkeypatch.delenv("ATLAS_GEMM_CFG", raising=False)
+    want = ref.cuda()(ids, mask).float().cpu()
+    err = (base.float().cpu() - want).abs().max() / want.abs().max()
+    tol = {torch.float16: 4e-3, torch.bfloat16: 3e-2, torch.float32: 2e-5}[dtype]
+    print(f"{dtype} bulk: max|d|/max|e| = {err:.2e}")
+    assert err <= tol
