@@ -841,10 +841,18 @@ attention_f32_kernel(const float* __restrict__ qk, const float* __restrict__ vt,
 // reference beats.
 template <class T>
 __global__ void __launch_bounds__(192)
-pool_packed_kernel(const typename T::elem* __restrict__ x, const int* __restrict__ cu, typename T::elem* __restrict__ out) {
+pool_packed_kernel(const typename T::elem* __restrict__ x, const int* __restrict__ cu, const int2* __restrict__ tokinfo, int mode,
+                   void* __restrict__ out_) {
     const int b = blockIdx.x;
     const int tb = cu[b], L = cu[b + 1] - tb;
     const typename T::elem* base = x + (size_t)tb * HID + threadIdx.x * 4;
+    if (mode == ATLAS_POOL_CLS) {
+        // last_hidden[:, 0] after masked_fill (retrievers.py:50, 55-56): position 0 is the first packed token if unmasked
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (L > 0 && tokinfo[tb].y == 0) load4<T>(base, v);
+        store4<T>((typename T::elem*)out_ + (size_t)b * HID + threadIdx.x * 4, v);
+        return;
+    }
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     for (int l = 0; l < L; ++l) {
         float v[4];
@@ -860,9 +868,12 @@ pool_packed_kernel(const typename T::elem* __restrict__ x, const int* __restrict
         if (T::DT == ATLAS_DT_F16) sum = f16_bits_to_f32(f64_to_f16_bits(s[r]));     // single rounding double -> fp16
         else if (T::DT == ATLAS_DT_BF16) sum = T::rnd((float)s[r]);                  // (double -> float -> bf16: the float step is
         else sum = (float)s[r];                                                       //  exact unless > 24 significant bits are live)
-        o[r] = sum / cnt;
+        o[r] = (mode == ATLAS_POOL_SQRT) ? sum / sqrtf(cnt) : sum / cnt;              // retrievers.py:53-54 / :51-52
     }
-    store4<T>(out + (size_t)b * HID + threadIdx.x * 4, o);
+    if (mode == ATLAS_POOL_SQRT)     // dtype tensor / fp32 tensor promotes: the reference returns fp32 here
+        *(float4*)((float*)out_ + (size_t)b * HID + threadIdx.x * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    else
+        store4<T>((typename T::elem*)out_ + (size_t)b * HID + threadIdx.x * 4, o);
 }
 
 // ==========================================================================================
@@ -930,7 +941,7 @@ int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int
                            w->eps, x);
     }
     // rows written contiguously at out (which may point into the passage slab: slab + row_offset * 768)
-    hipLaunchKernelGGL(pool_packed_kernel<T>, dim3((unsigned)n), dim3(192), 0, stream, x, cu, (E*)out);
+    hipLaunchKernelGGL(pool_packed_kernel<T>, dim3((unsigned)n), dim3(192), 0, stream, x, cu, tokinfo, w->pooling, out);
     return (int)hipGetLastError();
 }
 }  // namespace
@@ -956,6 +967,7 @@ int atlas_contriever_embed(const atlas_bert_weights* w, const int64_t* input_ids
         w->n_layers > ATLAS_BERT_MAX_LAYERS || (int64_t)n * L > 0x7fffffff)
         return ATLAS_E_UNSUPPORTED;
     if (w->dtype != ATLAS_DT_F16 && w->dtype != ATLAS_DT_BF16 && w->dtype != ATLAS_DT_F32) return ATLAS_E_UNSUPPORTED;
+    if (w->pooling < ATLAS_POOL_AVERAGE || w->pooling > ATLAS_POOL_CLS) return ATLAS_E_UNSUPPORTED;
     if (ws_bytes < atlas_contriever_workspace_bytes(n, L, w->dtype)) return ATLAS_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     if (w->dtype == ATLAS_DT_F16) return run_encoder<F16>(w, input_ids, attention_mask, token_type_ids, n, L, out, ws, stream);

@@ -26,6 +26,7 @@ import torch.nn as nn
 from . import _lib
 
 EMBEDDINGS_DIM: int = 768
+_POOLING = {"average": 0, "sqrt": 1, "cls": 2}        # ATLAS_POOL_* of include/atlas_hip.h
 
 
 class BertConfigLite:
@@ -111,7 +112,7 @@ class Contriever(nn.Module):
     # ---- weights -> C-ABI struct (fused QKV), cached until a parameter changes ----
     def _pack(self):
         params = list(self.parameters())
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = tuple((p.data_ptr(), p._version) for p in params) + (self.config.pooling,)
         if self._packed is not None and self._packed[0] == key:
             return self._packed[1]
         c = self.config
@@ -126,6 +127,7 @@ class Contriever(nn.Module):
         w.n_layers, w.n_heads, w.hidden, w.intermediate = c.num_hidden_layers, c.num_attention_heads, c.hidden_size, c.intermediate_size
         w.eps = float(c.layer_norm_eps)
         w.dtype = _lib.torch_dtype_code(self.embeddings.word_embeddings.weight.dtype)
+        w.pooling = _POOLING[c.pooling]
         e = self.embeddings
         w.word_emb, w.pos_emb, w.type_emb = dev(e.word_embeddings.weight), dev(e.position_embeddings.weight), dev(e.token_type_embeddings.weight)
         w.emb_ln_w, w.emb_ln_b = dev(e.LayerNorm.weight), dev(e.LayerNorm.bias)
@@ -154,9 +156,13 @@ class Contriever(nn.Module):
                 "atlas_amd.Contriever is an inference encoder (index refresh, query embedding under torch.no_grad()); "
                 "a forward that needs autograd (retriever training) is not implemented and there is no eager fallback"
             )
-        if self.config.pooling != "average":
-            raise _lib.AtlasHipError(f"pooling={self.config.pooling!r} is not implemented (atlas uses 'average')")
+        if self.config.pooling not in _POOLING:
+            raise _lib.AtlasHipError(f"pooling={self.config.pooling!r}: the reference knows 'average', 'sqrt', 'cls' (retrievers.py:51-56)")
         return p.dtype
+
+    def _out_dtype(self):
+        # 'sqrt' divides a model-dtype tensor by an fp32 tensor: torch promotes, the reference returns fp32 (retrievers.py:53-54)
+        return torch.float32 if self.config.pooling == "sqrt" else self.embeddings.word_embeddings.weight.dtype
 
     def embed_into(self, out: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor, token_type_ids=None,
                    trim_padding=False):
@@ -169,7 +175,7 @@ class Contriever(nn.Module):
         dtype = self._check_accelerated()
         L = _lib.lib()
         n, seq = input_ids.shape
-        assert out.dtype == dtype and out.is_contiguous() and tuple(out.shape) == (n, EMBEDDINGS_DIM)
+        assert out.dtype == self._out_dtype() and out.is_contiguous() and tuple(out.shape) == (n, EMBEDDINGS_DIM)
         if n == 0:
             return out
         if trim_padding:
@@ -196,8 +202,7 @@ class Contriever(nn.Module):
                 output_hidden_states=None, normalize=False, trim_padding=False):
         """retrievers.py:22-60. Only the arguments atlas.py passes are supported (ids, mask, token_type_ids)."""
         assert position_ids is None and head_mask is None and inputs_embeds is None and encoder_hidden_states is None
-        dtype = self.embeddings.word_embeddings.weight.dtype
-        out = torch.empty((input_ids.shape[0], EMBEDDINGS_DIM), dtype=dtype, device=input_ids.device)
+        out = torch.empty((input_ids.shape[0], EMBEDDINGS_DIM), dtype=self._out_dtype(), device=input_ids.device)
         self.embed_into(out, input_ids, attention_mask, token_type_ids, trim_padding=trim_padding)
         if normalize:
             out = torch.nn.functional.normalize(out, dim=-1).clone()

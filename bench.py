@@ -212,6 +212,30 @@ def main():
                    "data": "synthetic token ids, random-init BERT-base weights",
                    "roofline": {"bound": "mfma", "achieved": pps * flops_pp / world / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                                 "frac": pps * flops_pp / world / 1e12 / 2500.0, "flops_per_passage": flops_pp}}
+        # SURVEY §8d variant (b): ragged passages, lengths uniform in 64..200 padded to the longest of the batch
+        # (padding="longest"); only real tokens are computed, so the real-token FLOPs are what the MFMAs do and the
+        # padded-token FLOPs are what a padded implementation would have spent
+        lens = torch.randint(64, 201, (nb,), generator=g, device=dev)
+        Lg = int(lens.max())
+        idg = torch.randint(1000, 30522, (nb, Lg), generator=g, device=dev)
+        mkg = (torch.arange(Lg, device=dev)[None, :] < lens[:, None]).to(torch.int64)
+        idg = idg * mkg
+        enc.embed_into(tgt[0], idg, mkg)
+        fence()
+        t3 = time.perf_counter()
+        for i in range(args.refresh_batches):
+            enc.embed_into(tgt[1 + i], idg, mkg)
+        fence()
+        dtg = time.perf_counter() - t3
+        if world > 1:
+            dtg = reduce_max(dtg)
+        lf = lens.double()
+        real_flops = float((169.9e6 * lf + 36864.0 * lf * lf).sum())
+        padded_flops = nb * (169.9e6 * Lg + 36864.0 * Lg * Lg)
+        refresh["ragged"] = {"lengths": "uniform 64..200, padded to %d" % Lg, "value": world * nb * args.refresh_batches / dtg, "unit": "passages/s",
+                             "real_token_tflops": real_flops * args.refresh_batches / dtg / 1e12,
+                             "padded_token_tflops_equivalent": padded_flops * args.refresh_batches / dtg / 1e12,
+                             "mean_len": float(lf.mean())}
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:

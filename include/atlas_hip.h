@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ATLAS_ABI_VERSION 2
+#define ATLAS_ABI_VERSION 3
 
 /* negative return codes */
 #define ATLAS_E_BADARG     (-1)  /* null pointer, B<=0, k<=0, d unsupported ...        */
@@ -148,12 +148,15 @@ int atlas_pool_write(const void* hidden_f16, const int64_t* mask, void* slab_f16
  *   input_ids, attention_mask, token_type_ids (nullable): int64 [n x L] device tensors (HF tokenizer output);
  *            attention_mask is any 0/1 pattern. Only tokens with mask != 0 are computed (packed on the device, no
  *            host sync): cost follows the real token count, results do not depend on the padding.
- *   out:     [n x 768] rows of `dtype`, contiguous; for fp16 it may point into the passage slab
+ *   out:     [n x 768] rows of `dtype` (fp32 for ATLAS_POOL_SQRT), contiguous; for fp16 it may point into the passage slab
  *            (slab + row_offset*768), which makes the refresh write atlas.py:79 part of the pooling epilogue.
  *            A row whose mask is all zero is NaN (0/0), as in the reference.
  *   L <= 512, hidden 768, 12 heads, intermediate 3072 (ATLAS_E_UNSUPPORTED otherwise).
  */
 #define ATLAS_BERT_MAX_LAYERS 24
+#define ATLAS_POOL_AVERAGE 0
+#define ATLAS_POOL_SQRT    1
+#define ATLAS_POOL_CLS     2
 typedef struct {
     const void *qkv_w, *qkv_b, *o_w, *o_b, *ln1_w, *ln1_b, *ff1_w, *ff1_b, *ff2_w, *ff2_b, *ln2_w, *ln2_b;
 } atlas_bert_layer;
@@ -161,6 +164,9 @@ typedef struct {
     int n_layers, n_heads, hidden, intermediate;
     float eps;                                   /* config.layer_norm_eps */
     int dtype;                                   /* ATLAS_DT_F16 | ATLAS_DT_BF16 | ATLAS_DT_F32: weights, activations, output */
+    int pooling;                                 /* config.pooling, retrievers.py:51-56: ATLAS_POOL_AVERAGE (atlas' default) |
+                                                    ATLAS_POOL_SQRT (sum / sqrt(count): the OUTPUT is fp32, as torch promotes) |
+                                                    ATLAS_POOL_CLS (hidden state of position 0, zero if that token is masked) */
     const void *word_emb, *pos_emb, *type_emb, *emb_ln_w, *emb_ln_b;
     atlas_bert_layer layers[ATLAS_BERT_MAX_LAYERS];
 } atlas_bert_weights;

@@ -184,10 +184,15 @@ class ContrieverRef(nn.Module):
         return self.encoder(self.embeddings(input_ids, token_type_ids), ext)
 
     @torch.no_grad()
-    def forward(self, input_ids, attention_mask, token_type_ids=None, normalize=False):
+    def forward(self, input_ids, attention_mask, token_type_ids=None, normalize=False, pooling="average"):
         last_hidden = self.last_hidden(input_ids, attention_mask, token_type_ids)
         last_hidden = last_hidden.masked_fill(~attention_mask[..., None].bool(), 0.0).clone()   # retrievers.py:50
-        emb = last_hidden.sum(dim=1).clone() / attention_mask.sum(dim=1)[..., None].clone()       # retrievers.py:52
+        if pooling == "average":
+            emb = last_hidden.sum(dim=1).clone() / attention_mask.sum(dim=1)[..., None].clone()   # retrievers.py:52
+        elif pooling == "sqrt":
+            emb = last_hidden.sum(dim=1) / torch.sqrt(attention_mask.sum(dim=1)[..., None].float())   # retrievers.py:54
+        elif pooling == "cls":
+            emb = last_hidden[:, 0]                                                               # retrievers.py:56
         if normalize:
             emb = torch.nn.functional.normalize(emb, dim=-1).clone()
         return emb

@@ -85,14 +85,23 @@ def main():
         assert all("position_ids" in k for k in missing.missing_keys), missing      # (a registered buffer, not a parameter)
         model.eval()
         ids, mask = synth_encoder.inputs(case)
+        extra = {}
         with torch.no_grad():
             e32 = model(input_ids=ids, attention_mask=mask).float().numpy()
+            for pooling in ("sqrt", "cls"):                          # retrievers.py:53-56 (config.pooling)
+                model.config.pooling = pooling
+                extra[f"emb_fp32_{pooling}"] = model(input_ids=ids, attention_mask=mask).numpy()
+            model.config.pooling = "average"
             m16 = model.half()
             bind_4_18(m16)
             e16 = m16(input_ids=ids, attention_mask=mask).numpy()
+            for pooling in ("sqrt", "cls"):
+                m16.config.pooling = pooling
+                extra[f"emb_fp16_{pooling}"] = m16(input_ids=ids, attention_mask=mask).numpy()   # 'sqrt' comes back as fp32 (promotion)
+            m16.config.pooling = "average"
         out = os.path.join(HERE, f"enc_{case['name']}.npz")
         np.savez_compressed(out, emb_fp32=e32, emb_fp16=e16, state_sha=np.frombuffer(synth_encoder.state_sha(sd).encode(), dtype=np.uint8),
-                            torch_version=np.frombuffer(torch.__version__.encode(), dtype=np.uint8))
+                            torch_version=np.frombuffer(torch.__version__.encode(), dtype=np.uint8), **extra)
         print(case["name"], "fp32", e32.shape, float(np.abs(e32).max()), "fp16 max|d| vs fp32", float(np.abs(e16.astype(np.float32) - e32).max()), "->", out)
 
 

@@ -41,8 +41,9 @@ def test_restatement_matches_reference_outputs(case):
     z, sd = _load(case)
     ids, mask = synth_encoder.inputs(case)
     m = _restatement(case, sd)
+    m16 = _restatement(case, sd).half()
     e32 = m(ids, mask).float().numpy()
-    e16 = m.half()(ids, mask).numpy()
+    e16 = m16(ids, mask).numpy()
     want32, want16 = z["emb_fp32"], z["emb_fp16"]
     scale = np.abs(want32).max()
     d32 = np.abs(e32 - want32).max() / scale
@@ -50,6 +51,13 @@ def test_restatement_matches_reference_outputs(case):
     same = np.array_equal(e32, want32) and np.array_equal(e16.view(np.uint16), want16.view(np.uint16))
     print(f"{case['name']}: fp32 max|d|/max|e| = {d32:.2e}, fp16 = {d16:.2e}, bit-identical = {same}")
     assert d32 <= 1e-5 and d16 <= 2e-3
+    for pooling in ("sqrt", "cls"):                       # config.pooling variants, retrievers.py:53-56
+        for tag, mm, tol in (("fp32", m, 1e-5), ("fp16", m16, 2e-3)):
+            got = mm(ids, mask, pooling=pooling)
+            want = z[f"emb_{tag}_{pooling}"]
+            assert got.numpy().dtype == want.dtype, (pooling, tag, got.dtype, want.dtype)     # 'sqrt' on fp16 returns fp32
+            d = np.abs(got.float().numpy() - want.astype(np.float32)).max() / np.abs(want.astype(np.float32)).max()
+            assert d <= tol, (pooling, tag, d)
 
 
 @pytest.mark.gpu
@@ -71,3 +79,12 @@ def test_hip_encoder_matches_reference_outputs(case, gpu_index_cls):
         cos = torch.nn.functional.cosine_similarity(got, want, dim=1).min()
         print(f"{case['name']} {dtype}: HIP vs reference max|d|/max|e| = {err:.2e}, min cos = {cos:.7f}")
         assert err <= tol and cos >= 0.99999, (str(dtype), float(err), float(cos))
+        tag = "fp32" if dtype == torch.float32 else "fp16"
+        for pooling in ("sqrt", "cls"):
+            m.config.pooling = pooling
+            got = m(ids.cuda(), mask.cuda())
+            wantp = torch.from_numpy(z[f"emb_{tag}_{pooling}"])
+            assert got.dtype == wantp.dtype, (pooling, got.dtype, wantp.dtype)
+            errp = (got.float().cpu() - wantp.float()).abs().max() / wantp.float().abs().max()
+            assert errp <= tol, (pooling, str(dtype), float(errp))
+        m.config.pooling = "average"
