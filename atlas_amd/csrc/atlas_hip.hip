@@ -496,6 +496,7 @@ int scan_variant_index() {
 
 constexpr int MERGE_NT = 1024;
 unsigned long long* g_merge_dbg = nullptr;   // tuning hook (atlas_dbg_set_merge_stamps); never set in production
+unsigned long long* g_scan_dbg = nullptr;    // tuning hook (atlas_dbg_set_scan_stamps)
 constexpr int SAMPLE_MAX = 16384;
 
 struct ScanPlan {
@@ -599,6 +600,7 @@ extern "C" int atlas_dbg_f64_to_f16(const double* in, uint16_t* out, int n, void
 
 // tuning hook, deliberately not in include/atlas_hip.h: device buffer of >= 8 u64 for merge phase stamps
 void atlas_dbg_set_merge_stamps(unsigned long long* p) { g_merge_dbg = p; }
+void atlas_dbg_set_scan_stamps(unsigned long long* p) { g_scan_dbg = p; }
 
 int atlas_abi_version(void) { return ATLAS_ABI_VERSION; }
 const char* atlas_build_info(void) {
@@ -674,6 +676,7 @@ int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t
         sp.rows_per_wg = pl.rows_per_wg; sp.nq = nq; sp.k = k; sp.cap = pl.cap; sp.keep_max = pl.keep_max;
         sp.buf_cap = pl.buf_cap;
         sp.pmax2_hint = pmax_hint * pmax_hint;
+        sp.dbg = g_scan_dbg;
         if (q0 == 0 && ev_scan_begin) (void)hipEventRecord((hipEvent_t)ev_scan_begin, stream);
         hipLaunchKernelGGL(var.kern, dim3(pl.G), dim3(var.nw * 64), pl.scan_lds, stream, sp);
         if (q0 == 0 && ev_scan_end) (void)hipEventRecord((hipEvent_t)ev_scan_end, stream);

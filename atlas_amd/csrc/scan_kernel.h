@@ -69,6 +69,7 @@ struct ScanParams {
     int nq, k, cap, keep_max;
     int buf_cap;              // entries of the LDS candidate buffer
     float pmax2_hint;
+    unsigned long long* dbg;  // tuning only (atlas_dbg_set_scan_stamps): 4 cycle stamps per workgroup; null in production
 };
 
 struct ScanSmem {   // byte offsets into dynamic LDS
@@ -148,6 +149,7 @@ scan_kernel(const ScanParams p) {
 
     // the query image is copied into LDS AFTER the first ring loads are in flight (their HBM latency
     // overlaps the 96 KiB copy from L2)
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 0] = __builtin_readcyclecounter();
     copy_qfrag_to_lds<NW * 64>(s_q, p.qfrag, tid);
     if (tid < 64) {
         s_theta[tid] = (tid < p.nq) ? p.theta0[tid] : pos_inf();
@@ -155,6 +157,7 @@ scan_kernel(const ScanParams p) {
     }
     if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; }
     __syncthreads();
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 1] = __builtin_readcyclecounter();
 
     f32x4 acc[PF][4];
 #pragma unroll
@@ -378,6 +381,7 @@ scan_kernel(const ScanParams p) {
         par ^= 1;
     }
 
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 2] = __builtin_readcyclecounter();
     // Final hand-over: each query's candidates of ALL workgroups end up contiguous in dense[q], so the
     // merge kernel reads them with coalesced loads and needs no per-workgroup bookkeeping. Buffered
     // entries go LDS -> dense directly; ONE global atomicAdd per (workgroup, query) reserves the range
@@ -431,6 +435,7 @@ scan_kernel(const ScanParams p) {
         atomicMax(&p.gstat[0], f32_bits(pm));
         if (pm > p.pmax2_hint) atomicOr(&p.gstat[1], (uint32_t)ATLAS_F_PMAX_VIOLATION);
     }
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 3] = __builtin_readcyclecounter();
 }
 
 
