@@ -106,6 +106,31 @@ template <class T> static __device__ __forceinline__ void store4(typename T::ele
     *(uint2*)p = make_uint2((uint32_t)T::st(v[0]) | ((uint32_t)T::st(v[1]) << 16), (uint32_t)T::st(v[2]) | ((uint32_t)T::st(v[3]) << 16));
 }
 
+// acc[a][b] += W-fragment a x activation-fragment b for one 16-byte k-chunk per lane. For fp32 a chunk is four k = 4 MFMAs:
+// they are issued element-major, so that consecutive MFMAs go to DIFFERENT accumulators (a dependent v_mfma_f32_16x16x4_f32
+// waits 40 cycles, an independent one issues after 32)
+template <class T, int FA, int FB>
+static __device__ __forceinline__ void mma_tile(const u4v (&fw)[FA], const u4v (&fa)[FB], f4 (&acc)[FA][FB]) {
+    if constexpr (T::DT == ATLAS_DT_F32) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int a = 0; a < FA; ++a) {
+                const uint32_t wa = fw[a][e];
+#pragma unroll
+                for (int b = 0; b < FB; ++b) {
+                    const uint32_t xb = fa[b][e];
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, wa), __builtin_bit_cast(float, xb), acc[a][b], 0, 0, 0);
+                }
+            }
+    } else {
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+#pragma unroll
+            for (int b = 0; b < FB; ++b) acc[a][b] = T::mma(fw[a], fa[b], acc[a][b]);
+    }
+}
+
 static __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
@@ -350,11 +375,14 @@ gemm_bt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         }
         if (kt + 1 < nk) stage(buf ^ 1, kt + 1);       // streams in while this tile is multiplied
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks) {
+            u4v vw[FA], va[FB];
 #pragma unroll
-            for (int a = 0; a < FA; ++a)
+            for (int a = 0; a < FA; ++a) vw[a] = __builtin_bit_cast(u4v, fw[ks][a]);
 #pragma unroll
-                for (int b = 0; b < FB; ++b) acc[a][b] = T::mma(fw[ks][a], fa[ks][b], acc[a][b]);
+            for (int b = 0; b < FB; ++b) va[b] = __builtin_bit_cast(u4v, fa[ks][b]);
+            mma_tile<T, FA, FB>(vw, va, acc);
+        }
         __builtin_amdgcn_sched_barrier(0);             // keep the drain + barrier BEHIND the MFMAs (hipcc hoists it otherwise)
         __syncthreads();
     }
@@ -562,14 +590,8 @@ gemm_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         // ---- multiply phase ----
         if (grpB && kt + 2 < nk) stage(buf, kt + 2);   // into the buffer both groups have finished reading
         PP_STAMP(4);
-#pragma unroll
-        for (int a = 0; a < FA; ++a)
-#pragma unroll
-            for (int b = 0; b < FB; ++b) acc[a][b] = T::mma(fw0[a], fa0[b], acc[a][b]);
-#pragma unroll
-        for (int a = 0; a < FA; ++a)
-#pragma unroll
-            for (int b = 0; b < FB; ++b) acc[a][b] = T::mma(fw1[a], fa1[b], acc[a][b]);
+        mma_tile<T, FA, FB>(fw0, fa0, acc);
+        mma_tile<T, FA, FB>(fw1, fa1, acc);
         __builtin_amdgcn_sched_barrier(0);
         PP_STAMP(5);
         if (!grpB) __builtin_amdgcn_s_waitcnt(0x0F70); // A: its pieces of tile kt+1 have landed
@@ -584,6 +606,116 @@ gemm_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         gemm_epilogue_lds<T, EPI>(acc, smem_raw, m0, n0, wave, lane, M, N, bias, R, C, VT, cu, tokinfo, Lp);
     else
         gemm_epilogue<T, EPI, FA, FB>(acc, m0, n0, wi, wj, lr, lg, M, N, bias, R, C, VT, cu, tokinfo, Lp);
+}
+
+// ------------------------------------------------------------------------------------------
+// The GEMM for SMALL batches (query embedding: tens of tokens per query after packing, <= 4096 token slots): 64 x 64
+// tiles so that a 768-wide GEMM of 1 300 tokens still makes ~250 workgroups, and a DEEP LDS-DMA pipeline. With tiles
+// this small the MFMAs of a k-tile take 130 (16-bit) to 1 000 (fp32) cycles while an LDS-DMA piece needs ~2 000 cycles
+// to land: one stage of prefetch (gemm_bt_kernel) pays that latency on every k-tile (FFN-2, 48 k-tiles: ~100 us of a
+// 108 us layer). Here STAGES - 1 k-tiles are in flight behind counted `s_waitcnt vmcnt(n)`; one barrier per k-tile;
+// fragment reads are inline asm (see gemm_pp_kernel). 3 stages x 16 KiB (fp16 / bf16) leave room for 3 workgroups per
+// CU, which matters as much as the depth: 8 stages (one workgroup per CU) were slower than the single-stage kernel.
+// Per forward of 64 queries x ~20 tokens (profiles/r01/query_gemm_configs.txt): 1.05 ms -> 0.93 ms (fp16), 3.83 -> 3.55 ms (fp32).
+// ------------------------------------------------------------------------------------------
+template <int N> static __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));     // vmcnt(N), expcnt / lgkmcnt untouched
+}
+template <int STAGES> static __device__ __forceinline__ void wait_tiles_in_flight(int younger) {   // 4 pieces per k-tile and wave
+    if constexpr (STAGES >= 8) {
+        if (younger >= 6) { wait_vmcnt<24>(); return; }
+        if (younger == 5) { wait_vmcnt<20>(); return; }
+        if (younger == 4) { wait_vmcnt<16>(); return; }
+        if (younger == 3) { wait_vmcnt<12>(); return; }
+    }
+    if (younger >= 2) wait_vmcnt<8>();
+    else if (younger == 1) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
+}
+
+template <class T, int EPI, int STAGES>
+__global__ void __launch_bounds__(256)
+gemm_ms_kernel(const typename T::elem* __restrict__ A, const typename T::elem* __restrict__ W, const typename T::elem* __restrict__ bias,
+               const typename T::elem* __restrict__ R, typename T::elem* __restrict__ C, typename T::elem* __restrict__ VT,
+               const int* __restrict__ cu, int n, const int2* __restrict__ tokinfo, int N, int K, int Lp) {
+    typedef typename T::elem E;
+    constexpr int BCOL = 64, BTOK = 64, FA = 2, FB = 2;
+    constexpr int EPC = 16 / (int)sizeof(E);
+    constexpr uint32_t STG = 64 * 128;                                 // bytes per operand stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // W stages | A stages
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int64_t M = cu[n];
+    const int ncol = N / BCOL;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int ctile = jj % ncol;
+    const int64_t ttile = (int64_t)(jj / ncol) * 8 + xcd;
+    if (ttile * BTOK >= M) return;
+    const int n0 = ctile * BCOL;
+    const int64_t m0 = ttile * BTOK;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int nk = K / (8 * EPC);
+
+    // this wave's 2 + 2 DMA pieces per k-tile (8 rows x 128 B each, source-side XOR swizzle)
+    const int ch = (lane & 7) ^ (lane >> 3);
+    const E* gw = W + (size_t)(n0 + wave * 16 + (lane >> 3)) * K + ch * EPC;
+    const E* ga[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int64_t ar = m0 + wave * 16 + i * 8 + (lane >> 3);
+        if (ar >= M) ar = M - 1;
+        ga[i] = A + (size_t)ar * K + ch * EPC;
+    }
+    auto stage = [&](const int kt) {
+        const int buf = kt % STAGES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + (size_t)i * 8 * K + kt * (8 * EPC)),
+                                             (__attribute__((address_space(3))) void*)(smem_raw + buf * STG + (wave * 16 + i * 8) * 128), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + kt * (8 * EPC)),
+                                             (__attribute__((address_space(3))) void*)(smem_raw + STAGES * STG + buf * STG + (wave * 16 + i * 8) * 128), 16, 0, 0);
+    };
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+    const uint32_t aw0 = lds0 + (wi * 32 + lr) * 128 + ((0 + lg) ^ (lr & 7)) * 16;
+    const uint32_t aw1 = lds0 + (wi * 32 + lr) * 128 + ((4 + lg) ^ (lr & 7)) * 16;
+    const uint32_t aa0 = lds0 + STAGES * STG + (wj * 32 + lr) * 128 + ((0 + lg) ^ (lr & 7)) * 16;
+    const uint32_t aa1 = lds0 + STAGES * STG + (wj * 32 + lr) * 128 + ((4 + lg) ^ (lr & 7)) * 16;
+
+    f4 acc[FA][FB];
+#pragma unroll
+    for (int a = 0; a < FA; ++a)
+#pragma unroll
+        for (int b = 0; b < FB; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < STAGES - 1 && kt < nk; ++kt) stage(kt);
+    for (int kt = 0; kt < nk; ++kt) {
+        // k-tile kt has landed when at most the pieces of the younger tiles already issued are outstanding
+        int younger = nk - 1 - kt;
+        if (younger > STAGES - 2) younger = STAGES - 2;
+        wait_tiles_in_flight<STAGES>(younger);
+        __builtin_amdgcn_s_barrier();                  // every wave's pieces of tile kt have landed; everybody is past tile kt-1
+        if (kt + STAGES - 1 < nk) stage(kt + STAGES - 1);    // into the buffer of tile kt-1
+        const uint32_t bo = (uint32_t)(kt % STAGES) * STG;
+        u4v fw0[FA], fa0[FB], fw1[FA], fa1[FB];
+        {
+            const uint32_t w0 = aw0 + bo, w1 = aw1 + bo, a0 = aa0 + bo, a1 = aa1 + bo;
+            asm volatile(
+                "ds_read_b128 %0, %8\n ds_read_b128 %1, %8 offset:2048\n ds_read_b128 %2, %9\n ds_read_b128 %3, %9 offset:2048\n"
+                "ds_read_b128 %4, %10\n ds_read_b128 %5, %10 offset:2048\n ds_read_b128 %6, %11\n ds_read_b128 %7, %11 offset:2048\n"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(fw0[0]), "=&v"(fw0[1]), "=&v"(fa0[0]), "=&v"(fa0[1]), "=&v"(fw1[0]), "=&v"(fw1[1]), "=&v"(fa1[0]), "=&v"(fa1[1])
+                : "v"(w0), "v"(a0), "v"(w1), "v"(a1)
+                : "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile<T, FA, FB>(fw0, fa0, acc);
+        mma_tile<T, FA, FB>(fw1, fa1, acc);
+    }
+    gemm_epilogue<T, EPI, FA, FB>(acc, m0, n0, wi, wj, lr, lg, M, N, bias, R, C, VT, cu, tokinfo, Lp);
 }
 
 // tile configurations (ATLAS_GEMM_CFG overrides; tuning)
@@ -607,7 +739,14 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
                            VT, cu, n, tokinfo, N, K, Lp, g_gemm_dbg);
     }
     else if (cfg == 2) go(gemm_bt_kernel<T, EPI, 256, 256, 2, 4>, 256, 256, 512);
-    else if (cfg == 3) go(gemm_bt_kernel<T, EPI, 64, 64, 2, 2>, 64, 64, 256);
+    else if (cfg == 3) {
+        constexpr int ST = (sizeof(typename T::elem) == 2) ? 3 : 4;   // measured: 3 x 16 KiB (3 workgroups / CU) best for 16-bit
+        (void)hipFuncSetAttribute((const void*)gemm_ms_kernel<T, EPI, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const unsigned mtiles = (unsigned)((Mmax + 63) / 64);
+        hipLaunchKernelGGL((gemm_ms_kernel<T, EPI, ST>), dim3((mtiles + 7) / 8 * 8 * (N / 64)), dim3(256), (size_t)ST * 2 * 64 * 128, stream, A, W,
+                           bias, R, C, VT, cu, n, tokinfo, N, K, Lp);
+    }
+    else if (cfg == 5) go(gemm_bt_kernel<T, EPI, 64, 64, 2, 2>, 64, 64, 256);
     else go(gemm_bt_kernel<T, EPI, 128, 128, 2, 2>, 128, 128, 256);
 }
 
