@@ -8,11 +8,16 @@
 // mode 2: global_load_dwordx4 to registers + ds_write_b128         mode 3: global_load_dwordx4 to registers only
 template <int MODE>
 __global__ void __launch_bounds__(512) dma_kernel(const unsigned char* __restrict__ src, int K_bytes, int tiles, int reps, unsigned* out,
-                                                   unsigned long long* cyc) {
+                                                   unsigned long long* cyc, int share, int deep) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // 512 rows of K_bytes; k-tile t = bytes [t*128, t*128+128) of every row; piece = 8 rows x 128 B
-    const unsigned char* base = src + (size_t)(blockIdx.x & 7) * 0;     // all blocks read the same rows: L2-resident
+    // rows 0-255 ("W"): the same for all blocks (L2-resident); rows 256-511 ("activations"): shared by `share` consecutive blocks,
+    // distinct otherwise (share = 0: everything shared). Mimics the GEMM, where 3-12 column tiles share an activation tile.
+    const unsigned char* base = src;
+    const bool blocked = share < 0;                 // activation tile stored k-tile-major: [k-tile][256 rows][128 B] (one k-tile = 32 KiB contiguous)
+    if (blocked) share = -share;
+    const unsigned char* abase = src + (size_t)256 * K_bytes + (share > 0 ? (size_t)(blockIdx.x / share + 1) * 256 * K_bytes : 0);
     uint4 accv = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const unsigned long long t0 = __builtin_readcyclecounter();
@@ -25,19 +30,21 @@ __global__ void __launch_bounds__(512) dma_kernel(const unsigned char* __restric
 #pragma unroll
                     for (int i = 0; i < npieces; ++i) {
                         const int row = ((MODE == 0 ? wave * 8 : wave * 16) + i) * 8 + (lane >> 3);
-                        const unsigned char* g = base + (size_t)row * K_bytes + t * 128 + (lane & 7) * 16;
+                        const unsigned char* g = (row < 256 ? base + (size_t)row * K_bytes + t * 128
+                                                            : (blocked ? abase + (size_t)t * 32768 + (size_t)(row - 256) * 128
+                                                                       : abase + (size_t)(row - 256) * K_bytes + t * 128)) + (lane & 7) * 16;
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                          (__attribute__((address_space(3))) void*)(smem + buf * 65536 + ((MODE == 0 ? wave * 8 : wave * 16) + i) * 1024), 16, 0, 0);
                     }
                 }
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-                __builtin_amdgcn_s_barrier();
+                if (deep) __builtin_amdgcn_s_waitcnt(0x0F70 | (48 & 15) | ((48 >> 4) << 14));   // vmcnt(48): up to 7 k-tiles of this wave in flight, no barrier
+                else { __builtin_amdgcn_s_waitcnt(0x0F70); __builtin_amdgcn_s_barrier(); }
             } else {
                 uint4 v[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int row = (wave * 8 + i) * 8 + (lane >> 3);
-                    v[i] = *(const uint4*)(base + (size_t)row * K_bytes + t * 128 + (lane & 7) * 16);
+                    v[i] = *(const uint4*)((row < 256 ? base + (size_t)row * K_bytes : abase + (size_t)(row - 256) * K_bytes) + t * 128 + (lane & 7) * 16);
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -47,19 +54,20 @@ __global__ void __launch_bounds__(512) dma_kernel(const unsigned char* __restric
                 if (MODE == 2) __syncthreads();
             }
         }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     const unsigned long long t1 = __builtin_readcyclecounter();
     if (tid == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
     if (MODE >= 2) { unsigned x = accv.x ^ accv.y ^ accv.z ^ accv.w ^ ((unsigned*)smem)[tid]; if (x == 0x12345) out[0] = x; }
     else if (((unsigned*)smem)[tid] == 0x12345) out[0] = 1;
 }
 
-extern "C" float dma_bench(int mode, const void* src, int K_bytes, int tiles, int reps, int blocks, void* out, void* cyc) {
+extern "C" float dma_bench(int mode, const void* src, int K_bytes, int tiles, int reps, int blocks, void* out, void* cyc, int share, int deep) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto launch = [&]() {
-        if (mode == 0) { hipFuncSetAttribute((const void*)dma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); hipLaunchKernelGGL(dma_kernel<0>, dim3(blocks), dim3(512), 131072, 0, (const unsigned char*)src, K_bytes, tiles, reps, (unsigned*)out, (unsigned long long*)cyc); }
-        if (mode == 1) { hipFuncSetAttribute((const void*)dma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); hipLaunchKernelGGL(dma_kernel<1>, dim3(blocks), dim3(512), 131072, 0, (const unsigned char*)src, K_bytes, tiles, reps, (unsigned*)out, (unsigned long long*)cyc); }
-        if (mode == 2) { hipFuncSetAttribute((const void*)dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); hipLaunchKernelGGL(dma_kernel<2>, dim3(blocks), dim3(512), 131072, 0, (const unsigned char*)src, K_bytes, tiles, reps, (unsigned*)out, (unsigned long long*)cyc); }
-        if (mode == 3) { hipFuncSetAttribute((const void*)dma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); hipLaunchKernelGGL(dma_kernel<3>, dim3(blocks), dim3(512), 131072, 0, (const unsigned char*)src, K_bytes, tiles, reps, (unsigned*)out, (unsigned long long*)cyc); }
+        if (mode == 0) { hipFuncSetAttribute((const void*)dma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); hipLaunchKernelGGL(dma_kernel<0>, dim3(blocks), dim3(512), 131072, 0, (const unsigned char*)src, K_bytes, tiles, reps, (unsigned*)out, (unsigned long long*)cyc, share, deep); }
+        if (mode == 1) { hipFuncSetAttribute((const void*)dma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); hipLaunchKernelGGL(dma_kernel<1>, dim3(blocks), dim3(512), 131072, 0, (const unsigned char*)src, K_bytes, tiles, reps, (unsigned*)out, (unsigned long long*)cyc, share, deep); }
+        if (mode == 2) { hipFuncSetAttribute((const void*)dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); hipLaunchKernelGGL(dma_kernel<2>, dim3(blocks), dim3(512), 131072, 0, (const unsigned char*)src, K_bytes, tiles, reps, (unsigned*)out, (unsigned long long*)cyc, share, deep); }
+        if (mode == 3) { hipFuncSetAttribute((const void*)dma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); hipLaunchKernelGGL(dma_kernel<3>, dim3(blocks), dim3(512), 131072, 0, (const unsigned char*)src, K_bytes, tiles, reps, (unsigned*)out, (unsigned long long*)cyc, share, deep); }
     };
     launch(); hipDeviceSynchronize();
     hipEventRecord(e0, 0); launch(); hipEventRecord(e1, 0); hipEventSynchronize(e1);
