@@ -3,7 +3,7 @@ import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 from atlas_amd import retrievers, _lib
-os.environ["ATLAS_GEMM_CFG"] = "4"
+os.environ["ATLAS_GEMM_CFG"] = os.environ.get("ATLAS_GEMM_CFG", "4")
 L = _lib.lib()
 L.atlas_dbg_set_gemm_stamps.argtypes = [ctypes.c_void_p]
 m = retrievers.Contriever(retrievers.BertConfigLite(num_hidden_layers=1)).half().eval().cuda().requires_grad_(False)
@@ -18,7 +18,7 @@ m.embed_into(out, ids, mask); torch.cuda.synchronize()        # last GEMM = FF2 
 L.atlas_dbg_set_gemm_stamps(None)
 t = dbg.cpu().view(8, 16, 8)
 t0 = int(t[:, 0, 0].min())
-names = ["dma", "reads", "bar1", "-", "mfma", "vmw", "bar2"]
+names = ["-", "reads", "dmaA/vmwB", "bar1", "dmaB", "mfma", "vmwA", "bar2"][1:]
 for w in (0, 1, 4, 5):
     print("wave", w)
     for kt in range(2, 8):
