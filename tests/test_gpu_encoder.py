@@ -192,3 +192,24 @@ def test_bulk_gemm_kernels_agree_bit_for_bit(dtype, gpu_index_cls, monkeypatch):
     tol = {torch.float16: 4e-3, torch.bfloat16: 3e-2, torch.float32: 2e-5}[dtype]
     print(f"{dtype} bulk: max|d|/max|e| = {err:.2e}")
     assert err <= tol
+
+
+def test_token_type_ids_and_rerank_call_shape(gpu_index_cls):
+    """retrieve_with_rerank (src/atlas.py:120-176) calls `retrieverfp16(**tokenizer_output, is_passages=True)`: the HF BERT
+    tokenizer output carries token_type_ids. Non-zero token types must reach the embedding sum (modeling_bert.py:236-238)."""
+    from atlas_amd import retrievers
+
+    ref, mine = _models(2)
+    ids, mask = _batch(7, 50, seed=41)
+    tt = (torch.rand((7, 50), generator=torch.Generator().manual_seed(42)) < 0.4).long() * mask
+    r16 = retrievers.DualEncoderRetriever(None, mine)
+    enc = {"input_ids": ids.cuda(), "token_type_ids": tt.cuda(), "attention_mask": mask.cuda()}
+    got = r16(**enc, is_passages=True).float().cpu()
+    want = ref.cuda()(ids.cuda(), mask.cuda(), token_type_ids=tt.cuda()).float().cpu()
+    assert (got - want).abs().max() / want.abs().max() <= 4e-3
+    without = r16(input_ids=ids.cuda(), attention_mask=mask.cuda(), is_passages=True).float().cpu()
+    assert (got - without).abs().max() > 1e-2 * want.abs().max()        # the token types did change the result
+    # the rerank arithmetic that follows (atlas.py:170-171) on these embeddings
+    q = torch.randn((1, 768), generator=torch.Generator().manual_seed(43)).cuda()
+    scores = torch.einsum("id, ijd->ij", [q, r16(**enc, is_passages=True).to(q).view(1, 7, -1)])
+    assert scores.shape == (1, 7) and torch.isfinite(scores).all()
