@@ -109,6 +109,41 @@ class Contriever(nn.Module):
         self._packed = None          # (key, BertWeights struct, tensors kept alive)
         self._ws = None
 
+    @classmethod
+    def from_pretrained(cls, path, pooling="average", **kwargs):
+        """`Contriever.from_pretrained(opt.retriever_model_path)` (src/model_io.py:45) for a LOCAL directory in the HF layout:
+        config.json + model.safetensors or pytorch_model.bin (facebook/contriever ships both). Keys may carry the `bert.`
+        prefix of task heads; `pooler.*` (unused: add_pooling_layer=False, retrievers.py:17) and position_ids buffers are
+        dropped. No hub download (there is no network on the target boxes)."""
+        import json
+        import os
+
+        with open(os.path.join(path, "config.json")) as f:
+            cj = json.load(f)
+        known = ("vocab_size", "hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size", "max_position_embeddings",
+                 "type_vocab_size", "layer_norm_eps", "initializer_range", "pad_token_id")
+        config = BertConfigLite(**{k: cj[k] for k in known if k in cj}, pooling=cj.get("pooling", pooling))
+        if cj.get("hidden_act", "gelu") != "gelu":
+            raise _lib.AtlasHipError(f"hidden_act={cj['hidden_act']!r}: only the exact-erf 'gelu' of BERT / Contriever is implemented")
+        st_path, bin_path = os.path.join(path, "model.safetensors"), os.path.join(path, "pytorch_model.bin")
+        if os.path.exists(st_path):
+            from safetensors.torch import load_file
+
+            sd = load_file(st_path)
+        elif os.path.exists(bin_path):
+            sd = torch.load(bin_path, map_location="cpu", weights_only=True)
+        else:
+            raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {path}")
+        clean = {}
+        for k, v in sd.items():
+            k = k[5:] if k.startswith("bert.") else k
+            if k.startswith("pooler.") or k.endswith("position_ids"):
+                continue
+            clean[k] = v
+        model = cls(config)
+        model.load_state_dict(clean, strict=True)
+        return model
+
     # ---- weights -> C-ABI struct (fused QKV), cached until a parameter changes ----
     def _pack(self):
         params = list(self.parameters())

@@ -174,3 +174,35 @@ def test_passage_store_roundtrip(tmp_path):
     st3_path = str(tmp_path / "store_max")
     st3 = PassageStore.open_shared(st3_path, lambda: PassageStore.iter_jsonl([str(f)], maxload=2))
     assert len(st3) == 2
+
+
+def test_contriever_from_pretrained_local_dir(tmp_path):
+    """src/model_io.py:45 loads the retriever with Contriever.from_pretrained(path): HF directory layout, both file formats,
+    optional `bert.` prefix and pooler weights"""
+    import json
+    import torch
+    from safetensors.torch import save_file
+    from atlas_amd import retrievers
+
+    cfg = dict(vocab_size=50, hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=3072,
+               max_position_embeddings=16, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu", model_type="bert")
+    src = retrievers.Contriever(retrievers.BertConfigLite(vocab_size=50, num_hidden_layers=1, max_position_embeddings=16))
+    sd = {k: v.detach().clone() for k, v in src.state_dict().items()}
+    for sub, fmt, prefix in (("a", "safetensors", ""), ("b", "bin", "bert.")):
+        d = tmp_path / sub
+        d.mkdir()
+        (d / "config.json").write_text(json.dumps(cfg))
+        out = {prefix + k: v for k, v in sd.items()}
+        out[prefix + "pooler.dense.weight"] = torch.zeros(768, 768)
+        out[prefix + "embeddings.position_ids"] = torch.arange(16)[None]
+        if fmt == "safetensors":
+            save_file(out, str(d / "model.safetensors"))
+        else:
+            torch.save(out, str(d / "pytorch_model.bin"))
+        m = retrievers.Contriever.from_pretrained(str(d))
+        assert m.config.num_hidden_layers == 1 and m.config.pooling == "average"
+        for k, v in m.state_dict().items():
+            assert torch.equal(v, sd[k]), k
+    (tmp_path / "a" / "config.json").write_text(json.dumps({**cfg, "hidden_act": "relu"}))
+    with pytest.raises(Exception, match="hidden_act"):
+        retrievers.Contriever.from_pretrained(str(tmp_path / "a"))
