@@ -718,7 +718,13 @@ gemm_ms_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     gemm_epilogue<T, EPI, FA, FB>(acc, m0, n0, wi, wj, lr, lg, M, N, bias, R, C, VT, cu, tokinfo, Lp);
 }
 
-// tile configurations (ATLAS_GEMM_CFG overrides; tuning)
+// GEMM configurations. The encoder picks by worst-case token slots n * L: > 16384 -> 4, > 4096 -> 0, else 3;
+// ATLAS_GEMM_CFG=<n> forces one (tuning and the bit-equality test: every configuration gives the same bits).
+//   4  gemm_pp_kernel  256 x 256, ping-pong schedule, LDS epilogue          (index refresh)
+//   2  gemm_bt_kernel  256 x 256, single phase                              (A/B reference for 4)
+//   0  gemm_bt_kernel  128 x 128
+//   3  gemm_ms_kernel  64 x 64, 3 (16-bit) / 4 (fp32) LDS-DMA stages        (query batches)
+//   5  gemm_bt_kernel  64 x 64, single stage                                (A/B reference for 3)
 unsigned long long* g_gemm_dbg = nullptr;    // tuning hook (atlas_dbg_set_gemm_stamps); never set in production
 
 template <class T, int EPI>
@@ -1041,7 +1047,7 @@ int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int
     int2* tokinfo = (int2*)p;
 
     const unsigned tok_blocks = (unsigned)((M + 3) / 4), pas_blocks = (unsigned)((n + 3) / 4);
-    // bulk refresh: the 256x256 ping-pong kernel (cfg 4; cfg 2 = gemm_bt_kernel 256x256, the single-phase version kept for A/B runs). Small batches (queries) need more, smaller tiles to cover the 256 CUs: 64 queries
+    // configuration table: see launch_gemm. Small batches (queries) need more, smaller tiles to cover the 256 CUs: 64 queries
     // x ~20 tokens are 21 x 12 tiles of 64x64 for a 768-wide GEMM
     const char* cfg_env = getenv("ATLAS_GEMM_CFG");
     const int cfg = cfg_env ? atoi(cfg_env) : (M > 16384 ? 4 : (M > 4096 ? 0 : 3));
