@@ -364,6 +364,8 @@ class HipDistributedIndex(object):
         return docs, out_scores
 
     def _pack(self, scores_d, rows_d, scores_h, rows_h, id_mul, id_add) -> torch.Tensor:
+        if scores_d.numel() == 0:                       # every rank's batch is empty: nothing to launch
+            return torch.empty(scores_d.shape, dtype=torch.int64, device=scores_d.device)
         if scores_d.is_cuda:
             L = _lib.lib()
             out = torch.empty(scores_d.shape, dtype=torch.int64, device=scores_d.device)
@@ -377,6 +379,8 @@ class HipDistributedIndex(object):
     def _merge(self, gathered: torch.Tensor, k: int) -> np.ndarray:
         """W*k -> k per query under the canonical order (replaces index.py:151)."""
         W, B, kk = gathered.shape
+        if B == 0:
+            return np.empty((0, k), dtype=np.int64)
         if gathered.is_cuda and W * kk <= 8192:
             L = _lib.lib()
             out = torch.empty((B, k), dtype=torch.int64, device=gathered.device)

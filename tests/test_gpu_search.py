@@ -291,3 +291,31 @@ def test_1m_oracle_subset(big, oracle_mod):
     s, i = idx._compute_scores_and_indices(q[:4], 40)
     es, ei = oracle_mod.search(q[:4].half().cpu().numpy(), slab.cpu().numpy(), 40)
     parity.assert_identical(s.cpu().numpy(), i.cpu().numpy(), es, ei, "1M oracle")
+
+
+def test_search_knn_over_rccl_world_size_1(gpu_index_cls, oracle_mod):
+    """The distributed branch of search_knn is taken whenever a process group exists, even at W = 1 (index.py:134). With the
+    `nccl` (= RCCL) backend this runs the device-side pack -> all_gather_into_tensor -> merge kernels and the fp16 query
+    all-gather on GPU tensors; results must equal the single-process ones (and the oracle)."""
+    import os
+    import socket
+    import torch.distributed as dist
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        N, k = 5000, 12
+        P = synth.passages_f16(N, 768, 71)
+        Q = synth.queries_f32(9, 768, 72)
+        idx = gpu_index_cls()
+        idx.init_embeddings([{"id": str(i), "title": f"t{i}", "text": f"x{i}"} for i in range(N)])
+        idx.embeddings[:, :] = torch.from_numpy(P).cuda().T
+        docs, scores = idx.search_knn(torch.from_numpy(Q).cuda(), k)
+        es, ei = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, k)
+        assert [[int(d["id"]) for d in row] for row in docs] == ei.tolist()
+        assert scores == es.astype(np.float32).tolist()
+        docs0, scores0 = idx.search_knn(torch.empty((0, 768), device="cuda"), k)      # an empty local batch is legal (evaluate.py:30-35)
+        assert docs0 == [] and scores0 == []
+    finally:
+        dist.destroy_process_group()
