@@ -319,3 +319,17 @@ def test_search_knn_over_rccl_world_size_1(gpu_index_cls, oracle_mod):
         assert docs0 == [] and scores0 == []
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scale", [0.05, 4.0, 0.0005])
+def test_other_exponent_buckets(scale, gpu_index_cls, oracle_mod):
+    """un-normalised slabs (0.05 * randn, scores O(0.3)) and large / tiny magnitudes: fp16 scores land in other
+    exponent buckets (coarser / finer ulps, subnormal scores), the certified margin scales with pmax"""
+    N, B, k = 60000, 20, 40
+    P = synth.normal_f32(N, 768, 81, scale).astype(np.float16)
+    Q = synth.queries_f32(B, 768, 82)
+    idx = _index(gpu_index_cls, P)
+    s, i = _search(idx, Q, k)
+    es, ei = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, k)
+    parity.assert_identical(s, i, es, ei, f"scale={scale}")
+    assert idx.last_search_stats["max_err_over_eps"] < 0.25
