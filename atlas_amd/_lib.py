@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_SO = os.path.join(HERE, "lib", "libatlas_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 DT_F16, DT_F32, DT_BF16 = 0, 1, 2
 STATUS_HEADER = 8
 ST_FLAGS, ST_PMAX_BITS, ST_N_FALLBACK, ST_N_CANDIDATES, ST_N_RESCORED, ST_MAXERR_BITS = 0, 1, 2, 3, 4, 5
@@ -39,6 +39,7 @@ class BertLayerW(ctypes.Structure):
 class BertWeights(ctypes.Structure):
     _fields_ = [("n_layers", ctypes.c_int), ("n_heads", ctypes.c_int), ("hidden", ctypes.c_int),
                 ("intermediate", ctypes.c_int), ("eps", ctypes.c_float), ("dtype", ctypes.c_int), ("pooling", ctypes.c_int),
+                ("vocab_size", ctypes.c_int), ("max_positions", ctypes.c_int), ("type_vocab", ctypes.c_int),
                 ("word_emb", ctypes.c_void_p), ("pos_emb", ctypes.c_void_p), ("type_emb", ctypes.c_void_p),
                 ("emb_ln_w", ctypes.c_void_p), ("emb_ln_b", ctypes.c_void_p),
                 ("layers", BertLayerW * BERT_MAX_LAYERS)]

@@ -202,7 +202,7 @@ pack_kernel(const int64_t* __restrict__ mask, int n, int L, const int* __restric
 template <class T>
 __global__ void __launch_bounds__(256)
 embed_ln_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ type_ids, int L, const int* __restrict__ cu, int n,
-                const int2* __restrict__ tokinfo,
+                const int2* __restrict__ tokinfo, int vocab, int type_vocab,
                 const typename T::elem* __restrict__ word, const typename T::elem* __restrict__ pos, const typename T::elem* __restrict__ type,
                 const typename T::elem* __restrict__ lnw, const typename T::elem* __restrict__ lnb, float eps, typename T::elem* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -210,7 +210,9 @@ embed_ln_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ typ
     if (t >= cu[n]) return;
     const int2 ti = tokinfo[t];
     const size_t src = (size_t)ti.x * L + ti.y;
-    const int64_t id = ids[src], ty = type_ids ? type_ids[src] : 0;
+    int64_t id = ids[src], ty = type_ids ? type_ids[src] : 0;
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);            // never read outside the tables (atlas_hip.h)
+    ty = ty < 0 ? 0 : (ty >= type_vocab ? type_vocab - 1 : ty);
     const int p = ti.y;
     float x[12];
 #pragma unroll
@@ -1054,6 +1056,7 @@ int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int
     hipLaunchKernelGGL(count_kernel, dim3(pas_blocks), dim3(256), 0, stream, attention_mask, n, L, counts);
     hipLaunchKernelGGL(pack_kernel, dim3(pas_blocks), dim3(256), 0, stream, attention_mask, n, L, counts, cu, tokinfo);
     hipLaunchKernelGGL(embed_ln_kernel<T>, dim3(tok_blocks), dim3(256), 0, stream, input_ids, token_type_ids, L, cu, n, tokinfo,
+                       w->vocab_size, w->type_vocab,
                        (const E*)w->word_emb, (const E*)w->pos_emb, (const E*)w->type_emb, (const E*)w->emb_ln_w,
                        (const E*)w->emb_ln_b, w->eps, x);
     for (int l = 0; l < w->n_layers; ++l) {
@@ -1113,6 +1116,7 @@ int atlas_contriever_embed(const atlas_bert_weights* w, const int64_t* input_ids
         return ATLAS_E_UNSUPPORTED;
     if (w->dtype != ATLAS_DT_F16 && w->dtype != ATLAS_DT_BF16 && w->dtype != ATLAS_DT_F32) return ATLAS_E_UNSUPPORTED;
     if (w->pooling < ATLAS_POOL_AVERAGE || w->pooling > ATLAS_POOL_CLS) return ATLAS_E_UNSUPPORTED;
+    if (w->vocab_size < 1 || w->type_vocab < 1 || w->max_positions < 1 || L > w->max_positions) return ATLAS_E_BADARG;
     if (ws_bytes < atlas_contriever_workspace_bytes(n, L, w->dtype)) return ATLAS_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     if (w->dtype == ATLAS_DT_F16) return run_encoder<F16>(w, input_ids, attention_mask, token_type_ids, n, L, out, ws, stream);

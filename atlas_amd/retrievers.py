@@ -163,6 +163,9 @@ class Contriever(nn.Module):
         w.eps = float(c.layer_norm_eps)
         w.dtype = _lib.torch_dtype_code(self.embeddings.word_embeddings.weight.dtype)
         w.pooling = _POOLING[c.pooling]
+        e0 = self.embeddings
+        w.vocab_size, w.max_positions, w.type_vocab = (e0.word_embeddings.weight.shape[0], e0.position_embeddings.weight.shape[0],
+                                                       e0.token_type_embeddings.weight.shape[0])
         e = self.embeddings
         w.word_emb, w.pos_emb, w.type_emb = dev(e.word_embeddings.weight), dev(e.position_embeddings.weight), dev(e.token_type_embeddings.weight)
         w.emb_ln_w, w.emb_ln_b = dev(e.LayerNorm.weight), dev(e.LayerNorm.bias)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ATLAS_ABI_VERSION 3
+#define ATLAS_ABI_VERSION 4
 
 /* negative return codes */
 #define ATLAS_E_BADARG     (-1)  /* null pointer, B<=0, k<=0, d unsupported ...        */
@@ -167,6 +167,9 @@ typedef struct {
     int pooling;                                 /* config.pooling, retrievers.py:51-56: ATLAS_POOL_AVERAGE (atlas' default) |
                                                     ATLAS_POOL_SQRT (sum / sqrt(count): the OUTPUT is fp32, as torch promotes) |
                                                     ATLAS_POOL_CLS (hidden state of position 0, zero if that token is masked) */
+    int vocab_size, max_positions, type_vocab;   /* rows of word_emb / pos_emb / type_emb. L > max_positions -> ATLAS_E_BADARG;
+                                                    token / type ids outside the tables are clamped into them (the reference
+                                                    raises a device-side assert there; this library never reads out of bounds) */
     const void *word_emb, *pos_emb, *type_emb, *emb_ln_w, *emb_ln_b;
     atlas_bert_layer layers[ATLAS_BERT_MAX_LAYERS];
 } atlas_bert_weights;

@@ -213,3 +213,20 @@ def test_token_type_ids_and_rerank_call_shape(gpu_index_cls):
     q = torch.randn((1, 768), generator=torch.Generator().manual_seed(43)).cuda()
     scores = torch.einsum("id, ijd->ij", [q, r16(**enc, is_passages=True).to(q).view(1, 7, -1)])
     assert scores.shape == (1, 7) and torch.isfinite(scores).all()
+
+
+def test_table_bounds(gpu_index_cls):
+    """sequence longer than the position table -> error, not an out-of-bounds read; ids outside the vocabulary are clamped"""
+    from atlas_amd import retrievers, _lib
+
+    m = retrievers.Contriever(retrievers.BertConfigLite(vocab_size=100, num_hidden_layers=1, max_position_embeddings=16))
+    m = m.half().eval().cuda().requires_grad_(False)
+    ids = torch.randint(0, 100, (3, 16)).cuda()
+    mask = torch.ones((3, 16), dtype=torch.int64).cuda()
+    ok = m(ids, mask)
+    assert torch.isfinite(ok.float()).all()
+    with pytest.raises(_lib.AtlasHipError, match="BADARG"):
+        m(torch.randint(0, 100, (3, 17)).cuda(), torch.ones((3, 17), dtype=torch.int64).cuda())
+    big = ids.clone(); big[0, 3] = 10**9; big[1, 2] = -5
+    clamped = ids.clone(); clamped[0, 3] = 99; clamped[1, 2] = 0
+    assert torch.equal(m(big, mask), m(clamped, mask))
