@@ -486,6 +486,8 @@ const ScanVariant kVariants[] = {
     {8, 4, 4, scan_kernel<8, 4, 4>, "scan_kernel<8,4,4>"},
     {16, 2, 4, scan_kernel<16, 2, 4>, "scan_kernel<16,2,4>"},
     {12, 2, 4, scan_kernel<12, 2, 4>, "scan_kernel<12,2,4>"},
+    {16, 1, 8, scan_kernel<16, 1, 8, 2>, "scan_kernel<16,1,8,nt>"},
+    {16, 1, 8, scan_kernel<16, 1, 8, 16>, "scan_kernel<16,1,8,sc1>"},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 int scan_variant_index() {

@@ -81,7 +81,8 @@ struct ScanSmem {   // byte offsets into dynamic LDS
     static constexpr int buf_off = aux_off + 768;         // buf_cap x {u32 score bits, u32 (query<<26)|row}
 };
 
-template <int NW, int PF, int RING>
+// AUX = cache-policy bits of the slab loads (0 = default, 2 = nt: rows are read once by one CU)
+template <int NW, int PF, int RING, int AUX = 0>
 __global__ void __launch_bounds__(NW * 64)
 scan_kernel(const ScanParams p) {
     // RING slots of PF fragments: RING-1 k-steps of loads in flight while one slot is consumed
@@ -140,7 +141,7 @@ scan_kernel(const ScanParams p) {
     for (int s = 0; s < RING - 1; ++s) {
 #pragma unroll
         for (int pf = 0; pf < PF; ++pf)
-            abuf[s][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)vo[pf], fill_step * 64, 0);
+            abuf[s][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)vo[pf], fill_step * 64, AUX);
         fill_advance();
         // keep issue order == ring order: hipcc's waitcnt for slot 0 is the minimum over the loop
         // entry and the back edge, so a shuffled prologue would cost ring depth on every revolution
@@ -268,7 +269,7 @@ scan_kernel(const ScanParams p) {
             const int fill = (j + RING - 1) % RING;
 #pragma unroll
             for (int pf = 0; pf < PF; ++pf)
-                abuf[fill][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)vo[pf], fill_step * 64, 0);
+                abuf[fill][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)vo[pf], fill_step * 64, AUX);
             fill_advance();
             __builtin_amdgcn_sched_barrier(0);
             uint4 b[4];
