@@ -185,4 +185,32 @@ ATLAS_HD float gelu_erf_poly(float v) {
     return (v >= 0.0f) ? v - h : h;     // NaN -> h = NaN
 }
 
+#if defined(__HIPCC__)
+// The same function on two values at once with the packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): the same
+// operations in the same order per element, so the results are bit-identical to gelu_erf_poly on the device (where the Horner steps are
+// fused multiply-adds in both). The select is replaced by max(v, 0) - |h| (identical: v - h for v >= 0, 0 - |h| = h for v < 0).
+typedef float gelu_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gelu_f2 gelu_erf_poly2(const gelu_f2 v) {
+    const gelu_f2 z = {fabsf(v.x) * 0.70710678118654752f, fabsf(v.y) * 0.70710678118654752f};
+    gelu_f2 p = {-4.536094274953939e-05f, -4.536094274953939e-05f};
+    p = __builtin_elementwise_fma(p, z, (gelu_f2){0.0004455238813534379f, 0.0004455238813534379f});
+    p = __builtin_elementwise_fma(p, z, (gelu_f2){-0.0014894854975864291f, -0.0014894854975864291f});
+    p = __builtin_elementwise_fma(p, z, (gelu_f2){-0.0007745709153823555f, -0.0007745709153823555f});
+    p = __builtin_elementwise_fma(p, z, (gelu_f2){0.028253639116883278f, 0.028253639116883278f});
+    p = __builtin_elementwise_fma(p, z, (gelu_f2){-0.1484816074371338f, -0.1484816074371338f});
+    p = __builtin_elementwise_fma(p, z, (gelu_f2){-0.9184163808822632f, -0.9184163808822632f});
+    p = __builtin_elementwise_fma(p, z, (gelu_f2){-1.6279085874557495f, -1.6279085874557495f});
+    p = p * z;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const gelu_f2 e = {__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
+#else
+    const gelu_f2 e = {exp2f(p.x), exp2f(p.y)};     // (host pass of hipcc only; never called there)
+#endif
+    const gelu_f2 a = {0.5f * fabsf(v.x), 0.5f * fabsf(v.y)};
+    const gelu_f2 habs = a * e;
+    const gelu_f2 relu = {__builtin_fmaxf(v.x, 0.0f), __builtin_fmaxf(v.y, 0.0f)};
+    return relu - habs;
+}
+#endif
+
 }  // namespace atlas

@@ -396,46 +396,109 @@ gemm_bt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 // so that global memory sees whole 512-byte rows (16 B per lane) instead of the fragment layout's 32-byte pieces, and
 // V^T sees 64 consecutive tokens per store. Rounding points are those of gemm_epilogue (dt(acc + bias) [gelu] is what
 // is parked in LDS; the residual is added on the way out). LDS tile [token][col], 8-byte granules XOR-ed with
-// (token & 15) << 2: conflict-free fragment writes and row reads.
+// (token & 15) << 2: conflict-free fragment writes and row reads. V tiles are parked TRANSPOSED ([col][token], transposed in
+// registers by two DPP exchanges) so that V^T rows leave as 16-byte stores of 8 consecutive keys.
 template <class T, int EPI>
-static __device__ __forceinline__ void gemm_epilogue_lds(f4 (&acc)[8][4], unsigned char* __restrict__ smem, int64_t m0, int n0, int wave,
-                                                         int lane, int64_t M, int N, const uint16_t* __restrict__ bias,
+static __device__ __forceinline__ void gemm_epilogue_lds(f4 (&acc)[8][4], unsigned char* __restrict__ smem,
+                                                         const uint16_t* __restrict__ s_bias /* LDS: bias[n0 .. n0+256) */, int64_t m0, int n0, int wave,
+                                                         int lane, int64_t M, int N,
                                                          const uint16_t* __restrict__ R, uint16_t* __restrict__ C,
                                                          uint16_t* __restrict__ VT, const int* __restrict__ cu,
-                                                         const int2* __restrict__ tokinfo, int Lp) {
+                                                         const int2* __restrict__ tokinfo, int Lp, const int diag = 0) {
     const int wi = wave >> 2, wj = wave & 3, lr = lane & 15, lg = lane >> 4;
+    const bool v_tile = (EPI == 3) && (n0 >= 2 * HID);        // workgroup-uniform: the V columns of the QKV projection
+    // EPI 2: the 16 residual row pieces this lane adds on the way out are requested FIRST, so that their latency runs under the
+    // conversion, the LDS writes and the barrier (in the store loop, four at a time, it was paid four times: ~8 us of a 17 us epilogue)
+    uint4 rv[16];
+    if (EPI == 2) {
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        const int col = wi * 128 + a * 16 + lg * 4;
-        float bv[4];
-        load4<T>(bias + n0 + col, bv);
+        for (int it = 0; it < 16; ++it) {
+            int64_t tok = m0 + wave * 32 + it * 2 + (lane >> 5);
+            if (tok >= M) tok = M - 1;                                                   // clamped: tail rows are never stored
+            rv[it] = (diag & 8) ? make_uint4(0u, 0u, 0u, 0u) : *(const uint4*)(R + (size_t)tok * N + n0 + 8 * (lane & 31));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // V tile: where this lane's 8 consecutive tokens (8j .. 8j+7 of the tile, j = lane & 31) live in V^T; requested before the
+    // conversion as well. One 16-byte store per column needs them in ONE passage at a key offset that is a multiple of 8.
+    int64_t vt_off = 0;            // element offset of token 8j inside a V^T row block: passage * 768 * Lp + key
+    bool vt_fast = false;
+    if (EPI == 3 && v_tile) {
+        const int64_t tok0 = m0 + 8 * (lane & 31);
+        if (tok0 + 7 < M) {
+            const int pb0 = tokinfo[tok0].x, pb7 = tokinfo[tok0 + 7].x;
+            const int pos0 = (int)(tok0 - cu[pb0]);
+            vt_off = (int64_t)pb0 * HID * Lp + pos0;
+            vt_fast = (pb0 == pb7) && ((pos0 & 7) == 0);
+        }
+    }
+    if (!(EPI == 3 && v_tile)) {
+        // LDS tile [token][col]: 512-byte token rows, 8-byte granules XOR-ed with (token & 15) << 2
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int t = wj * 64 + b * 16 + lr;
-            uint16_t o[4];
+        for (int a = 0; a < 8; ++a) {
+            const int col = wi * 128 + a * 16 + lg * 4;
+            float bv[4];
+            load4<T>(s_bias + col, bv);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = T::rnd(acc[a][b][r] + bv[r]);                                 // Linear output in the model dtype
-                if (EPI == 1) v = gelu_erf_poly(v);                                     // erf GELU in fp32 (common.h)
-                o[r] = T::st(v);
+            for (int b = 0; b < 4; ++b) {
+                const int t = wj * 64 + b * 16 + lr;
+                uint16_t o[4];
+                if (EPI == 1) {                                                             // erf GELU in fp32, two values per instruction (common.h)
+                    const gelu_f2 g01 = gelu_erf_poly2((gelu_f2){T::rnd(acc[a][b][0] + bv[0]), T::rnd(acc[a][b][1] + bv[1])});
+                    const gelu_f2 g23 = gelu_erf_poly2((gelu_f2){T::rnd(acc[a][b][2] + bv[2]), T::rnd(acc[a][b][3] + bv[3])});
+                    o[0] = T::st(g01.x); o[1] = T::st(g01.y); o[2] = T::st(g23.x); o[3] = T::st(g23.y);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = T::st(acc[a][b][r] + bv[r]);        // Linear output in the model dtype
+                }
+                const int gr = (col >> 2) ^ ((t & 15) << 2);
+                *(uint2*)(smem + t * 512 + gr * 8) = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
             }
-            const int gr = (col >> 2) ^ ((t & 15) << 2);
-            *(uint2*)(smem + t * 512 + gr * 8) = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+        }
+    } else {
+        // V tile: LDS tile [col][token] (transposed). A lane holds 4 columns of ONE token; two DPP exchanges inside each quad of
+        // lanes (tokens 4q .. 4q+3 of a fragment) turn that into 4 tokens of ONE column = one 8-byte granule:
+        //   after xor 1: lane keeps 2 of its 4 columns (even lane: 0,1; odd lane: 2,3) for the token pair of (lane, lane ^ 1)
+        //   after xor 2: lane keeps 1 of those 2 columns for the 4 tokens of its quad
+        // column of lane lr inside the group of 4: 2 * (lr & 1) + ((lr >> 1) & 1). Granules are XOR-ed with (col & 3) << 2: the 16
+        // lanes of a row group hit 16 different granule slots, the 4 row groups the same ones (4 passes = the minimum for 512 B).
+        const bool odd1 = lane & 1, odd2 = lane & 2;
+        const int ciq = 2 * (lr & 1) + ((lr >> 1) & 1);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            float bv[4];
+            load4<T>(s_bias + wi * 128 + a * 16 + lg * 4, bv);
+            const int colT = wi * 128 + a * 16 + lg * 4 + ciq;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                uint16_t o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = T::st(acc[a][b][r] + bv[r]);             // Linear output in the model dtype
+                const uint32_t p01 = (uint32_t)o[0] | ((uint32_t)o[1] << 16), p23 = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+                const uint32_t keep1 = odd1 ? p23 : p01;
+                const uint32_t recv1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)(odd1 ? p01 : p23), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                const uint32_t ev = odd1 ? recv1 : keep1, od = odd1 ? keep1 : recv1;        // even / odd token of the pair
+                const uint32_t cA = (ev & 0xffffu) | (od << 16), cB = (ev >> 16) | (od & 0xffff0000u);
+                const uint32_t keep2 = odd2 ? cB : cA;
+                const uint32_t recv2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)(odd2 ? cA : cB), 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+                const uint2 g = odd2 ? make_uint2(recv2, keep2) : make_uint2(keep2, recv2);  // tokens 4q, 4q+1 | 4q+2, 4q+3
+                const int gi = wj * 16 + b * 4 + (lr >> 2);
+                *(uint2*)(smem + colT * 512 + ((gi ^ ((colT & 3) << 2)) * 8)) = g;
+            }
         }
     }
     __syncthreads();
-    if (!(EPI == 3 && n0 >= 2 * HID)) {
+    const int j = lane & 31;
+    if (!(EPI == 3 && v_tile)) {
         const int ldc = (EPI == 3) ? 2 * HID : N;
-        const int j = lane & 31;
-#pragma unroll 4
+#pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int t = wave * 32 + it * 2 + (lane >> 5);
             const int64_t tok = m0 + t;
             if (tok >= M) continue;
             uint4 v = *(const uint4*)(smem + t * 512 + (((2 * j) ^ ((t & 15) << 2)) * 8));
             if (EPI == 2) {
-                const uint4 rv = *(const uint4*)(R + (size_t)tok * N + n0 + 8 * j);
-                const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w};
+                const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, rw[4] = {rv[it].x, rv[it].y, rv[it].z, rv[it].w};
                 uint32_t ow[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -445,26 +508,31 @@ static __device__ __forceinline__ void gemm_epilogue_lds(f4 (&acc)[8][4], unsign
                 }
                 v = make_uint4(ow[0], ow[1], ow[2], ow[3]);
             }
-            *(uint4*)(C + (size_t)tok * ldc + n0 + 8 * j) = v;
+            if (!(diag & 4) || v.x == 0x12345678u) *(uint4*)(C + (size_t)tok * ldc + n0 + 8 * j) = v;
         }
     } else {
-        // V columns: V^T[passage][h*64+d][rank in passage] -- lanes run along tokens, so a store covers 64 consecutive keys
-#pragma unroll 1
-        for (int tc = 0; tc < 4; ++tc) {
-            const int t = tc * 64 + lane;
-            const int64_t tok = m0 + t;
-            const bool valid = tok < M;
-            int64_t pb = 0;
-            int pos = 0;
-            if (valid) { pb = tokinfo[tok].x; pos = (int)(tok - cu[pb]); }
-            uint16_t* dst = VT + ((size_t)pb * HID + (n0 - 2 * HID) + wave * 32) * Lp + pos;
-            const unsigned char* src = smem + t * 512;
-            const int sw = (t & 15) << 2;
-#pragma unroll 8
-            for (int c = 0; c < 32; ++c) {
-                const int cc = wave * 32 + c;
-                const uint16_t v = *(const uint16_t*)(src + (((cc >> 2) ^ sw) * 8) + (cc & 3) * 2);
-                if (valid) dst[(size_t)c * Lp] = v;
+        // V^T[passage][h*64+d][rank in passage]: a lane stores 8 consecutive keys of one column (16 B) where the passage layout
+        // allows it; token groups that straddle passages or start at a key offset that is not a multiple of 8 (ragged batches) go
+        // out as single elements
+        const int64_t tok0 = m0 + 8 * j;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int colT = wave * 32 + it * 2 + (lane >> 5);
+            const uint4 v = *(const uint4*)(smem + colT * 512 + (((2 * j) ^ ((colT & 3) << 2)) * 8));
+            const int64_t crow = (int64_t)(n0 - 2 * HID + colT) * Lp;
+            if (diag & 4) { if (v.x != 0x12345678u) continue; }
+            if (vt_fast) {
+                *(uint4*)(VT + vt_off + crow) = v;
+            } else {
+                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int64_t tok = tok0 + e;
+                    if (tok < M) {
+                        const int64_t pb = tokinfo[tok].x;
+                        VT[(pb * HID) * Lp + (tok - cu[pb]) + crow] = (uint16_t)(w4[e >> 1] >> ((e & 1) * 16));
+                    }
+                }
             }
         }
     }
@@ -494,7 +562,8 @@ __global__ void __launch_bounds__(512)
 gemm_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem* __restrict__ W, const typename T::elem* __restrict__ bias,
                const typename T::elem* __restrict__ R, typename T::elem* __restrict__ C, typename T::elem* __restrict__ VT,
                const int* __restrict__ cu, int n, const int2* __restrict__ tokinfo, int N, int K, int Lp,
-               unsigned long long* __restrict__ dbg /* tuning only: cycle stamps of block 0; null in production */) {
+               unsigned long long* __restrict__ dbg /* tuning only: cycle stamps of block 0; null in production */,
+               int diag /* tuning only (ATLAS_GEMM_DIAG): 1 = no epilogue, 2 = no k-loop, 4 = no global stores, 8 = no residual loads; 0 in production */) {
     typedef typename T::elem E;
     constexpr int BCOL = 256, BTOK = 256, WT = 4, FA = 8, FB = 4;
     constexpr int EPC = 16 / (int)sizeof(E);
@@ -514,7 +583,7 @@ gemm_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     const int64_t m0 = ttile * BTOK;
     const int lr = lane & 15, lg = lane >> 4;
 
-    const int nk = K / (8 * EPC);
+    const int nk = (diag & 2) ? 0 : K / (8 * EPC);
     // this wave's DMA pieces: 4 x 8 rows of W and 4 x 8 rows of the activations per k-tile (8 rows x 128 B each,
     // source-side XOR swizzle as in gemm_bt_kernel)
     const int ch = (lane & 7) ^ (lane >> 3);
@@ -550,8 +619,18 @@ gemm_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 #pragma unroll
         for (int b = 0; b < FB; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
 
+    // the tile's 256 bias values are parked in LDS (behind the four stage buffers) for the epilogue: read from global there,
+    // they were the first thing every wave waited for after the k-loop (one cold L2 / HBM latency per tile)
+    uint16_t* s_bias = (uint16_t*)(smem_raw + 4 * STG);
+    uint2 bias_reg = make_uint2(0u, 0u);
+    if constexpr (sizeof(E) == 2) {
+        if (tid < 64) bias_reg = *(const uint2*)(bias + n0 + 4 * tid);
+    }
     stage(0, 0);
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's pieces of tile 0 have landed
+    if constexpr (sizeof(E) == 2) {
+        if (tid < 64) *(uint2*)(s_bias + 4 * tid) = bias_reg;
+    }
     __builtin_amdgcn_s_barrier();
     if (grpB) {                                        // B's phase 0: nothing to multiply yet
         if (nk > 1) stage(1, 1);
@@ -604,8 +683,9 @@ gemm_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     }
 #undef PP_STAMP
     if (!grpB) __builtin_amdgcn_s_barrier();           // A matches B's extra barrier: every wave is past its last LDS read
+    if (diag & 1) { if (acc[0][0][0] == 12345.678f) C[0] = 0; return; }
     if constexpr (sizeof(E) == 2)
-        gemm_epilogue_lds<T, EPI>(acc, smem_raw, m0, n0, wave, lane, M, N, bias, R, C, VT, cu, tokinfo, Lp);
+        gemm_epilogue_lds<T, EPI>(acc, smem_raw, s_bias, m0, n0, wave, lane, M, N, R, C, VT, cu, tokinfo, Lp, diag);
     else
         gemm_epilogue<T, EPI, FA, FB>(acc, m0, n0, wi, wj, lr, lg, M, N, bias, R, C, VT, cu, tokinfo, Lp);
 }
@@ -728,6 +808,7 @@ gemm_ms_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 //   3  gemm_ms_kernel  64 x 64, 3 (16-bit) / 4 (fp32) LDS-DMA stages        (query batches)
 //   5  gemm_bt_kernel  64 x 64, single stage                                (A/B reference for 3)
 unsigned long long* g_gemm_dbg = nullptr;    // tuning hook (atlas_dbg_set_gemm_stamps); never set in production
+int g_gemm_diag = 0;                         // tuning hook (atlas_dbg_set_gemm_diag); never set in production
 
 template <class T, int EPI>
 static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, const typename T::elem* W, const typename T::elem* bias,
@@ -743,8 +824,8 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
     if (cfg == 4) {
         (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         const unsigned mtiles = (unsigned)((Mmax + 255) / 256);
-        hipLaunchKernelGGL((gemm_pp_kernel<T, EPI>), dim3((mtiles + 7) / 8 * 8 * (N / 256)), dim3(512), 128 * 1024, stream, A, W, bias, R, C,
-                           VT, cu, n, tokinfo, N, K, Lp, g_gemm_dbg);
+        hipLaunchKernelGGL((gemm_pp_kernel<T, EPI>), dim3((mtiles + 7) / 8 * 8 * (N / 256)), dim3(512), 128 * 1024 + 512, stream, A, W, bias, R, C,
+                           VT, cu, n, tokinfo, N, K, Lp, g_gemm_dbg, g_gemm_diag);
     }
     else if (cfg == 2) go(gemm_bt_kernel<T, EPI, 256, 256, 2, 4>, 256, 256, 512);
     else if (cfg == 3) {
@@ -1097,6 +1178,7 @@ int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int
 extern "C" {
 
 void atlas_dbg_set_gemm_stamps(unsigned long long* p) { g_gemm_dbg = p; }   // tuning hook, not part of include/atlas_hip.h
+void atlas_dbg_set_gemm_diag(int d) { g_gemm_diag = d; }                     // tuning hook, not part of include/atlas_hip.h
 
 size_t atlas_contriever_workspace_bytes(int n, int L, int dtype) {
     if (n <= 0 || L <= 0) return 0;
