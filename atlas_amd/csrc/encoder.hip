@@ -874,33 +874,64 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
     const uint16_t* Qb = qk + (size_t)tb * (2 * HID) + h * DHEAD;
     const uint16_t* Kb = Qb + HID;
     const uint16_t* Vt = vt + ((size_t)b * HID + h * DHEAD) * LpMax;
+    // the first query fragment of this wave is requested before K / V^T are staged (its latency runs under the staging), the
+    // next one before the current one is computed
+    auto load_q = [&](const int qf, uint4& qa, uint4& qb) {
+        int qrow = qf * 16 + lr; if (qrow >= L) qrow = L - 1;
+        qa = *(const uint4*)(Qb + (size_t)qrow * (2 * HID) + lg * 8);
+        qb = *(const uint4*)(Qb + (size_t)qrow * (2 * HID) + 32 + lg * 8);
+    };
+    uint4 q0n = make_uint4(0, 0, 0, 0), q1n = q0n;
+    if (wave * 16 < L) load_q(wave, q0n, q1n);
     for (int j = tid; j < Lp; j += 256) sMask[j] = (j < L) ? 0.0f : -__builtin_inff();
-    for (int idx = tid; idx < Lp * 8; idx += 256) {
-        const int key = idx >> 3, ch = idx & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (key < L) v = *(const uint4*)(Kb + (size_t)key * (2 * HID) + ch * 8);
-        sK[key * 8 + (ch ^ (key & 7))] = v;
-    }
+    // staging: four 16-byte chunks of K and four of V^T per thread are requested before the first is written to LDS (one chunk per
+    // loop iteration was eight serialised memory latencies per workgroup at L = 128)
     const int cpr = Lp / 8;                                    // 16-B chunks per V^T row
-    for (int idx = tid; idx < 64 * cpr; idx += 256) {
-        const int dim = idx / cpr, c = idx - dim * cpr;
-        uint4 v = *(const uint4*)(Vt + (size_t)dim * LpMax + c * 8);
-        const int left = L - c * 8;                            // columns >= L were never written: force them to 0
-        if (left < 8) {
-            uint32_t wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (e >= left) wv[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
-            v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+    for (int base = 0; base < MAXKF * 16 * 8; base += 4 * 256) {     // compile-time trip count (Lp <= MAXKF * 16): no loop-entry drain
+        if (base >= Lp * 8) break;
+        uint4 kv[4], vv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = base + i * 256 + tid;
+            const int key = idx >> 3, ch = idx & 7;
+            kv[i] = *(const uint4*)(Kb + (size_t)(key < L ? key : L - 1) * (2 * HID) + ch * 8);   // unconditional (clamped): no branch, all in flight
         }
-        *(uint4*)(sVt + dim * vstride + c * 8) = v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = base + i * 256 + tid;              // V^T has 64 * cpr = Lp * 8 chunks as well
+            const int idc = idx < Lp * 8 ? idx : Lp * 8 - 1;
+            const int dim = idc / cpr, c = idc - dim * cpr;
+            vv[i] = *(const uint4*)(Vt + (size_t)dim * LpMax + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = base + i * 256 + tid;
+            const int key = idx >> 3, ch = idx & 7;
+            if (idx < Lp * 8) sK[key * 8 + (ch ^ (key & 7))] = (key < L) ? kv[i] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = base + i * 256 + tid;
+            if (idx >= Lp * 8) continue;
+            const int dim = idx / cpr, c = idx - dim * cpr;
+            uint4 v = vv[i];
+            const int left = L - c * 8;                        // columns >= L were never written: force them to 0
+            if (left < 8) {
+                uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (e >= left) wv[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+                v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+            }
+            *(uint4*)(sVt + dim * vstride + c * 8) = v;
+        }
     }
     __syncthreads();
     const int nkf = Lp / 16;
     for (int qf = wave; qf * 16 < L; qf += 4) {
-        int qrow = qf * 16 + lr; if (qrow >= L) qrow = L - 1;
-        const uint4 q0 = *(const uint4*)(Qb + (size_t)qrow * (2 * HID) + lg * 8);
-        const uint4 q1 = *(const uint4*)(Qb + (size_t)qrow * (2 * HID) + 32 + lg * 8);
+        const uint4 q0 = q0n, q1 = q1n;
+        if ((qf + 4) * 16 < L) load_q(qf + 4, q0n, q1n);
         f4 s[MAXKF];
 #pragma unroll
         for (int kf = 0; kf < MAXKF; ++kf) {
