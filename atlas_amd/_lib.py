@@ -9,7 +9,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_SO = os.path.join(HERE, "lib", "libatlas_hip.so")
+HIP_SO = os.environ.get("ATLAS_HIP_SO") or os.path.join(HERE, "lib", "libatlas_hip.so")   # ATLAS_HIP_SO: A/B runs of two builds (dev)
 
 ABI_VERSION = 4
 DT_F16, DT_F32, DT_BF16 = 0, 1, 2

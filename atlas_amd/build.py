@@ -39,7 +39,10 @@ def build_hip(force=False, verbose=False):
     if force or _newer(HIP_SO, srcs + extra):
         hip_srcs = sorted(f for f in extra if f.endswith(".hip"))
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-               "-Wall", "-Wno-unused-function", *hip_srcs, "-o", HIP_SO]
+               "-Wall", "-Wno-unused-function",
+               # MFMA results stay in architectural VGPRs: the epilogues / softmax work on them with VALU, and hipcc's default
+               # AGPR form paid one v_accvgpr_read per element (6 700 of them across encoder.hip)
+               "-mllvm", "-amdgpu-mfma-vgpr-form=1", *hip_srcs, "-o", HIP_SO]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -31,6 +31,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 #include "../../include/atlas_hip.h"
@@ -404,7 +405,7 @@ static __device__ __forceinline__ void gemm_epilogue_lds(f4 (&acc)[8][4], unsign
                                                          int lane, int64_t M, int N,
                                                          const uint16_t* __restrict__ R, uint16_t* __restrict__ C,
                                                          uint16_t* __restrict__ VT, const int* __restrict__ cu,
-                                                         const int2* __restrict__ tokinfo, int Lp, const int diag = 0) {
+                                                         const int2* __restrict__ tokinfo, int Lp) {
     const int wi = wave >> 2, wj = wave & 3, lr = lane & 15, lg = lane >> 4;
     const bool v_tile = (EPI == 3) && (n0 >= 2 * HID);        // workgroup-uniform: the V columns of the QKV projection
     // EPI 2: the 16 residual row pieces this lane adds on the way out are requested FIRST, so that their latency runs under the
@@ -415,7 +416,7 @@ static __device__ __forceinline__ void gemm_epilogue_lds(f4 (&acc)[8][4], unsign
         for (int it = 0; it < 16; ++it) {
             int64_t tok = m0 + wave * 32 + it * 2 + (lane >> 5);
             if (tok >= M) tok = M - 1;                                                   // clamped: tail rows are never stored
-            rv[it] = (diag & 8) ? make_uint4(0u, 0u, 0u, 0u) : *(const uint4*)(R + (size_t)tok * N + n0 + 8 * (lane & 31));
+            rv[it] = *(const uint4*)(R + (size_t)tok * N + n0 + 8 * (lane & 31));
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -508,7 +509,7 @@ static __device__ __forceinline__ void gemm_epilogue_lds(f4 (&acc)[8][4], unsign
                 }
                 v = make_uint4(ow[0], ow[1], ow[2], ow[3]);
             }
-            if (!(diag & 4) || v.x == 0x12345678u) *(uint4*)(C + (size_t)tok * ldc + n0 + 8 * j) = v;
+            *(uint4*)(C + (size_t)tok * ldc + n0 + 8 * j) = v;
         }
     } else {
         // V^T[passage][h*64+d][rank in passage]: a lane stores 8 consecutive keys of one column (16 B) where the passage layout
@@ -520,7 +521,6 @@ static __device__ __forceinline__ void gemm_epilogue_lds(f4 (&acc)[8][4], unsign
             const int colT = wave * 32 + it * 2 + (lane >> 5);
             const uint4 v = *(const uint4*)(smem + colT * 512 + (((2 * j) ^ ((colT & 3) << 2)) * 8));
             const int64_t crow = (int64_t)(n0 - 2 * HID + colT) * Lp;
-            if (diag & 4) { if (v.x != 0x12345678u) continue; }
             if (vt_fast) {
                 *(uint4*)(VT + vt_off + crow) = v;
             } else {
@@ -563,7 +563,7 @@ gemm_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
                const typename T::elem* __restrict__ R, typename T::elem* __restrict__ C, typename T::elem* __restrict__ VT,
                const int* __restrict__ cu, int n, const int2* __restrict__ tokinfo, int N, int K, int Lp,
                unsigned long long* __restrict__ dbg /* tuning only: cycle stamps of block 0; null in production */,
-               int diag /* tuning only (ATLAS_GEMM_DIAG): 1 = no epilogue, 2 = no k-loop, 4 = no global stores, 8 = no residual loads; 0 in production */) {
+               int diag /* tuning only (ATLAS_GEMM_DIAG): 1 = no epilogue, 2 = no k-loop; 0 in production */) {
     typedef typename T::elem E;
     constexpr int BCOL = 256, BTOK = 256, WT = 4, FA = 8, FB = 4;
     constexpr int EPC = 16 / (int)sizeof(E);
@@ -638,6 +638,7 @@ gemm_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     }
     const bool stamp = dbg != nullptr && blockIdx.x == 0 && lane == 0;
 #define PP_STAMP(i) do { if (stamp && kt < 16) dbg[(wave * 16 + kt) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+    if (stamp && wave == 0) { dbg[1024] = __builtin_readcyclecounter(); dbg[1025] = wall_clock64(); }   // shader clock vs 100 MHz clock over the k-loop
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         PP_STAMP(0);
@@ -682,10 +683,11 @@ gemm_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         PP_STAMP(7);
     }
 #undef PP_STAMP
+    if (stamp && wave == 0) { dbg[1026] = __builtin_readcyclecounter(); dbg[1027] = wall_clock64(); dbg[1028] = (unsigned long long)nk; }
     if (!grpB) __builtin_amdgcn_s_barrier();           // A matches B's extra barrier: every wave is past its last LDS read
     if (diag & 1) { if (acc[0][0][0] == 12345.678f) C[0] = 0; return; }
     if constexpr (sizeof(E) == 2)
-        gemm_epilogue_lds<T, EPI>(acc, smem_raw, s_bias, m0, n0, wave, lane, M, N, R, C, VT, cu, tokinfo, Lp, diag);
+        gemm_epilogue_lds<T, EPI>(acc, smem_raw, s_bias, m0, n0, wave, lane, M, N, R, C, VT, cu, tokinfo, Lp);
     else
         gemm_epilogue<T, EPI, FA, FB>(acc, m0, n0, wi, wj, lr, lg, M, N, bias, R, C, VT, cu, tokinfo, Lp);
 }
@@ -929,14 +931,16 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
     }
     __syncthreads();
     const int nkf = Lp / 16;
-    for (int qf = wave; qf * 16 < L; qf += 4) {
-        const uint4 q0 = q0n, q1 = q1n;
-        if ((qf + 4) * 16 < L) load_q(qf + 4, q0n, q1n);
+    // One query fragment (16 queries x all keys). FULL: every one of the MAXKF key fragments exists and holds real keys only
+    // (L = MAXKF * 16, e.g. 128-token passages): no guards, no mask. Both variants do the same arithmetic per element, so a
+    // passage gives the same bits whichever one serves it (the batch's padded length picks MAXKF).
+    auto fragment = [&](const int qf, const uint4 q0, const uint4 q1, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         f4 s[MAXKF];
 #pragma unroll
         for (int kf = 0; kf < MAXKF; ++kf) {
             s[kf] = (f4){0.f, 0.f, 0.f, 0.f};
-            if (kf < nkf) {
+            if (FULL || kf < nkf) {
                 const int krow = kf * 16 + lr;
                 const uint4 k0 = sK[krow * 8 + (lg ^ (krow & 7))];
                 const uint4 k1 = sK[krow * 8 + ((4 + lg) ^ (krow & 7))];
@@ -944,50 +948,108 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
                 s[kf] = T::mma(k1, q1, s[kf]);
             }
         }
-        float mx = -__builtin_inff();
+        uint32_t pk[MAXKF][2];                                      // softmax(...).type_as(model dtype), two keys per word
+        if constexpr (T::DT == ATLAS_DT_F16) {
+            // fp16 model: the three model-dtype steps (dt(q.k), / sqrt(64) -- exact --, + mask) run on PACKED halves
+            // (v_cvt_pk_f16_f32, v_pk_mul_f16, v_pk_add_f16, v_pk_max_f16); the softmax itself is fp32 as in the reference
+            // (modeling_bert.py:352): e = 2^(v * log2 e - max * log2 e), one mixed-precision fma + v_exp_f32 per key
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            h2 v[MAXKF][2];
+            h2 mx2 = {(_Float16)(-__builtin_inff()), (_Float16)(-__builtin_inff())};
 #pragma unroll
-        for (int kf = 0; kf < MAXKF; ++kf)
-            if (kf < nkf) {
-                const float4 am = *(const float4*)(sMask + kf * 16 + lg * 4);
-                const float a4[4] = {am.x, am.y, am.z, am.w};
+            for (int kf = 0; kf < MAXKF; ++kf)
+                if (FULL || kf < nkf) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    // dt(q.k) / sqrt(64) is exact in fp16/bf16; + mask is an add in the model dtype (modeling_bert.py:346-349)
-                    const float v = T::rnd(T::rnd(s[kf][r]) * 0.125f + a4[r]);
-                    s[kf][r] = v;
-                    mx = fmaxf(mx, v);
+                    for (int e = 0; e < 2; ++e) {
+                        h2 x = {(_Float16)s[kf][2 * e], (_Float16)s[kf][2 * e + 1]};
+                        x = x * (h2){(_Float16)0.125f, (_Float16)0.125f};
+                        if (!FULL) {
+                            const float2 am = *(const float2*)(sMask + kf * 16 + lg * 4 + 2 * e);
+                            x = x + (h2){(_Float16)am.x, (_Float16)am.y};
+                        }
+                        v[kf][e] = x;
+                        mx2 = __builtin_elementwise_max(mx2, x);
+                    }
                 }
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.f;
+            float mx = fmaxf((float)mx2.x, (float)mx2.y);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float nmx = -mx * 1.4426950408889634f;
+            f2 ex[MAXKF][2];
+            f2 sum2 = {0.f, 0.f};
 #pragma unroll
-        for (int kf = 0; kf < MAXKF; ++kf)
-            if (kf < nkf) {
+            for (int kf = 0; kf < MAXKF; ++kf)
+                if (FULL || kf < nkf) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __expf(s[kf][r] - mx);            // exp(-inf) = 0 for padded keys
-                    s[kf][r] = e;
-                    sum += e;
+                    for (int e = 0; e < 2; ++e) {
+                        const f2 ee = {__builtin_amdgcn_exp2f(__builtin_fmaf((float)v[kf][e].x, 1.4426950408889634f, nmx)),
+                                       __builtin_amdgcn_exp2f(__builtin_fmaf((float)v[kf][e].y, 1.4426950408889634f, nmx))};   // 2^-inf = 0 for padded keys
+                        ex[kf][e] = ee;
+                        sum2 += ee;
+                    }
                 }
-            }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        const float inv = 1.0f / sum;
+            float sum = sum2.x + sum2.y;
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int kf = 0; kf < MAXKF; ++kf)
+                if (FULL || kf < nkf) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const f2 pe = ex[kf][e] * (f2){inv, inv};
+                        const h2 ph = {(_Float16)pe.x, (_Float16)pe.y};
+                        pk[kf][e] = __builtin_bit_cast(uint32_t, ph);
+                    }
+                }
+        } else {
+            float mx = -__builtin_inff();
+#pragma unroll
+            for (int kf = 0; kf < MAXKF; ++kf)
+                if (FULL || kf < nkf) {
+                    const float4 am = *(const float4*)(sMask + kf * 16 + lg * 4);
+                    const float a4[4] = {am.x, am.y, am.z, am.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // dt(q.k) / sqrt(64) is exact in fp16/bf16; + mask is an add in the model dtype (modeling_bert.py:346-349)
+                        const float v = T::rnd(T::rnd(s[kf][r]) * 0.125f + a4[r]);
+                        s[kf][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int kf = 0; kf < MAXKF; ++kf)
+                if (FULL || kf < nkf) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __expf(s[kf][r] - mx);            // exp(-inf) = 0 for padded keys
+                        s[kf][r] = e;
+                        sum += e;
+                    }
+                }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int kf = 0; kf < MAXKF; ++kf)
+                if (FULL || kf < nkf) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        pk[kf][e] = (uint32_t)T::st(s[kf][2 * e] * inv) | ((uint32_t)T::st(s[kf][2 * e + 1] * inv) << 16);
+                }
+        }
         // ctx = P V, P straight from the registers above
         f4 o[4];
 #pragma unroll
         for (int df = 0; df < 4; ++df) o[df] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < MAXKF / 2; ++ks)
-            if (2 * ks < nkf) {
-                uint32_t pw[4];                                         // softmax(...).type_as(model dtype)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    pw[e] = (uint32_t)T::st(s[2 * ks][2 * e] * inv) | ((uint32_t)T::st(s[2 * ks][2 * e + 1] * inv) << 16);
-                    pw[2 + e] = (uint32_t)T::st(s[2 * ks + 1][2 * e] * inv) | ((uint32_t)T::st(s[2 * ks + 1][2 * e + 1] * inv) << 16);
-                }
-                const uint4 pa = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+            if (FULL || 2 * ks < nkf) {
+                const uint4 pa = make_uint4(pk[2 * ks][0], pk[2 * ks][1], pk[2 * ks + 1][0], pk[2 * ks + 1][1]);
 #pragma unroll
                 for (int df = 0; df < 4; ++df) {
                     const uint16_t* vrow = sVt + (df * 16 + lr) * vstride + ks * 32 + lg * 4;
@@ -1001,8 +1063,15 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = qf * 16 + lg * 4 + r;
-                if (row < L) ctx[((size_t)tb + row) * HID + h * DHEAD + df * 16 + lr] = T::st(o[df][r]);
+                if (FULL || row < L) ctx[((size_t)tb + row) * HID + h * DHEAD + df * 16 + lr] = T::st(o[df][r]);
             }
+    };
+    const bool full = (L == MAXKF * 16);                         // workgroup-uniform
+    for (int qf = wave; qf * 16 < L; qf += 4) {
+        const uint4 q0 = q0n, q1 = q1n;
+        if ((qf + 4) * 16 < L) load_q(qf + 4, q0n, q1n);
+        if (full) fragment(qf, q0, q1, std::true_type{});
+        else fragment(qf, q0, q1, std::false_type{});
     }
 }
 

@@ -12,11 +12,14 @@ ids = torch.randint(1000, 30522, (512, 128), generator=g).cuda()
 mask = torch.ones((512, 128), dtype=torch.int64).cuda()
 out = torch.empty((512, 768), dtype=torch.float16, device="cuda")
 m.embed_into(out, ids, mask); torch.cuda.synchronize()
-dbg = torch.zeros(8 * 16 * 8, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(8 * 16 * 8 + 16, dtype=torch.int64, device="cuda")
 L.atlas_dbg_set_gemm_stamps(dbg.data_ptr())
 m.embed_into(out, ids, mask); torch.cuda.synchronize()        # last GEMM = FF2 (K = 3072, 48 k-tiles; first 16 stamped)
 L.atlas_dbg_set_gemm_stamps(None)
-t = dbg.cpu().view(8, 16, 8)
+tail = dbg.cpu()[1024:1029].tolist()
+sc, rc, nk = tail[2] - tail[0], tail[3] - tail[1], tail[4]
+print("k-loop of block 0: %d k-tiles, %d shader cycles in %.2f us (100 MHz clock) -> %.0f MHz, %.0f cycles = %.3f us per k-tile (stamps on)" % (nk, sc, rc / 100.0, sc / rc * 100.0, sc / nk, rc / 100.0 / nk))
+t = dbg.cpu()[:1024].view(8, 16, 8)
 t0 = int(t[:, 0, 0].min())
 names = ["-", "reads", "dmaA/vmwB", "bar1", "dmaB", "mfma", "vmwA", "bar2"][1:]
 for w in (0, 1, 4, 5):
