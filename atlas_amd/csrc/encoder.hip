@@ -423,14 +423,23 @@ static __device__ __forceinline__ void gemm_epilogue_lds(f4 (&acc)[8][4], unsign
     // V tile: where this lane's 8 consecutive tokens (8j .. 8j+7 of the tile, j = lane & 31) live in V^T; requested before the
     // conversion as well. One 16-byte store per column needs them in ONE passage at a key offset that is a multiple of 8.
     int64_t vt_off = 0;            // element offset of token 8j inside a V^T row block: passage * 768 * Lp + key
-    bool vt_fast = false;
+    int vt_mode = 3;               // 0: one 16-byte store | 1: four 4-byte stores (key offset even) | 2: 2 + 3 x 4 + 2 bytes (odd) | 3: per element
+    int64_t vt_off8[8];            // mode 3 only (groups that straddle passages / the end of the batch): per-token offsets, -1 = no token
     if (EPI == 3 && v_tile) {
         const int64_t tok0 = m0 + 8 * (lane & 31);
         if (tok0 + 7 < M) {
             const int pb0 = tokinfo[tok0].x, pb7 = tokinfo[tok0 + 7].x;
             const int pos0 = (int)(tok0 - cu[pb0]);
             vt_off = (int64_t)pb0 * HID * Lp + pos0;
-            vt_fast = (pb0 == pb7) && ((pos0 & 7) == 0);
+            if (pb0 == pb7) vt_mode = ((pos0 & 7) == 0) ? 0 : ((pos0 & 1) == 0) ? 1 : 2;
+        }
+        if (vt_mode == 3) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int64_t tok = tok0 + e;
+                vt_off8[e] = -1;
+                if (tok < M) { const int64_t pb = tokinfo[tok].x; vt_off8[e] = pb * HID * Lp + (tok - cu[pb]); }
+            }
         }
     }
     if (!(EPI == 3 && v_tile)) {
@@ -515,24 +524,27 @@ static __device__ __forceinline__ void gemm_epilogue_lds(f4 (&acc)[8][4], unsign
         // V^T[passage][h*64+d][rank in passage]: a lane stores 8 consecutive keys of one column (16 B) where the passage layout
         // allows it; token groups that straddle passages or start at a key offset that is not a multiple of 8 (ragged batches) go
         // out as single elements
-        const int64_t tok0 = m0 + 8 * j;
 #pragma unroll 4
         for (int it = 0; it < 16; ++it) {
             const int colT = wave * 32 + it * 2 + (lane >> 5);
             const uint4 v = *(const uint4*)(smem + colT * 512 + (((2 * j) ^ ((colT & 3) << 2)) * 8));
             const int64_t crow = (int64_t)(n0 - 2 * HID + colT) * Lp;
-            if (vt_fast) {
-                *(uint4*)(VT + vt_off + crow) = v;
+            uint16_t* dst = VT + vt_off + crow;
+            if (vt_mode == 0) {
+                *(uint4*)dst = v;
+            } else if (vt_mode == 1) {                       // ragged batch, even key offset: 4-byte aligned
+                ((uint32_t*)dst)[0] = v.x; ((uint32_t*)dst)[1] = v.y; ((uint32_t*)dst)[2] = v.z; ((uint32_t*)dst)[3] = v.w;
+            } else if (vt_mode == 2) {                       // odd key offset: the inner six keys as three aligned words
+                dst[0] = (uint16_t)v.x;
+                ((uint32_t*)(dst + 1))[0] = (v.x >> 16) | (v.y << 16);
+                ((uint32_t*)(dst + 1))[1] = (v.y >> 16) | (v.z << 16);
+                ((uint32_t*)(dst + 1))[2] = (v.z >> 16) | (v.w << 16);
+                dst[7] = (uint16_t)(v.w >> 16);
             } else {
                 const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int64_t tok = tok0 + e;
-                    if (tok < M) {
-                        const int64_t pb = tokinfo[tok].x;
-                        VT[(pb * HID) * Lp + (tok - cu[pb]) + crow] = (uint16_t)(w4[e >> 1] >> ((e & 1) * 16));
-                    }
-                }
+                for (int e = 0; e < 8; ++e)
+                    if (vt_off8[e] >= 0) VT[vt_off8[e] + crow] = (uint16_t)(w4[e >> 1] >> ((e & 1) * 16));
             }
         }
     }
