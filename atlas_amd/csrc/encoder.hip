@@ -399,14 +399,19 @@ gemm_bt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 // is parked in LDS; the residual is added on the way out). LDS tile [token][col], 8-byte granules XOR-ed with
 // (token & 15) << 2: conflict-free fragment writes and row reads. V tiles are parked TRANSPOSED ([col][token], transposed in
 // registers by two DPP exchanges) so that V^T rows leave as 16-byte stores of 8 consecutive keys.
-template <class T, int EPI>
+// BTOK = token rows of the tile: 256 (8 waves, gemm_pp_kernel) or 128 (4 waves, gemm_co_kernel); 256 columns either way
+template <class T, int EPI, int BTOK = 256>
 static __device__ __forceinline__ void gemm_epilogue_lds(f4 (&acc)[8][4], unsigned char* __restrict__ smem,
                                                          const uint16_t* __restrict__ s_bias /* LDS: bias[n0 .. n0+256) */, int64_t m0, int n0, int wave,
                                                          int lane, int64_t M, int N,
                                                          const uint16_t* __restrict__ R, uint16_t* __restrict__ C,
                                                          uint16_t* __restrict__ VT, const int* __restrict__ cu,
                                                          const int2* __restrict__ tokinfo, int Lp) {
-    const int wi = wave >> 2, wj = wave & 3, lr = lane & 15, lg = lane >> 4;
+    constexpr int WT = BTOK / 64;                               // waves along the tokens (wave tile = 128 columns x 64 tokens)
+    constexpr int OCT = BTOK / 8;                               // token octets per tile row of the transposed (V) layout
+    constexpr int CPI = 64 / OCT;                               // V columns per wave instruction
+    constexpr int CW = 256 / (BTOK / 32);                       // V columns per wave
+    const int wi = wave / WT, wj = wave % WT, lr = lane & 15, lg = lane >> 4;
     const bool v_tile = (EPI == 3) && (n0 >= 2 * HID);        // workgroup-uniform: the V columns of the QKV projection
     // EPI 2: the 16 residual row pieces this lane adds on the way out are requested FIRST, so that their latency runs under the
     // conversion, the LDS writes and the barrier (in the store loop, four at a time, it was paid four times: ~8 us of a 17 us epilogue)
@@ -426,7 +431,7 @@ static __device__ __forceinline__ void gemm_epilogue_lds(f4 (&acc)[8][4], unsign
     int vt_mode = 3;               // 0: one 16-byte store | 1: four 4-byte stores (key offset even) | 2: 2 + 3 x 4 + 2 bytes (odd) | 3: per element
     int64_t vt_off8[8];            // mode 3 only (groups that straddle passages / the end of the batch): per-token offsets, -1 = no token
     if (EPI == 3 && v_tile) {
-        const int64_t tok0 = m0 + 8 * (lane & 31);
+        const int64_t tok0 = m0 + 8 * (lane % OCT);
         if (tok0 + 7 < M) {
             const int pb0 = tokinfo[tok0].x, pb7 = tokinfo[tok0 + 7].x;
             const int pos0 = (int)(tok0 - cu[pb0]);
@@ -493,13 +498,13 @@ static __device__ __forceinline__ void gemm_epilogue_lds(f4 (&acc)[8][4], unsign
                 const uint32_t recv2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)(odd2 ? cA : cB), 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
                 const uint2 g = odd2 ? make_uint2(recv2, keep2) : make_uint2(keep2, recv2);  // tokens 4q, 4q+1 | 4q+2, 4q+3
                 const int gi = wj * 16 + b * 4 + (lr >> 2);
-                *(uint2*)(smem + colT * 512 + ((gi ^ ((colT & 3) << 2)) * 8)) = g;
+                *(uint2*)(smem + colT * (BTOK * 2) + ((gi ^ ((colT & 3) << 2)) * 8)) = g;
             }
         }
     }
     __syncthreads();
-    const int j = lane & 31;
     if (!(EPI == 3 && v_tile)) {
+        const int j = lane & 31;
         const int ldc = (EPI == 3) ? 2 * HID : N;
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
@@ -526,8 +531,9 @@ static __device__ __forceinline__ void gemm_epilogue_lds(f4 (&acc)[8][4], unsign
         // out as single elements
 #pragma unroll 4
         for (int it = 0; it < 16; ++it) {
-            const int colT = wave * 32 + it * 2 + (lane >> 5);
-            const uint4 v = *(const uint4*)(smem + colT * 512 + (((2 * j) ^ ((colT & 3) << 2)) * 8));
+            const int colT = wave * CW + it * CPI + lane / OCT;
+            const int j = lane % OCT;
+            const uint4 v = *(const uint4*)(smem + colT * (BTOK * 2) + (((2 * j) ^ ((colT & 3) << 2)) * 8));
             const int64_t crow = (int64_t)(n0 - 2 * HID + colT) * Lp;
             uint16_t* dst = VT + vt_off + crow;
             if (vt_mode == 0) {
@@ -705,6 +711,109 @@ gemm_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 }
 
 // ------------------------------------------------------------------------------------------
+// The bulk GEMM as TWO co-resident workgroups per CU (gemm_co_kernel): 256 columns x 128 tokens per workgroup, 4 waves (one per
+// SIMD, wave tile 128 x 64 as in gemm_pp_kernel), ONE 48 KiB LDS stage: all 24 fragments of a k-tile are read into registers,
+// then the stage is refilled by LDS-DMA under the 64 MFMAs. A workgroup alone stalls on the landing time of its pieces; the
+// second workgroup of the CU (own stage, own two barriers per k-tile) fills those gaps with its MFMAs. 64 KiB of LDS per
+// workgroup (the epilogue's [128 tokens][256 columns] tile) and <= 256 registers keep two resident. Same k order per element
+// as every other configuration: identical bits.
+// Measured in the same run against gemm_pp_kernel (profiles/r01/gemm_fixed_cost.txt): QKV 253 vs 253 us, out-proj 102 vs 102,
+// FFN-1 377 vs 394, FFN-2 297 vs 293 -> it serves FFN-1 (12 column tiles: most W reuse per activation tile). The hope that one
+// workgroup's epilogue would hide under the other's k-loop did not come true: the two stay in lock-step; starting the second
+// one half a tile late (first dispatch round, HW_ID wave slot parity) or giving the slots different s_setprio changed nothing.
+// ------------------------------------------------------------------------------------------
+template <class T, int EPI>
+__global__ void __launch_bounds__(256, 2)
+gemm_co_kernel(const typename T::elem* __restrict__ A, const typename T::elem* __restrict__ W, const typename T::elem* __restrict__ bias,
+               const typename T::elem* __restrict__ R, typename T::elem* __restrict__ C, typename T::elem* __restrict__ VT,
+               const int* __restrict__ cu, int n, const int2* __restrict__ tokinfo, int N, int K, int Lp, int diag /* tuning only: 1 = no epilogue */) {
+    typedef typename T::elem E;
+    static_assert(sizeof(E) == 2, "16-bit dtypes only");
+    constexpr int BCOL = 256, BTOK = 128, FA = 8, FB = 4;
+    constexpr int EPC = 8;
+    constexpr uint32_t AOFF = 256 * 128;                             // W rows | activation rows
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int64_t M = cu[n];
+    const int ncol = N / BCOL;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int ctile = jj % ncol;
+    const int64_t ttile = (int64_t)(jj / ncol) * 8 + xcd;
+    if (ttile * BTOK >= M) return;
+    const int n0 = ctile * BCOL;
+    const int64_t m0 = ttile * BTOK;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int nk = K / (8 * EPC);
+    const int ch = (lane & 7) ^ (lane >> 3);
+    const E* gw = W + (size_t)(n0 + wave * 64 + (lane >> 3)) * K + ch * EPC;       // piece i: + i * 8 rows
+    const E* ga[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int64_t ar = m0 + wave * 32 + i * 8 + (lane >> 3);
+        if (ar >= M) ar = M - 1;
+        ga[i] = A + (size_t)ar * K + ch * EPC;
+    }
+    auto stage = [&](const int kt) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + (size_t)i * 8 * K + kt * (8 * EPC)),
+                                             (__attribute__((address_space(3))) void*)(smem_raw + (wave * 64 + i * 8) * 128), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + kt * (8 * EPC)),
+                                             (__attribute__((address_space(3))) void*)(smem_raw + AOFF + (wave * 32 + i * 8) * 128), 16, 0, 0);
+    };
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+    const uint32_t w0 = lds0 + (wi * 128 + lr) * 128 + ((0 + lg) ^ (lr & 7)) * 16;
+    const uint32_t w1 = lds0 + (wi * 128 + lr) * 128 + ((4 + lg) ^ (lr & 7)) * 16;
+    const uint32_t a0 = lds0 + AOFF + (wj * 64 + lr) * 128 + ((0 + lg) ^ (lr & 7)) * 16;
+    const uint32_t a1 = lds0 + AOFF + (wj * 64 + lr) * 128 + ((4 + lg) ^ (lr & 7)) * 16;
+
+    f4 acc[FA][FB];
+#pragma unroll
+    for (int a = 0; a < FA; ++a)
+#pragma unroll
+        for (int b = 0; b < FB; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    uint16_t* s_bias = (uint16_t*)(smem_raw + 64 * 1024);
+    uint2 bias_reg = make_uint2(0u, 0u);
+    if (tid < 64) bias_reg = *(const uint2*)(bias + n0 + 4 * tid);
+    stage(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's pieces of tile kt have landed
+        if (kt == 0 && tid < 64) *(uint2*)(s_bias + 4 * tid) = bias_reg;
+        __builtin_amdgcn_s_barrier();                  // ... everybody's
+        u4v fw0[FA], fa0[FB], fw1[FA], fa1[FB];
+        asm volatile(
+            "ds_read_b128 %0, %24\n ds_read_b128 %1, %24 offset:2048\n ds_read_b128 %2, %24 offset:4096\n ds_read_b128 %3, %24 offset:6144\n"
+            "ds_read_b128 %4, %24 offset:8192\n ds_read_b128 %5, %24 offset:10240\n ds_read_b128 %6, %24 offset:12288\n ds_read_b128 %7, %24 offset:14336\n"
+            "ds_read_b128 %8, %25\n ds_read_b128 %9, %25 offset:2048\n ds_read_b128 %10, %25 offset:4096\n ds_read_b128 %11, %25 offset:6144\n"
+            "ds_read_b128 %12, %26\n ds_read_b128 %13, %26 offset:2048\n ds_read_b128 %14, %26 offset:4096\n ds_read_b128 %15, %26 offset:6144\n"
+            "ds_read_b128 %16, %26 offset:8192\n ds_read_b128 %17, %26 offset:10240\n ds_read_b128 %18, %26 offset:12288\n ds_read_b128 %19, %26 offset:14336\n"
+            "ds_read_b128 %20, %27\n ds_read_b128 %21, %27 offset:2048\n ds_read_b128 %22, %27 offset:4096\n ds_read_b128 %23, %27 offset:6144\n"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(fw0[0]), "=&v"(fw0[1]), "=&v"(fw0[2]), "=&v"(fw0[3]), "=&v"(fw0[4]), "=&v"(fw0[5]), "=&v"(fw0[6]), "=&v"(fw0[7]),
+              "=&v"(fa0[0]), "=&v"(fa0[1]), "=&v"(fa0[2]), "=&v"(fa0[3]),
+              "=&v"(fw1[0]), "=&v"(fw1[1]), "=&v"(fw1[2]), "=&v"(fw1[3]), "=&v"(fw1[4]), "=&v"(fw1[5]), "=&v"(fw1[6]), "=&v"(fw1[7]),
+              "=&v"(fa1[0]), "=&v"(fa1[1]), "=&v"(fa1[2]), "=&v"(fa1[3])
+            : "v"(w0), "v"(a0), "v"(w1), "v"(a1)
+            : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                  // every wave holds its fragments: the stage may be overwritten
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) stage(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile<T, FA, FB>(fw0, fa0, acc);
+        mma_tile<T, FA, FB>(fw1, fa1, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (diag & 1) { if (acc[0][0][0] == 12345.678f) C[0] = 0; return; }
+    gemm_epilogue_lds<T, EPI, BTOK>(acc, smem_raw, s_bias, m0, n0, wave, lane, M, N, R, C, VT, cu, tokinfo, Lp);
+}
+
+// ------------------------------------------------------------------------------------------
 // The GEMM for SMALL batches (query embedding: tens of tokens per query after packing, <= 4096 token slots): 64 x 64
 // tiles so that a 768-wide GEMM of 1 300 tokens still makes ~250 workgroups, and a DEEP LDS-DMA pipeline. With tiles
 // this small the MFMAs of a k-tile take 130 (16-bit) to 1 000 (fp32) cycles while an LDS-DMA piece needs ~2 000 cycles
@@ -816,7 +925,9 @@ gemm_ms_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 
 // GEMM configurations. The encoder picks by worst-case token slots n * L: > 16384 -> 4, > 4096 -> 0, else 3;
 // ATLAS_GEMM_CFG=<n> forces one (tuning and the bit-equality test: every configuration gives the same bits).
-//   4  gemm_pp_kernel  256 x 256, ping-pong schedule, LDS epilogue          (index refresh)
+//   4  gemm_pp_kernel  256 x 256, ping-pong schedule, LDS epilogue          (index refresh; FFN-1 of the 16-bit dtypes goes to 6)
+//   6  gemm_co_kernel  256 x 128, two co-resident workgroups per CU         (16-bit dtypes; every GEMM when forced)
+//   7  gemm_pp_kernel  for every GEMM                                        (A/B reference for the 4 / 6 split)
 //   2  gemm_bt_kernel  256 x 256, single phase                              (A/B reference for 4)
 //   0  gemm_bt_kernel  128 x 128
 //   3  gemm_ms_kernel  64 x 64, 3 (16-bit) / 4 (fp32) LDS-DMA stages        (query batches)
@@ -835,11 +946,21 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
         hipLaunchKernelGGL(kern, dim3((mtiles + 7) / 8 * 8 * (N / bcol)), dim3(nthreads), lds, stream, A, W, bias, R, C, VT,
                            cu, n, tokinfo, N, K, Lp);
     };
+    if (cfg == 4 && EPI == 1 && sizeof(typename T::elem) == 2) cfg = 6;     // FFN-1: the two-workgroup kernel is 4 % faster there
+    if (cfg == 7) cfg = 4;                                                  // 7 = gemm_pp_kernel for every GEMM (A/B)
     if (cfg == 4) {
         (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         const unsigned mtiles = (unsigned)((Mmax + 255) / 256);
         hipLaunchKernelGGL((gemm_pp_kernel<T, EPI>), dim3((mtiles + 7) / 8 * 8 * (N / 256)), dim3(512), 128 * 1024 + 512, stream, A, W, bias, R, C,
                            VT, cu, n, tokinfo, N, K, Lp, g_gemm_dbg, g_gemm_diag);
+    }
+    else if (cfg == 6) {
+        if constexpr (sizeof(typename T::elem) == 2) {
+            (void)hipFuncSetAttribute((const void*)gemm_co_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            const unsigned mtiles = (unsigned)((Mmax + 127) / 128);
+            hipLaunchKernelGGL((gemm_co_kernel<T, EPI>), dim3((mtiles + 7) / 8 * 8 * (N / 256)), dim3(256), 64 * 1024 + 512, stream, A, W, bias, R, C,
+                               VT, cu, n, tokinfo, N, K, Lp, g_gemm_diag);
+        } else go(gemm_bt_kernel<T, EPI, 256, 256, 2, 4>, 256, 256, 512);
     }
     else if (cfg == 2) go(gemm_bt_kernel<T, EPI, 256, 256, 2, 4>, 256, 256, 512);
     else if (cfg == 3) {

@@ -183,7 +183,7 @@ def test_bulk_gemm_kernels_agree_bit_for_bit(dtype, gpu_index_cls, monkeypatch):
     monkeypatch.delenv("ATLAS_GEMM_CFG", raising=False)
     base = mine(ids, mask)
     assert torch.equal(mine(ids, mask), base)
-    for cfg in ("4", "2", "0", "3"):
+    for cfg in ("4", "6", "7", "2", "0", "3"):
         monkeypatch.setenv("ATLAS_GEMM_CFG", cfg)
         assert torch.equal(mine(ids, mask), base), f"cfg {cfg} differs from the default configuration"
     monkeypatch.delenv("ATLAS_GEMM_CFG", raising=False)

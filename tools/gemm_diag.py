@@ -6,7 +6,7 @@ import torch
 from atlas_amd import retrievers, _lib
 L = _lib.lib()
 L.atlas_dbg_set_gemm_diag.argtypes = [ctypes.c_int]
-modes = [int(a) for a in sys.argv[1:]] or [0, 1, 2]
+modes = [a for a in sys.argv[1:]] or ["0", "1", "2"]     # "diag" or "cfg:diag"
 NB = int(os.environ.get("NB", "512"))
 m = retrievers.Contriever(retrievers.BertConfigLite()).half().eval().cuda().requires_grad_(False)
 g = torch.Generator().manual_seed(1)
@@ -14,7 +14,9 @@ ids = torch.randint(1000, 30522, (NB, 128), generator=g).cuda()
 mask = torch.ones((NB, 128), dtype=torch.int64).cuda()
 out = torch.empty((NB, 768), dtype=torch.float16, device="cuda")
 for md in modes:
-    L.atlas_dbg_set_gemm_diag(md)
+    if ":" in md:
+        os.environ["ATLAS_GEMM_CFG"], md = md.split(":")
+    L.atlas_dbg_set_gemm_diag(int(md))
     for _ in range(4):
         m.embed_into(out, ids, mask)
     torch.cuda.synchronize()
