@@ -22,6 +22,7 @@
 //   gemm_pp_kernel<T,EPI>   C[M,N] = A[M,K] . W[N,K]^T + bias on the matrix cores, 256 x 256 tiles, LDS-DMA staging, the
 //                        two waves of a SIMD in opposite read / multiply phases; epilogues: QKV split + V^T | erf GELU |
 //                        + residual, written out through LDS in whole rows        (MFMA-bound: the refresh roofline)
+//   gemm_co_kernel<T,EPI>   the same GEMM as two co-resident 4-wave workgroups per CU on 256 x 128 tiles (serves FFN-1)
 //   gemm_bt_kernel<T,EPI,..>  the single-phase version; 128 x 128 and 64 x 64 tiles serve small (query) batches
 //   attention_kernel<T,MAXKF>  per (passage, head): S^T = K.Q^T -> dtype -> /8 -> fp32 softmax -> dtype P -> P.V, P in registers
 //   attention_f32_kernel the same on v_mfma_f32_16x16x4_f32 for the fp32 model
