@@ -1065,16 +1065,20 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
     }
     __syncthreads();
     const int nkf = Lp / 16;
-    // One query fragment (16 queries x all keys). FULL: every one of the MAXKF key fragments exists and holds real keys only
-    // (L = MAXKF * 16, e.g. 128-token passages): no guards, no mask. Both variants do the same arithmetic per element, so a
-    // passage gives the same bits whichever one serves it (the batch's padded length picks MAXKF).
-    auto fragment = [&](const int qf, const uint4 q0, const uint4 q1, auto full_tag) {
+    // One query fragment (16 queries x all keys), compiled for NKF key fragments: the passage's own padded length picks the
+    // variant (Lp / 16 = 2, 4, ... MAXKF), so ragged batches pay for their own keys and not for run-time guards up to the
+    // batch's longest passage. FULL: all keys are real (L = Lp): no mask. For MAXKF = 32 (passages > 256 tokens) there is one
+    // guarded variant instead of sixteen. Every variant does the same arithmetic per element in the same order, so a passage
+    // gives the same bits whichever one serves it.
+    auto fragment = [&](const int qf, const uint4 q0, const uint4 q1, auto nkf_tag, auto full_tag) {
+        constexpr int NKF = decltype(nkf_tag)::value;
         constexpr bool FULL = decltype(full_tag)::value;
-        f4 s[MAXKF];
+        constexpr bool GUARD = (MAXKF > 16);                    // NKF = MAXKF with run-time guards on nkf
+        f4 s[NKF];
 #pragma unroll
-        for (int kf = 0; kf < MAXKF; ++kf) {
+        for (int kf = 0; kf < NKF; ++kf) {
             s[kf] = (f4){0.f, 0.f, 0.f, 0.f};
-            if (FULL || kf < nkf) {
+            if (!GUARD || FULL || kf < nkf) {
                 const int krow = kf * 16 + lr;
                 const uint4 k0 = sK[krow * 8 + (lg ^ (krow & 7))];
                 const uint4 k1 = sK[krow * 8 + ((4 + lg) ^ (krow & 7))];
@@ -1082,18 +1086,18 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
                 s[kf] = T::mma(k1, q1, s[kf]);
             }
         }
-        uint32_t pk[MAXKF][2];                                      // softmax(...).type_as(model dtype), two keys per word
+        uint32_t pk[NKF][2];                                      // softmax(...).type_as(model dtype), two keys per word
         if constexpr (T::DT == ATLAS_DT_F16) {
             // fp16 model: the three model-dtype steps (dt(q.k), / sqrt(64) -- exact --, + mask) run on PACKED halves
             // (v_cvt_pk_f16_f32, v_pk_mul_f16, v_pk_add_f16, v_pk_max_f16); the softmax itself is fp32 as in the reference
             // (modeling_bert.py:352): e = 2^(v * log2 e - max * log2 e), one mixed-precision fma + v_exp_f32 per key
             typedef _Float16 h2 __attribute__((ext_vector_type(2)));
             typedef float f2 __attribute__((ext_vector_type(2)));
-            h2 v[MAXKF][2];
+            h2 v[NKF][2];
             h2 mx2 = {(_Float16)(-__builtin_inff()), (_Float16)(-__builtin_inff())};
 #pragma unroll
-            for (int kf = 0; kf < MAXKF; ++kf)
-                if (FULL || kf < nkf) {
+            for (int kf = 0; kf < NKF; ++kf)
+                if (!GUARD || FULL || kf < nkf) {
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         h2 x = {(_Float16)s[kf][2 * e], (_Float16)s[kf][2 * e + 1]};
@@ -1110,11 +1114,11 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float nmx = -mx * 1.4426950408889634f;
-            f2 ex[MAXKF][2];
+            f2 ex[NKF][2];
             f2 sum2 = {0.f, 0.f};
 #pragma unroll
-            for (int kf = 0; kf < MAXKF; ++kf)
-                if (FULL || kf < nkf) {
+            for (int kf = 0; kf < NKF; ++kf)
+                if (!GUARD || FULL || kf < nkf) {
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const f2 ee = {__builtin_amdgcn_exp2f(__builtin_fmaf((float)v[kf][e].x, 1.4426950408889634f, nmx)),
@@ -1128,8 +1132,8 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
             sum += __shfl_xor(sum, 32);
             const float inv = 1.0f / sum;
 #pragma unroll
-            for (int kf = 0; kf < MAXKF; ++kf)
-                if (FULL || kf < nkf) {
+            for (int kf = 0; kf < NKF; ++kf)
+                if (!GUARD || FULL || kf < nkf) {
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const f2 pe = ex[kf][e] * (f2){inv, inv};
@@ -1140,8 +1144,8 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
         } else {
             float mx = -__builtin_inff();
 #pragma unroll
-            for (int kf = 0; kf < MAXKF; ++kf)
-                if (FULL || kf < nkf) {
+            for (int kf = 0; kf < NKF; ++kf)
+                if (!GUARD || FULL || kf < nkf) {
                     const float4 am = *(const float4*)(sMask + kf * 16 + lg * 4);
                     const float a4[4] = {am.x, am.y, am.z, am.w};
 #pragma unroll
@@ -1156,8 +1160,8 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             float sum = 0.f;
 #pragma unroll
-            for (int kf = 0; kf < MAXKF; ++kf)
-                if (FULL || kf < nkf) {
+            for (int kf = 0; kf < NKF; ++kf)
+                if (!GUARD || FULL || kf < nkf) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float e = __expf(s[kf][r] - mx);            // exp(-inf) = 0 for padded keys
@@ -1169,8 +1173,8 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
             sum += __shfl_xor(sum, 32);
             const float inv = 1.0f / sum;
 #pragma unroll
-            for (int kf = 0; kf < MAXKF; ++kf)
-                if (FULL || kf < nkf) {
+            for (int kf = 0; kf < NKF; ++kf)
+                if (!GUARD || FULL || kf < nkf) {
 #pragma unroll
                     for (int e = 0; e < 2; ++e)
                         pk[kf][e] = (uint32_t)T::st(s[kf][2 * e] * inv) | ((uint32_t)T::st(s[kf][2 * e + 1] * inv) << 16);
@@ -1181,8 +1185,8 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
 #pragma unroll
         for (int df = 0; df < 4; ++df) o[df] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < MAXKF / 2; ++ks)
-            if (FULL || 2 * ks < nkf) {
+        for (int ks = 0; ks < NKF / 2; ++ks)
+            if (!GUARD || FULL || 2 * ks < nkf) {
                 const uint4 pa = make_uint4(pk[2 * ks][0], pk[2 * ks][1], pk[2 * ks + 1][0], pk[2 * ks + 1][1]);
 #pragma unroll
                 for (int df = 0; df < 4; ++df) {
@@ -1200,12 +1204,34 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
                 if (FULL || row < L) ctx[((size_t)tb + row) * HID + h * DHEAD + df * 16 + lr] = T::st(o[df][r]);
             }
     };
-    const bool full = (L == MAXKF * 16);                         // workgroup-uniform
-    for (int qf = wave; qf * 16 < L; qf += 4) {
-        const uint4 q0 = q0n, q1 = q1n;
-        if ((qf + 4) * 16 < L) load_q(qf + 4, q0n, q1n);
-        if (full) fragment(qf, q0, q1, std::true_type{});
-        else fragment(qf, q0, q1, std::false_type{});
+    const bool full = (L == Lp);                                 // workgroup-uniform
+    auto run = [&](auto nkf_tag) {
+        for (int qf = wave; qf * 16 < L; qf += 4) {
+            const uint4 q0 = q0n, q1 = q1n;
+            if ((qf + 4) * 16 < L) load_q(qf + 4, q0n, q1n);
+            if (full) fragment(qf, q0, q1, nkf_tag, std::true_type{});
+            else fragment(qf, q0, q1, nkf_tag, std::false_type{});
+        }
+    };
+    if constexpr (MAXKF > 16) {
+        run(std::integral_constant<int, MAXKF>{});
+    } else {
+        switch (nkf) {                                           // Lp is a multiple of 32: nkf is even
+            case 2: run(std::integral_constant<int, 2>{}); break;
+            case 4: run(std::integral_constant<int, 4>{}); break;
+            case 6: run(std::integral_constant<int, 6>{}); break;
+            case 8: run(std::integral_constant<int, 8>{}); break;
+            default:
+                if constexpr (MAXKF > 8) {
+                    switch (nkf) {
+                        case 10: run(std::integral_constant<int, 10>{}); break;
+                        case 12: run(std::integral_constant<int, 12>{}); break;
+                        case 14: run(std::integral_constant<int, 14>{}); break;
+                        default: run(std::integral_constant<int, 16>{}); break;
+                    }
+                }
+                break;
+        }
     }
 }
 
