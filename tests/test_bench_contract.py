@@ -1,0 +1,61 @@
+"""The benchmark line's contract (no GPU needed): the committed bench lines under profiles/ carry every field the driver and the
+judge read, with consistent arithmetic (value = queries x steps / time, roofline.frac = achieved / peak, algorithmic bytes =
+rows x 1536), and bench.py itself refuses to run without an MI355X instead of timing a fallback."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LINES = ["bench_default_32m.json", "bench_4m.json", "bench_1m.json"]
+
+
+@pytest.mark.parametrize("name", LINES)
+def test_committed_bench_line_has_the_contract_fields(name):
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r01", name)).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "queries/s" and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["dtype"] == "f16" and d["scaling"] in ("weak", "strong") and d["n_gpus"] == 1
+    assert "workload" in d["config"] and "model" not in d["config"]
+    q = d["config"]["queries"]
+    assert abs(d["value"] - q / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    rows = d["config"]["passages_per_gpu"]
+    assert r["algorithmic_bytes_per_launch"] == rows * 768 * 2
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms_mean"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
+    if r["traffic"] is not None:        # PMC bytes per launch: at least the algorithmic bytes, not wildly more (no wasted re-reads)
+        assert 1.0 <= r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.1
+    # the whole step cannot be faster than its dominant kernel
+    assert d["ms_per_step"] >= r["kernel_ms_min"]
+
+
+def test_default_line_carries_cpu_baseline_and_refresh():
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r01", LINES[0])).read().strip().splitlines()[-1])
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == "queries/s" and c["value"] > 0
+    f = d["refresh"]
+    assert f["unit"] == "passages/s" and f["roofline"]["bound"] == "mfma" and f["roofline"]["peak"] == 2500.0
+    flops = 169.9e6 * f["passage_len"] + 36864.0 * f["passage_len"] ** 2
+    assert abs(f["roofline"]["flops_per_passage"] - flops) < 1.0
+    assert abs(f["roofline"]["achieved"] - f["value"] * flops / 1e12) <= 1e-6 * f["roofline"]["achieved"]
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode != 0 and "MI355X" in (p.stderr + p.stdout)
+    assert not any(line.startswith("{") for line in p.stdout.splitlines())      # no JSON line from a fallback
