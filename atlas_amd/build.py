@@ -45,7 +45,13 @@ def build_hip(force=False, verbose=False):
                "-mllvm", "-amdgpu-mfma-vgpr-form=1", *hip_srcs, "-o", HIP_SO]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        try:
+            subprocess.check_call(cmd)
+        except subprocess.CalledProcessError:
+            # a hipcc without the MFMA-form switch: same code, AGPR-form MFMAs (slower epilogues / softmax, same results)
+            cmd = [c for c in cmd if c not in ("-mllvm", "-amdgpu-mfma-vgpr-form=1")]
+            print("retrying without -amdgpu-mfma-vgpr-form:", " ".join(cmd))
+            subprocess.check_call(cmd)
     return HIP_SO
 
 
