@@ -1072,6 +1072,7 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
     // gives the same bits whichever one serves it.
     auto fragment = [&](const int qf, const uint4 q0, const uint4 q1, auto nkf_tag, auto full_tag) {
         constexpr int NKF = decltype(nkf_tag)::value;
+        asm volatile("" ::: "memory");      // keeps hipcc from hoisting one variant's LDS reads over the switch (154 -> 108 VGPRs: four workgroups per CU again)
         constexpr bool FULL = decltype(full_tag)::value;
         constexpr bool GUARD = (MAXKF > 16);                    // NKF = MAXKF with run-time guards on nkf
         f4 s[NKF];
