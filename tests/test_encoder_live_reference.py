@@ -1,0 +1,64 @@
+"""Where the reference checkout is present (/root/reference, build container only), run its OWN Contriever
+(src/retrievers.py over src/modeling_bert.py, unmodified, through the transformers-4.18 shim of
+tests/golden/make_golden_encoder.py) on fresh random weights and inputs -- other shapes, masks with holes, token types and
+poolings than the committed fixtures -- and hold the torch restatement (oracle/contriever_ref.py) to it: same ops in the same
+order on the same machine, so bit-identical in fp32 and in the `.half()` copy. Skipped on the GPU box (no /root/reference)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "src", "retrievers.py")), reason="reference checkout not present")
+
+
+@pytest.fixture(scope="module")
+def ref_mod():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_encoder as mg
+
+    return mg, mg.import_reference_contriever()
+
+
+@pytest.mark.parametrize("layers,n,L,seed,holes", [(1, 5, 17, 1, False), (2, 9, 40, 2, True), (3, 4, 64, 3, False)])
+def test_restatement_is_bit_identical_to_the_reference_run_live(layers, n, L, seed, holes, ref_mod):
+    from transformers.models.bert.configuration_bert import BertConfig
+    from oracle.contriever_ref import BertConfigLite, ContrieverRef
+
+    mg, ref = ref_mod
+    vocab = 977
+    torch.manual_seed(seed)
+    config = BertConfig(vocab_size=vocab, hidden_size=768, num_hidden_layers=layers, num_attention_heads=12, intermediate_size=3072,
+                        max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_dropout_prob=0.1,
+                        attention_probs_dropout_prob=0.1)
+    model = mg.bind_4_18(ref.Contriever(config)).eval()
+    with torch.no_grad():                                    # LayerNorm affine away from (1, 0): the non-standard LN matters
+        for name, p in model.named_parameters():
+            if "LayerNorm" in name:
+                p.add_(0.1 * torch.randn_like(p))
+    mine = ContrieverRef(BertConfigLite(vocab_size=vocab, num_hidden_layers=layers)).eval()
+    sd = {k: v for k, v in model.state_dict().items() if "position_ids" not in k}
+    r = mine.load_state_dict(sd, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    g = torch.Generator().manual_seed(100 + seed)
+    ids = torch.randint(0, vocab, (n, L), generator=g)
+    lens = torch.randint(1, L + 1, (n,), generator=g)
+    mask = (torch.arange(L)[None, :] < lens[:, None]).long()
+    if holes:
+        mask = mask * (torch.rand((n, L), generator=g) > 0.2).long()
+        mask[:, 0] = 1
+    tt = (torch.rand((n, L), generator=g) < 0.3).long() * mask
+    with torch.no_grad():
+        for pooling in ("average", "sqrt", "cls"):
+            model.config.pooling = pooling
+            want = model(input_ids=ids, attention_mask=mask, token_type_ids=tt)
+            got = mine(ids, mask, token_type_ids=tt, pooling=pooling)
+            assert got.dtype == want.dtype and torch.equal(got, want), (pooling, float((got - want).abs().max()))
+        model.config.pooling = "average"
+        m16 = mg.bind_4_18(model.half())
+        mine16 = mine.half()
+        want = m16(input_ids=ids, attention_mask=mask, token_type_ids=tt)
+        got = mine16(ids, mask, token_type_ids=tt)
+        assert got.dtype == torch.float16 and torch.equal(got, want), float((got.float() - want.float()).abs().max())
