@@ -337,8 +337,9 @@ class HipDistributedIndex(object):
             raise RuntimeError(f"selected index k out of range (topk={topk} > {self._slab.shape[0]} passages in shard)")
         scores_d, rows_d, scores, rows = self._local_topk(allqueries, topk)
         if not dist_utils.is_initialized():
-            docs = [[self.doc_map[int(x)] for x in sample] for sample in rows]
-            return docs, [[float(s) for s in sample] for sample in scores]
+            doc_map = self.doc_map                       # (tolist() converts in C: half the host time of per-element int() / float())
+            docs = [[doc_map[x] for x in sample] for sample in rows.tolist()]
+            return docs, scores.astype(np.float64).tolist()
 
         rank = dist_utils.get_rank()
         id_mul, id_add = self._gid_params()
