@@ -22,8 +22,6 @@ What differs underneath:
 There is no CPU path: every compute call goes through atlas_amd/_lib.py and raises if the HIP
 library is missing or the slab is not on a GPU.
 """
-import ctypes
-import math
 import os
 import pickle
 from typing import List, Optional, Tuple
@@ -93,7 +91,11 @@ class HipDistributedIndex(object):
         """Resolve the winners' passages from a node-local `passage_store.PassageStore` (keyed by global passage id)
         instead of exchanging them between ranks: search_knn then has no text collective.
         The store must have been built in this index's global-id order: `PassageStore.iter_jsonl` for passages loaded
-        round-robin by `index_io.load_passages`, `PassageStore.iter_saved_index` for an index loaded with `load_index`."""
+        round-robin by `index_io.load_passages`, `PassageStore.iter_saved_index` for an index loaded with `load_index`.
+        Collective (every rank attaches): the store must hold exactly as many passages as all shards together."""
+        total = sum(int(n) for n in dist_utils.all_gather_object(len(self.doc_map)))
+        if len(store) != total:
+            raise ValueError(f"passage store holds {len(store)} passages, the index {total}: it was built from another corpus")
         self._passage_store = store
 
     # ------------------------------------------------------------------ storage
@@ -122,61 +124,80 @@ class HipDistributedIndex(object):
         if self._slab is None or e.data_ptr() != self._slab.data_ptr() or tuple(e.shape) != (self._slab.shape[1], self._slab.shape[0]):
             self._set_slab(e.T.contiguous() if not e.T.is_contiguous() else e.T)
 
-    # ------------------------------------------------------------------ persistence (index.py:55-111)
+    # ------------------------------------------------------------------ persistence
+    # On-disk format of the reference (src/index.py:55-111, preprocessing/download_index.py:12-14), which prebuilt Atlas
+    # indices use: `total_saved_shards` pairs of files, rank r owning the ids [r*S/W, (r+1)*S/W):
+    #     embeddings.{id}.pt   torch.save of a contiguous (d, n_id) fp16 tensor
+    #     passages.{id}.pt     pickle of the list of the n_id passage dicts
+    # A rank's rows are cut into runs of ceil(n / (S/W)) rows. The slab is (N, d), so a shard is transposed on the device
+    # on its way out / in; the file contents are the reference's.
     def _get_saved_embedding_path(self, save_dir: str, shard: int) -> str:
-        return os.path.join(save_dir, f"embeddings.{shard}.pt")
+        return os.path.join(save_dir, "embeddings.%d.pt" % shard)
 
     def _get_saved_passages_path(self, save_dir: str, shard: int) -> str:
-        return os.path.join(save_dir, f"passages.{shard}.pt")
+        return os.path.join(save_dir, "passages.%d.pt" % shard)
+
+    @staticmethod
+    def _owned_shard_ids(total_saved_shards: int) -> range:
+        world, rank = dist_utils.get_world_size(), dist_utils.get_rank()
+        assert total_saved_shards % world == 0, "N workers must be a multiple of shards to save"
+        per_rank = total_saved_shards // world
+        return range(rank * per_rank, (rank + 1) * per_rank)
+
+    @staticmethod
+    def _row_runs(n_rows: int, n_files: int) -> List[Tuple[int, int]]:
+        """[start, end) of the rows each of this rank's files holds; files past the last row hold nothing."""
+        run = -(-n_rows // n_files) if n_rows else 0
+        return [(min(j * run, n_rows), min((j + 1) * run, n_rows)) for j in range(n_files)]
 
     def save_index(self, path: str, total_saved_shards: int, overwrite_saved_passages: bool = False) -> None:
-        """Same files as the reference: embeddings.{s}.pt = contiguous (d, n) fp16, passages.{s}.pt = pickle."""
+        """Embeddings are always rewritten; a passages file is kept if it already exists unless `overwrite_saved_passages`
+        (index.py:80-83). Unlike the reference, a rank with fewer rows than files (or none: the reference divides by a zero
+        step there) still writes all of its files, the surplus ones empty, so that `load_index` finds every id."""
         assert self.embeddings is not None
         self._check_slab()
-        rank = dist_utils.get_rank()
-        ws = dist_utils.get_world_size()
-        assert total_saved_shards % ws == 0, f"N workers must be a multiple of shards to save"
-        shards_per_worker = total_saved_shards // ws
-        n_embeddings = self.embeddings.shape[1]
-        embeddings_per_shard = math.ceil(n_embeddings / shards_per_worker)
-        assert n_embeddings == len(self.doc_map), len(self.doc_map)
-        for shard_ind, (shard_start) in enumerate(range(0, n_embeddings, embeddings_per_shard)):
-            shard_end = min(shard_start + embeddings_per_shard, n_embeddings)
-            shard_id = shard_ind + rank * shards_per_worker  # get global shard number
-            passage_shard_path = self._get_saved_passages_path(path, shard_id)
-            if not os.path.exists(passage_shard_path) or overwrite_saved_passages:
-                passage_shard = [self.doc_map[i] for i in range(shard_start, shard_end)]
-                with open(passage_shard_path, "wb") as fobj:
-                    pickle.dump(passage_shard, fobj, protocol=pickle.HIGHEST_PROTOCOL)
-            embeddings_shard = self._slab[shard_start:shard_end].T.contiguous()   # (d, n), reference layout
-            torch.save(embeddings_shard, self._get_saved_embedding_path(path, shard_id))
+        ids = self._owned_shard_ids(total_saved_shards)
+        n_rows = int(self._slab.shape[0])
+        assert n_rows == len(self.doc_map), len(self.doc_map)
+        for shard_id, (lo, hi) in zip(ids, self._row_runs(n_rows, len(ids))):
+            p_file = self._get_saved_passages_path(path, shard_id)
+            if overwrite_saved_passages or not os.path.exists(p_file):
+                with open(p_file, "wb") as fobj:
+                    pickle.dump([self.doc_map[r] for r in range(lo, hi)], fobj, protocol=pickle.HIGHEST_PROTOCOL)
+            block = self._slab[lo:hi].T.contiguous().cpu()         # (d, n): transposed where the slab lives, then one D2H copy
+            torch.save(block, self._get_saved_embedding_path(path, shard_id))
 
     def load_index(self, path: str, total_saved_shards: int):
-        """Loads sharded embeddings and passages files written by this class or by the reference."""
-        rank = dist_utils.get_rank()
-        ws = dist_utils.get_world_size()
-        assert total_saved_shards % ws == 0, f"N workers must be a multiple of shards to save"
-        shards_per_worker = total_saved_shards // ws
-        passages = []
-        rows = []
-        dev = self._device()
-        for shard_id in range(rank * shards_per_worker, (rank + 1) * shards_per_worker):
+        """Reads this rank's files (written by this class or by the reference) into one pre-allocated slab: every (d, n) block is
+        moved to the device as it is and transposed THERE into its rows (peak device memory = slab + one block; nothing is
+        transposed or concatenated on the host)."""
+        ids = self._owned_shard_ids(total_saved_shards)
+        chunks = []
+        for shard_id in ids:
             with open(self._get_saved_passages_path(path, shard_id), "rb") as fobj:
-                passages.append(pickle.load(fobj))
-            e = torch.load(self._get_saved_embedding_path(path, shard_id), map_location="cpu")   # (d, n)
-            rows.append(e.to(torch.float16).T.contiguous().to(dev))                               # (n, d)
-        self.doc_map = {}
-        n_passages = 0
-        for chunk in passages:
-            for p in chunk:
-                self.doc_map[n_passages] = p
-                n_passages += 1
-        self._set_slab(torch.cat(rows, dim=0).contiguous())
+                chunks.append(pickle.load(fobj))
+        n_rows = sum(len(c) for c in chunks)
+        dev = self._device()
+        slab, dim, row = None, EMBEDDINGS_DIM, 0
+        for shard_id, chunk in zip(ids, chunks):
+            block = torch.load(self._get_saved_embedding_path(path, shard_id), map_location="cpu")
+            assert block.dim() == 2 and block.shape[1] == len(chunk), (tuple(block.shape), len(chunk))
+            if slab is None:
+                dim = int(block.shape[0])
+                slab = torch.empty((n_rows, dim), dtype=torch.float16, device=dev)
+            assert block.shape[0] == dim
+            if len(chunk):
+                slab[row: row + len(chunk)].copy_(block.to(device=dev, dtype=torch.float16).T)
+            row += len(chunk)
+        if slab is None:
+            slab = torch.empty((0, dim), dtype=torch.float16, device=dev)
+        self.doc_map = dict(enumerate(p for chunk in chunks for p in chunk))
+        self._set_slab(slab)
         # saved shards are contiguous runs of passages: global id = offset of this rank + row
         self._gid_mode = "contiguous"
-        sizes = dist_utils.all_gather_object(int(self._slab.shape[0]))
+        sizes = dist_utils.all_gather_object(n_rows)
         self._gid_bounds = np.cumsum([0] + [int(s) for s in sizes])
-        self._gid_offset = int(self._gid_bounds[rank])
+        self._gid_offset = int(self._gid_bounds[dist_utils.get_rank()])
 
     # ------------------------------------------------------------------ global ids
     def _gid_params(self) -> Tuple[int, int]:

@@ -61,21 +61,10 @@ class PassageStore:
     def iter_jsonl(filenames, maxload: int = -1):
         """every line of the passage files, parsed exactly like index_io.load_passages (title/section join, None for blank
         lines) but for ALL ranks: item c is global passage c"""
-        counter = 0
-        for filename in filenames:
-            with open(filename) as fobj:
-                for line in fobj:
-                    if maxload > -1 and counter >= maxload:
-                        return
-                    if line.strip() != "":
-                        item = json.loads(line)
-                        assert "id" in item
-                        if "title" in item and "section" in item and len(item["section"]) > 0:
-                            item["title"] = f"{item['title']}: {item['section']}"
-                        yield item
-                    else:
-                        yield None
-                    counter += 1
+        from . import index_io       # (index_io imports this module at load time)
+
+        for _, line in index_io.iter_passage_lines(filenames, maxload):
+            yield index_io.parse_passage_line(line)
 
     @staticmethod
     def iter_saved_index(index_dir: str, total_saved_shards: int):
@@ -86,13 +75,37 @@ class PassageStore:
                 for p in pickle.load(fobj):
                     yield p
 
+    @staticmethod
+    def node_local_rank(local_rank: Optional[int] = None) -> int:
+        """This process's rank on its node: the caller's value (`opt.local_rank`, which src/slurm.py fills from SLURM_LOCALID),
+        else LOCAL_RANK (torchrun), else SLURM_LOCALID, else the global rank (single-node jobs started by hand)."""
+        if local_rank is not None and int(local_rank) >= 0:
+            return int(local_rank)
+        for var in ("LOCAL_RANK", "SLURM_LOCALID"):
+            if os.environ.get(var, "") != "":
+                return int(os.environ[var])
+        return dist_utils.get_rank()
+
     @classmethod
-    def open_shared(cls, path: str, make_items) -> "PassageStore":
-        """Collective. The first rank of each node (LOCAL_RANK 0, or rank 0 without a launcher) builds the store from
-        `make_items()` if it does not exist yet; everyone maps it after a barrier."""
-        local_rank = int(os.environ.get("LOCAL_RANK", dist_utils.get_rank()))
-        if local_rank == 0 and not (os.path.exists(path + ".off.npy") and os.path.exists(path + ".bin")):
-            cls.build_from_items(path, make_items())
+    def open_shared(cls, path: str, make_items, signature: Optional[str] = None, local_rank: Optional[int] = None) -> "PassageStore":
+        """Collective. The first rank of each node builds the store from `make_items()` unless one with the same `signature`
+        (what it was built from: index_io._corpus_signature) is already there; everyone maps it after a barrier. A store built from
+        another corpus / max_passages / shard count is rebuilt, never reused: its ids would resolve to the wrong text."""
+        meta_path = path + ".meta.json"
+        if cls.node_local_rank(local_rank) == 0:
+            fresh = os.path.exists(path + ".off.npy") and os.path.exists(path + ".bin")
+            if fresh and signature is not None:
+                try:
+                    with open(meta_path) as f:
+                        fresh = json.load(f).get("signature") == signature
+                except (OSError, ValueError):
+                    fresh = False
+            if not fresh:
+                cls.build_from_items(path, make_items())
+                tmp = meta_path + ".tmp%d" % os.getpid()
+                with open(tmp, "w") as f:
+                    json.dump({"signature": signature}, f)
+                os.replace(tmp, meta_path)
         if dist_utils.is_initialized():
             dist_utils.barrier()
         return cls(path)

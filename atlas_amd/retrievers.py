@@ -17,6 +17,7 @@ There is no eager-PyTorch fallback.
 
 Not provided (raises AtlasHipError): forward with autograd (retriever training, atlas.py:457-465); CPU tensors.
 """
+import contextlib
 import copy
 import ctypes
 
@@ -54,6 +55,9 @@ class _Embeddings(nn.Module):
         self.position_embeddings = nn.Embedding(c.max_position_embeddings, c.hidden_size)
         self.token_type_embeddings = nn.Embedding(c.type_vocab_size, c.hidden_size)
         self.LayerNorm = _LayerNormParams(c.hidden_size, c.layer_norm_eps)
+        # persistent buffer of the reference's BertEmbeddings (modeling_bert.py:205): every Atlas checkpoint carries
+        # `...embeddings.position_ids`, and src/model_io.py:122 loads with strict=True
+        self.register_buffer("position_ids", torch.arange(c.max_position_embeddings).expand((1, -1)))
 
 
 class _SelfAttention(nn.Module):
@@ -113,8 +117,7 @@ class Contriever(nn.Module):
     def from_pretrained(cls, path, pooling="average", **kwargs):
         """`Contriever.from_pretrained(opt.retriever_model_path)` (src/model_io.py:45) for a LOCAL directory in the HF layout:
         config.json + model.safetensors or pytorch_model.bin (facebook/contriever ships both). Keys may carry the `bert.`
-        prefix of task heads; `pooler.*` (unused: add_pooling_layer=False, retrievers.py:17) and position_ids buffers are
-        dropped. No hub download (there is no network on the target boxes)."""
+        prefix of task heads; `pooler.*` (unused: add_pooling_layer=False, retrievers.py:17) is dropped. No hub download (there is no network on the target boxes)."""
         import json
         import os
 
@@ -137,10 +140,12 @@ class Contriever(nn.Module):
         clean = {}
         for k, v in sd.items():
             k = k[5:] if k.startswith("bert.") else k
-            if k.startswith("pooler.") or k.endswith("position_ids"):
+            if k.startswith("pooler."):
                 continue
             clean[k] = v
         model = cls(config)
+        # checkpoints written by transformers >= 4.31 no longer carry the position_ids buffer
+        clean.setdefault("embeddings.position_ids", model.embeddings.position_ids)
         model.load_state_dict(clean, strict=True)
         return model
 
@@ -264,78 +269,93 @@ class Contriever(nn.Module):
         return new
 
 
-class BaseRetriever(torch.nn.Module):
-    """A retriever needs to be able to embed queries and passages, and have a forward function (retrievers.py:63-87)"""
+@contextlib.contextmanager
+def _frozen_eval(module):
+    """run `module` in eval mode without autograd and put its mode back afterwards"""
+    was_training = module.training
+    module.eval()
+    try:
+        with torch.no_grad():
+            yield module
+    finally:
+        module.train(was_training)
+
+
+class BaseRetriever(nn.Module):
+    """The retriever surface atlas.py talks to (src/retrievers.py:63-87): `forward(*args, is_passages=False, **kw)` dispatches to
+    `embed_passages` / `embed_queries`, and gradient checkpointing is switched on every child encoder.
+
+    Subclasses name the child modules that play the two roles (the attribute names are the checkpoint prefixes
+    `retriever.contriever.*` / `retriever.{query,passage}_contriever.*`, src/model_io.py:62-71); a subclass without roles has to
+    override the two `embed_*` methods, as in the reference."""
+
+    query_role = None        # attribute holding the query encoder
+    passage_role = None      # attribute holding the passage encoder
 
     def __init__(self, *args, **kwargs):
-        super(BaseRetriever, self).__init__()
+        super().__init__()
+
+    def _encode(self, role, args, kwargs, queries=False):
+        if role is None:
+            raise NotImplementedError()
+        encoder = getattr(self, role)
+        if queries and isinstance(encoder, Contriever):
+            # queries arrive padded to max_length (atlas.py retriever_tokenize): size the launch by the real tokens
+            kwargs.setdefault("trim_padding", True)
+        return encoder(*args, **kwargs)
 
     def embed_queries(self, *args, **kwargs):
-        raise NotImplementedError()
+        return self._encode(self.query_role, args, kwargs, queries=True)
 
     def embed_passages(self, *args, **kwargs):
-        raise NotImplementedError()
+        return self._encode(self.passage_role, args, kwargs)
 
     def forward(self, *args, is_passages=False, **kwargs):
-        if is_passages:
-            return self.embed_passages(*args, **kwargs)
-        else:
-            return self.embed_queries(*args, **kwargs)
+        embed = self.embed_passages if is_passages else self.embed_queries
+        return embed(*args, **kwargs)
+
+    def _each_child(self, method):
+        for child in self.children():
+            getattr(child, method)()
 
     def gradient_checkpointing_enable(self):
-        for m in self.children():
-            m.gradient_checkpointing_enable()
+        self._each_child("gradient_checkpointing_enable")
 
     def gradient_checkpointing_disable(self):
-        for m in self.children():
-            m.gradient_checkpointing_disable()
+        self._each_child("gradient_checkpointing_disable")
 
 
 class DualEncoderRetriever(BaseRetriever):
-    """Wrapper for standard contriever, or other dual encoders that parameter-share (retrievers.py:90-105)"""
+    """One shared encoder for queries and passages (src/retrievers.py:90-105)."""
+
+    query_role = passage_role = "contriever"
 
     def __init__(self, opt, contriever):
-        super(DualEncoderRetriever, self).__init__()
+        super().__init__()
         self.opt = opt
         self.contriever = contriever
 
-    def _embed(self, *args, **kwargs):
+    def _embed(self, *args, **kwargs):       # kept: the reference exposes it
         return self.contriever(*args, **kwargs)
-
-    def embed_queries(self, *args, **kwargs):
-        # queries are tokenised with padding="max_length" (atlas.py retriever_tokenize): cut the all-padding tail
-        if isinstance(self.contriever, Contriever):
-            kwargs.setdefault("trim_padding", True)
-        return self._embed(*args, **kwargs)
-
-    def embed_passages(self, *args, **kwargs):
-        return self._embed(*args, **kwargs)
 
 
 class UntiedDualEncoderRetriever(BaseRetriever):
-    """Like DualEncoderRetriever, but dedicated encoders for passage and query embedding (retrievers.py:108-135)"""
+    """Separate query and passage encoders (src/retrievers.py:108-135). With `opt.query_side_retriever_training` the passage
+    encoder is frozen: passages are embedded in eval mode without autograd, whatever mode the module is in."""
+
+    query_role, passage_role = "query_contriever", "passage_contriever"
 
     def __init__(self, opt, query_encoder, passage_encoder=None):
-        super(UntiedDualEncoderRetriever, self).__init__()
+        super().__init__()
         self.opt = opt
         self.query_contriever = query_encoder
         if passage_encoder is None:
+            # as the reference: a wrapped (`.module`) query encoder is copied, a bare one is shared
             passage_encoder = copy.deepcopy(query_encoder) if hasattr(query_encoder, "module") else query_encoder
         self.passage_contriever = passage_encoder
 
-    def embed_queries(self, *args, **kwargs):
-        if isinstance(self.query_contriever, Contriever):
-            kwargs.setdefault("trim_padding", True)
-        return self.query_contriever(*args, **kwargs)
-
     def embed_passages(self, *args, **kwargs):
-        if self.opt.query_side_retriever_training:
-            is_train = self.passage_contriever.training
-            self.passage_contriever.eval()
-            with torch.no_grad():
-                passage_emb = self.passage_contriever(*args, **kwargs)
-            if is_train:
-                self.passage_contriever.train()
-        else:
-            passage_emb = self.passage_contriever(*args, **kwargs)
-        return passage_emb
+        if not self.opt.query_side_retriever_training:
+            return super().embed_passages(*args, **kwargs)
+        with _frozen_eval(self.passage_contriever):
+            return super().embed_passages(*args, **kwargs)
