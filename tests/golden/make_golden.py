@@ -9,7 +9,10 @@ the 2-process case `torch.Tensor.cuda = identity` + gloo. The code that runs is 
 (_compute_scores_and_indices, search_knn, serialize_listdocs, dist_utils.varsize_*).
 
 Outputs (committed): tests/golden/<case>.npz with the reference's top-k scores (fp16) and ids,
-plus the sha256 of the regenerated inputs (tests/synth.py is integer-deterministic).
+plus the sha256 of the regenerated inputs (tests/synth.py is integer-deterministic), plus the SAME
+reference call with k + EXT neighbours (`ext_scores`, `ext_ids`): the reference's own scores of every id
+near the k-th place, which is what lets tests/parity.py decide row by row whether a difference between the
+reference's list and the canonical one is explained by a 1-ulp score difference or a tie.
 """
 import os
 import sys
@@ -23,6 +26,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 import synth  # noqa: E402
 
 REF = "/root/reference"
+EXT = 24          # extra neighbours of the extended reference call
 
 
 def import_reference_index():
@@ -76,6 +80,7 @@ def _dist_worker(rank, W, port, c, out_dir):
     import torch.distributed as dist
 
     torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.set_num_threads(1)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=W)
     DistributedIndex = import_reference_index()
@@ -90,19 +95,27 @@ def _dist_worker(rank, W, port, c, out_dir):
     idx.embeddings[:, :] = torch.from_numpy(P[mine]).T
     docs, scores = idx.search_knn(torch.from_numpy(Q), c["k"])
     ids = np.array([[int(d["id"]) for d in row] for row in docs], dtype=np.int64)
+    docs_x, scores_x = idx.search_knn(torch.from_numpy(Q), c["k"] + EXT)          # the same collective, k + EXT neighbours
+    ids_x = np.array([[int(d["id"]) for d in row] for row in docs_x], dtype=np.int64)
     np.savez(os.path.join(out_dir, f"_dist_rank{rank}.npz"), ids=ids,
-             scores=np.array(scores, dtype=np.float32).astype(np.float16))
+             scores=np.array(scores, dtype=np.float32).astype(np.float16), ids_x=ids_x,
+             scores_x=np.array(scores_x, dtype=np.float32).astype(np.float16))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def main():
     torch.manual_seed(0)
+    # one thread: the reference's CPU matmul splits the reduction differently from run to run when threaded (observed here:
+    # regenerating these fixtures moved one score of 2 560 by 1 fp16 ulp), and the k and k + EXT calls must see the same scores
+    torch.set_num_threads(1)
     DistributedIndex = import_reference_index()
     for name, c in CASES.items():
         P, Q = make_inputs(c)
         s, i = run_single(DistributedIndex, P, Q, c["k"])
+        sx, ix = run_single(DistributedIndex, P, Q, min(c["N"], c["k"] + EXT))
         np.savez_compressed(os.path.join(HERE, f"{name}.npz"), ref_scores=s.astype(np.float16), ref_ids=i.astype(np.int64),
+                            ext_scores=sx.astype(np.float16), ext_ids=ix.astype(np.int64),
                             sha=np.array(synth.sha(P, Q)), **{k: np.array(v) for k, v in c.items()})
         print(name, s.shape, "written")
     import torch.multiprocessing as mp
@@ -114,6 +127,7 @@ def main():
     Qall = synth.queries_f32(sum(c["batch"]), 768, c["qs"])
     np.savez_compressed(os.path.join(HERE, "e_dist_w2.npz"), ref_ids=np.concatenate([p["ids"] for p in parts]),
                         ref_scores=np.concatenate([p["scores"] for p in parts]), sha=np.array(synth.sha(P, Qall)),
+                        ext_ids=np.concatenate([p["ids_x"] for p in parts]), ext_scores=np.concatenate([p["scores_x"] for p in parts]),
                         N=np.array(c["N"]), k=np.array(c["k"]), ps=np.array(c["ps"]), qs=np.array(c["qs"]),
                         batch=np.array(c["batch"]))
     for r in range(2):

@@ -2,8 +2,9 @@
 made by tests/golden/make_golden.py through an import shim; the reference ships no tests of its own).
 
 The reference (torch CPU fp16 matmul + topk) rounds a small fraction of scores 1 ulp away from the
-correctly rounded value and orders ties arbitrarily; the comparison is therefore tie-/1-ulp-aware and the
-test prints how many rows agree outright.
+correctly rounded value and orders ties arbitrarily; tests/parity.py::compare_with_reference decides row by
+row from the reference's own scores around the cut (no agreement-rate threshold): clean rows must be
+identical, every other difference must be explained by a tie or a 1-ulp difference of the id that differs.
 """
 import os
 
@@ -34,11 +35,11 @@ def test_oracle_vs_reference_single(case, oracle_mod):
     q16 = oracle_mod.f32_to_f16(Q)
     assert np.array_equal(q16.view(np.uint16), Q.astype(np.float16).view(np.uint16))   # `.half()` == RNE
     s, i, full = oracle_mod.search(q16, P, k, return_full=True)
-    st = parity.compare_with_reference(g["ref_scores"], g["ref_ids"], full, s, i)
+    st = parity.compare_with_reference(g["ref_scores"], g["ref_ids"], g["ext_scores"], g["ext_ids"], full, s, i)
     print(case, st)
     assert st["max_ulp"] <= 1
-    if case != "c_dups":     # with forced 4-way ties the reference's id order is arbitrary by construction
-        assert st["identical_sets"] >= 0.7 * st["rows"]
+    if case != "c_dups":     # with forced 4-way ties every row has a canonical tie: rule (d) carries that case
+        assert st["clean_rows"] >= 1, "the sharp rule was never exercised"
 
 
 def test_oracle_vs_reference_distributed_w2(oracle_mod):
@@ -49,7 +50,7 @@ def test_oracle_vs_reference_distributed_w2(oracle_mod):
     Q = synth.queries_f32(int(np.sum(g["batch"])), 768, int(g["qs"]))
     assert synth.sha(P, Q) == str(g["sha"])
     s, i, full = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, k, return_full=True)
-    st = parity.compare_with_reference(g["ref_scores"], g["ref_ids"], full, s, i)
+    st = parity.compare_with_reference(g["ref_scores"], g["ref_ids"], g["ext_scores"], g["ext_ids"], full, s, i)
     print("dist", st)
     assert st["max_ulp"] <= 1
 

@@ -44,10 +44,17 @@ def test_oracle_agrees_with_the_reference_run_live(N, B, k, scale, dup, seed, re
     idx.is_in_gpu = False
     idx.init_embeddings([{"id": str(i)} for i in range(P.shape[0])])
     idx.embeddings[:, :] = torch.from_numpy(P).T
-    rs, ri = idx._compute_scores_and_indices(torch.from_numpy(Q), k)           # the reference's two torch calls
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)        # threaded, the reference's CPU matmul is not run-to-run deterministic: both calls must see the same scores
+    try:
+        rs, ri = idx._compute_scores_and_indices(torch.from_numpy(Q), k)           # the reference's two torch calls
+        xs, xi = idx._compute_scores_and_indices(torch.from_numpy(Q), min(P.shape[0], k + 24))   # ... and its scores around the cut
+    finally:
+        torch.set_num_threads(threads)
     s, i, full = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, k, return_full=True)
-    st = parity.compare_with_reference(rs.numpy().astype(np.float16), ri.numpy().astype(np.int64), full, s, i)
+    st = parity.compare_with_reference(rs.numpy().astype(np.float16), ri.numpy().astype(np.int64), xs.numpy().astype(np.float16),
+                                       xi.numpy().astype(np.int64), full, s, i)
     print((N, B, k, scale, dup), st)
     assert st["max_ulp"] <= 1
     if dup == 1 and k < N:
-        assert st["identical_sets"] >= 0.5 * st["rows"]
+        assert st["clean_rows"] >= 1, "the sharp rule (clean rows must be identical) was never exercised"
