@@ -10,6 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_SO = os.environ.get("ATLAS_HIP_SO") or os.path.join(HERE, "lib", "libatlas_hip.so")   # ATLAS_HIP_SO: A/B runs of two builds (dev)
+TUNE_SO = os.path.join(HERE, "lib", "libatlas_hip_tune.so")   # the -DATLAS_TUNING=1 build: lib(tuning=True), tools/ and configuration tests only
 
 ABI_VERSION = 4
 DT_F16, DT_F32, DT_BF16 = 0, 1, 2
@@ -50,20 +51,35 @@ class AtlasHipError(RuntimeError):
 
 
 _lib = None
+_tune = None
 
 
-def lib():
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(HIP_SO):
+def lib(tuning=False):
+    """The product library. tuning=True: the tuning build of the same sources (process-global knobs: scan variant, GEMM
+    configuration, cycle stamps) -- never used by the product path."""
+    global _lib, _tune
+    if tuning:
+        if _tune is None:
+            _tune = _bind(TUNE_SO)
+            vp, i32 = ctypes.c_void_p, ctypes.c_int
+            for name, args in (("atlas_tune_set_scan_variant", [i32]), ("atlas_tune_set_gemm_cfg", [i32]), ("atlas_tune_set_gemm_diag", [i32]),
+                               ("atlas_tune_set_gemm_stamps", [vp]), ("atlas_tune_set_merge_stamps", [vp]), ("atlas_tune_set_scan_stamps", [vp])):
+                getattr(_tune, name).argtypes, getattr(_tune, name).restype = args, None
+        return _tune
+    if _lib is None:
+        _lib = _bind(HIP_SO)
+    return _lib
+
+
+def _bind(path):
+    if not os.path.exists(path):
         raise AtlasHipError(
-            f"{HIP_SO} is missing: the HIP extension is not built (run `python -m atlas_amd.build`). "
+            f"{path} is missing: the HIP extension is not built (run `python -m atlas_amd.build`). "
             "atlas_amd has no CPU fallback."
         )
     import torch  # noqa: F401  (loads torch's HIP runtime first; see module docstring)
 
-    L = ctypes.CDLL(HIP_SO)
+    L = ctypes.CDLL(path)
     vp, i64, i32, f32, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
     L.atlas_abi_version.restype = i32
     L.atlas_abi_version.argtypes = []
@@ -93,7 +109,6 @@ def lib():
     L.atlas_slab_pmax.argtypes = [vp, i64, i32, vp, vp]
     if L.atlas_abi_version() != ABI_VERSION:
         raise AtlasHipError(f"ABI mismatch: library {L.atlas_abi_version()} vs binding {ABI_VERSION}")
-    _lib = L
     return L
 
 

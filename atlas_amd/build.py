@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 HIP_SO = os.path.join(LIBDIR, "libatlas_hip.so")
+TUNE_SO = os.path.join(LIBDIR, "libatlas_hip_tune.so")     # -DATLAS_TUNING=1: knobs + stamps for tools/ and the configuration tests
 HOST_SO = os.path.join(LIBDIR, "libatlas_host.so")
 
 
@@ -31,8 +32,10 @@ def _hipcc():
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
-def build_hip(force=False, verbose=False):
+def build_hip(force=False, verbose=False, tuning=False):
+    """the product library (no knobs, no mutable globals) or, with tuning=True, the tuning build of the same sources"""
     os.makedirs(LIBDIR, exist_ok=True)
+    HIP_SO = TUNE_SO if tuning else globals()["HIP_SO"]
     srcs = [os.path.join(CSRC, "atlas_hip.hip"), os.path.join(CSRC, "common.h"),
             os.path.join(HERE, "..", "include", "atlas_hip.h")]
     extra = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
@@ -42,7 +45,7 @@ def build_hip(force=False, verbose=False):
                "-Wall", "-Wno-unused-function",
                # MFMA results stay in architectural VGPRs: the epilogues / softmax work on them with VALU, and hipcc's default
                # AGPR form paid one v_accvgpr_read per element (6 700 of them across encoder.hip)
-               "-mllvm", "-amdgpu-mfma-vgpr-form=1", *hip_srcs, "-o", HIP_SO]
+               "-mllvm", "-amdgpu-mfma-vgpr-form=1", *(["-DATLAS_TUNING=1"] if tuning else []), *hip_srcs, "-o", HIP_SO]
         if verbose:
             print(" ".join(cmd))
         try:
@@ -68,7 +71,9 @@ def build_host(force=False, verbose=False):
 
 
 def build_all(force=False, verbose=False):
-    return build_hip(force, verbose), build_host(force, verbose)
+    hip = build_hip(force, verbose)
+    build_hip(force, verbose, tuning=True)
+    return hip, build_host(force, verbose)
 
 
 if __name__ == "__main__":

@@ -22,6 +22,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#ifndef ATLAS_TUNING
+#define ATLAS_TUNING 0
+#endif
+
 #include "common.h"
 #include "scan_kernel.h"
 #include "../../include/atlas_hip.h"
@@ -162,15 +166,19 @@ merge_rescore_kernel(const MergeParams p) {
     for (int i = tid; i < p.d; i += NT) qs[i] = p.qrow[(size_t)q * p.d + i];
     if (tid < 64) misc[tid] = (tid == 2) ? 0xffffffffu : 0u;
     const uint32_t total = p.dense_cnt[q];
-    if (total > (uint32_t)p.key_cap || total > (uint32_t)p.dense_cap) { fallback(); return; }   // TODO(perf): stream from L2
+    if (total > (uint32_t)p.dense_cap) { fallback(); return; }
     const uint2* D = p.dense + (size_t)q * p.dense_cap;
+    // the first key_cap keys are cached in LDS; a longer candidate list (poor initial threshold, adversarial data) is streamed
+    // from the dense array (L2) in the two later passes instead of being handed to the exact path
+    const uint32_t ncache = total < (uint32_t)p.key_cap ? total : (uint32_t)p.key_cap;
+    auto key_at = [&](const uint32_t i) -> uint32_t { return i < ncache ? keys[i] : f32_order_key(bits_f32(D[i].x)); };
     __syncthreads();
     if (p.dbg && q == 0 && tid == 0) p.dbg[1] = __builtin_readcyclecounter();
     // (1) keys -> LDS (coalesced), with min / max
     uint32_t kmax = 0, kmin = 0xffffffffu;
     for (uint32_t i = tid; i < total; i += NT) {
         const uint32_t key = f32_order_key(bits_f32(D[i].x));
-        keys[i] = key;
+        if (i < ncache) keys[i] = key;
         kmax = key > kmax ? key : kmax;
         kmin = key < kmin ? key : kmin;
     }
@@ -195,7 +203,7 @@ merge_rescore_kernel(const MergeParams p) {
         uint32_t* hist = (uint32_t*)s_key;                                          // 4 KB of the (still unused) key area
         for (int i = tid; i < 1024; i += NT) hist[i] = 0;
         __syncthreads();
-        for (uint32_t i = tid; i < total; i += NT) atomicAdd(&hist[(keys[i] - kmin) >> shift], 1u);
+        for (uint32_t i = tid; i < total; i += NT) atomicAdd(&hist[(key_at(i) - kmin) >> shift], 1u);
         __syncthreads();
         if (tid < 64) {
             // lane l owns bins [16l, 16l+16); suffix sums across lanes find the lane, then the bin
@@ -226,7 +234,7 @@ merge_rescore_kernel(const MergeParams p) {
     // (3) candidate band (keys in LDS decide; only band members are re-read)
     const uint32_t theta_key = f32_order_key(theta);
     for (uint32_t i = tid; i < total; i += NT) {
-        if (keys[i] > theta_key) {
+        if (key_at(i) > theta_key) {
             const uint2 e = D[i];
             const uint32_t sidx = atomicAdd(&misc[5], 1u);
             if (sidx < MERGE_SMAX) { s_row[sidx] = e.y; s_app[sidx] = bits_f32(e.x); }
@@ -310,23 +318,91 @@ merge_rescore_kernel(const MergeParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// exact path (no MFMA): canonical keys for every row, then an exact radix select
+// exact path (no MFMA): canonical keys for every row, then an exact radix select.
+// Batched: ONE slab pass scores every row against up to EXACT_QB queries (keys[t][row]), and every selection kernel handles
+// the whole batch (blockIdx.y = query of the batch). A slab row is read once per EXACT_QB queries instead of once per query.
 // ------------------------------------------------------------------------------------------
+#define EXACT_QB 8                // queries per slab pass
+#define EXACT_PASSES 6            // radix passes: the canonical key uses bits 47..0 (16-bit score key | 32-bit inverted row)
+
+// One wave per row. Lane j is chain j of the canonical order for ALL queries of the batch: c[t] += q_t[e] * p[e] for its elements
+// e = j, j+64, ... in order (common.h exact_dot_f16). The 64 chains of each query are then combined by the canonical balanced tree
+// c[j] += c[j+m], m = 1, 2, .. 32 -- as a reduce-scatter for the first three levels (each lane keeps half of its queries and
+// hands the other half to its partner: 4 + 2 + 1 exchanges instead of 3 x 8), then a plain butterfly. A lane adds (own, partner)
+// or (partner, own): IEEE addition is commutative, so every sum has the bits the serial tree gives (oracle/oracle.c).
+// Afterwards lane j holds the score of query ((j&1)<<2)|(j&2)|((j>>2)&1).
+template <bool D768>
 __global__ void __launch_bounds__(256)
-exact_keys_kernel(const uint16_t* __restrict__ slab, int64_t N, int d, const uint16_t* __restrict__ qrow,
-                  uint64_t* __restrict__ keys) {
+exact_keys_batch_kernel(const uint16_t* __restrict__ slab, int64_t N, int d, const uint16_t* __restrict__ qrow /*[nq][d]*/, int nq,
+                        uint64_t* __restrict__ keys /*[EXACT_QB][N]*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint16_t* qs = (uint16_t*)smem;
-    for (int i = threadIdx.x; i < d; i += 256) qs[i] = qrow[i];
+    uint16_t* qs = (uint16_t*)smem;                                // [EXACT_QB][d] fp16 bits (queries >= nq are zero)
+    for (int i = threadIdx.x; i < EXACT_QB * d; i += 256) {
+        const int t = i / d;
+        qs[i] = (t < nq) ? qrow[i] : (uint16_t)0;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < N; r += (int64_t)gridDim.x * 4) {   // one wave per row
-        const double s = wave_exact_dot(qs, slab + (size_t)r * d, d, lane);
-        if (lane == 0) keys[r] = local_key(f64_to_f16_bits_rto(s), (uint32_t)r);
+    double qreg[D768 ? EXACT_QB : 1][D768 ? D_FAST / 64 : 1];      // d == 768: the lane's 12 elements of every query live in registers
+    if (D768) {
+#pragma unroll
+        for (int t = 0; t < EXACT_QB; ++t)
+#pragma unroll
+            for (int i = 0; i < D_FAST / 64; ++i) qreg[t][i] = (double)(float)__builtin_bit_cast(_Float16, qs[t * D_FAST + i * 64 + lane]);
+    }
+    const int mine = ((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1);
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < N; r += (int64_t)gridDim.x * 4) {
+        const uint16_t* prow = slab + (size_t)r * d;
+        double c[EXACT_QB];
+#pragma unroll
+        for (int t = 0; t < EXACT_QB; ++t) c[t] = 0.0;
+        if (D768) {
+            uint16_t pv[D_FAST / 64];
+#pragma unroll
+            for (int i = 0; i < D_FAST / 64; ++i) pv[i] = prow[i * 64 + lane];          // all 12 loads in flight
+#pragma unroll
+            for (int i = 0; i < D_FAST / 64; ++i) {
+                const double pd = (double)(float)__builtin_bit_cast(_Float16, pv[i]);
+#pragma unroll
+                for (int t = 0; t < EXACT_QB; ++t) c[t] += qreg[t][i] * pd;
+            }
+        } else {
+            for (int e = lane; e < d; e += 64) {
+                const double pd = (double)(float)__builtin_bit_cast(_Float16, prow[e]);
+#pragma unroll
+                for (int t = 0; t < EXACT_QB; ++t) c[t] += (double)(float)__builtin_bit_cast(_Float16, qs[t * d + e]) * pd;
+            }
+        }
+        // levels m = 1, 2, 4 as a reduce-scatter over the queries
+        {
+            const bool up = lane & 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double keep = up ? c[i + 4] : c[i], give = up ? c[i] : c[i + 4];
+                c[i] = keep + __shfl_xor(give, 1);
+            }
+        }
+        {
+            const bool up = lane & 2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const double keep = up ? c[i + 2] : c[i], give = up ? c[i] : c[i + 2];
+                c[i] = keep + __shfl_xor(give, 2);
+            }
+        }
+        {
+            const bool up = lane & 4;
+            const double keep = up ? c[1] : c[0], give = up ? c[0] : c[1];
+            c[0] = keep + __shfl_xor(give, 4);
+        }
+        double sc = c[0];
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) sc += __shfl_xor(sc, m);
+        if (lane < EXACT_QB && mine < nq) keys[(size_t)mine * N + r] = local_key(f64_to_f16_bits_rto(sc), (uint32_t)r);
     }
 }
 
-// state derived from the histograms of the passes already done: (prefix, remaining rank)
+// state derived from the histograms of the passes already done: (prefix, remaining rank). Pass ps looks at byte 5 - ps.
 static __device__ __forceinline__ void radix_state(const uint32_t* __restrict__ hists, int npass_done, int k,
                                                    uint64_t& prefix, uint32_t& rem) {
     prefix = 0; rem = (uint32_t)k;
@@ -338,19 +414,24 @@ static __device__ __forceinline__ void radix_state(const uint32_t* __restrict__ 
             acc += h[bi];
         }
         rem -= acc;
-        prefix |= (uint64_t)b << (56 - 8 * ps);
+        prefix |= (uint64_t)b << (40 - 8 * ps);
     }
 }
 
+// per-query state words of the selection, contiguous per query of the batch: hists[EXACT_PASSES][256] | nsel | pad
+#define EXACT_STATE_WORDS (EXACT_PASSES * 256 + 64)
+
 __global__ void __launch_bounds__(256)
-exact_hist_kernel(const uint64_t* __restrict__ keys, int64_t N, int k, int pass, uint32_t* __restrict__ hists) {
+exact_hist_kernel(const uint64_t* __restrict__ keys_all, int64_t N, int k, int pass, uint32_t* __restrict__ state_all) {
+    const uint64_t* keys = keys_all + (size_t)blockIdx.y * N;
+    uint32_t* hists = state_all + (size_t)blockIdx.y * EXACT_STATE_WORDS;
     __shared__ uint32_t lh[256];
     __shared__ uint64_t s_prefix;
     lh[threadIdx.x] = 0;
     if (threadIdx.x == 0) { uint64_t pf; uint32_t rem; radix_state(hists, pass, k, pf, rem); s_prefix = pf; }
     __syncthreads();
     const uint64_t prefix = s_prefix;
-    const int shift = 56 - 8 * pass;
+    const int shift = 40 - 8 * pass;
     for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < N; r += (int64_t)gridDim.x * 256) {
         const uint64_t key = keys[r];
         if (pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8)))
@@ -362,12 +443,16 @@ exact_hist_kernel(const uint64_t* __restrict__ keys, int64_t N, int k, int pass,
 
 // keys >= kth are exactly min(k,N) keys (unique): gather, rank by counting, write outputs
 __global__ void __launch_bounds__(256)
-exact_collect_kernel(const uint64_t* __restrict__ keys, int64_t N, int k, const uint32_t* __restrict__ hists,
-                     uint64_t* __restrict__ sel /*[k]*/, uint32_t* __restrict__ nsel) {
+exact_collect_kernel(const uint64_t* __restrict__ keys_all, int64_t N, int k, uint32_t* __restrict__ state_all,
+                     uint64_t* __restrict__ sel_all /*[EXACT_QB][k]*/) {
+    const uint64_t* keys = keys_all + (size_t)blockIdx.y * N;
+    uint32_t* state = state_all + (size_t)blockIdx.y * EXACT_STATE_WORDS;
+    uint32_t* nsel = state + EXACT_PASSES * 256;
+    uint64_t* sel = sel_all + (size_t)blockIdx.y * k;
     __shared__ uint64_t s_kth;
     if (threadIdx.x == 0) {
         uint64_t pf; uint32_t rem;
-        radix_state(hists, 8, k, pf, rem);
+        radix_state(state, EXACT_PASSES, k, pf, rem);
         s_kth = ((int64_t)k <= N) ? pf : 0ull;     // fewer than k rows: take everything
     }
     __syncthreads();
@@ -381,10 +466,14 @@ exact_collect_kernel(const uint64_t* __restrict__ keys, int64_t N, int k, const 
     }
 }
 
+// one block per query of the batch
 __global__ void __launch_bounds__(256)
-exact_emit_kernel(const uint64_t* __restrict__ sel, const uint32_t* __restrict__ nsel, int k,
-                  uint16_t* __restrict__ o_score, int64_t* __restrict__ o_idx) {
-    uint32_t n = *nsel;
+exact_emit_kernel(const uint64_t* __restrict__ sel_all, const uint32_t* __restrict__ state_all, int k,
+                  uint16_t* __restrict__ o_score_all, int64_t* __restrict__ o_idx_all) {
+    const uint64_t* sel = sel_all + (size_t)blockIdx.x * k;
+    uint16_t* o_score = o_score_all + (size_t)blockIdx.x * k;
+    int64_t* o_idx = o_idx_all + (size_t)blockIdx.x * k;
+    uint32_t n = state_all[(size_t)blockIdx.x * EXACT_STATE_WORDS + EXACT_PASSES * 256];
     if (n > (uint32_t)k) n = (uint32_t)k;
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
         const uint64_t ki = sel[i];
@@ -478,28 +567,35 @@ namespace {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// scan_kernel instantiations selectable at run time (tuning: ATLAS_SCAN_VARIANT=<index>)
+// scan_kernel instantiations. The product library runs kVariants[0] and has no knobs, no environment reads and no mutable
+// globals (include/atlas_hip.h). The TUNING build (-DATLAS_TUNING=1 -> libatlas_hip_tune.so, used by tools/ and by the
+// configuration-equality tests only) adds the other instantiations and process-global hooks (atlas_tune_*).
 struct ScanVariant { int nw, pf, ring; void (*kern)(const ScanParams); const char* name; };
 const ScanVariant kVariants[] = {
     {16, 1, 8, scan_kernel<16, 1, 8>, "scan_kernel<16,1,8>"},
+#if ATLAS_TUNING
     {8, 2, 8, scan_kernel<8, 2, 8>, "scan_kernel<8,2,8>"},
     {8, 4, 4, scan_kernel<8, 4, 4>, "scan_kernel<8,4,4>"},
     {16, 2, 4, scan_kernel<16, 2, 4>, "scan_kernel<16,2,4>"},
     {12, 2, 4, scan_kernel<12, 2, 4>, "scan_kernel<12,2,4>"},
     {16, 1, 8, scan_kernel<16, 1, 8, 2>, "scan_kernel<16,1,8,nt>"},
     {16, 1, 8, scan_kernel<16, 1, 8, 16>, "scan_kernel<16,1,8,sc1>"},
+#endif
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-int scan_variant_index() {
-    const char* e = getenv("ATLAS_SCAN_VARIANT");
-    int v = e ? atoi(e) : 0;
-    return (v >= 0 && v < kNumVariants) ? v : 0;
-}
 
 constexpr int MERGE_NT = 1024;
-unsigned long long* g_merge_dbg = nullptr;   // tuning hook (atlas_dbg_set_merge_stamps); never set in production
-unsigned long long* g_scan_dbg = nullptr;    // tuning hook (atlas_dbg_set_scan_stamps)
 constexpr int SAMPLE_MAX = 16384;
+#if ATLAS_TUNING
+int g_scan_variant = 0;                      // atlas_tune_set_scan_variant
+unsigned long long* g_merge_dbg = nullptr;   // atlas_tune_set_merge_stamps
+unsigned long long* g_scan_dbg = nullptr;    // atlas_tune_set_scan_stamps
+int scan_variant_index() { return (g_scan_variant >= 0 && g_scan_variant < kNumVariants) ? g_scan_variant : 0; }
+#else
+constexpr unsigned long long* g_merge_dbg = nullptr;
+constexpr unsigned long long* g_scan_dbg = nullptr;
+constexpr int scan_variant_index() { return 0; }
+#endif
 
 struct ScanPlan {
     int G;               // workgroups
@@ -512,13 +608,10 @@ struct ScanPlan {
     size_t scan_lds, merge_lds;
 };
 
-int device_cus() {
-    static int cus = 0;     // immutable after first query; benign cache
-    if (cus == 0) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+int device_cus() {       // the current device's CU count, asked every time (no cached state; an attribute read, not a property dump)
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
     return cus;
 }
 
@@ -555,7 +648,7 @@ ScanPlan make_plan(int64_t N, int d, int k, int cus, const ScanVariant& v) {
     pl.off_qflag = o;  o += 256;
     pl.off_dense_cnt = o; o += 256;
     pl.off_sample = o; o += (size_t)QCHUNK * SAMPLE_MAX * 4;
-    pl.dense_cap = 32768;
+    pl.dense_cap = 131072;
     pl.off_dense = o;  o += (size_t)QCHUNK * pl.dense_cap * 8;
     pl.off_lists = o;  o += (size_t)pl.G * 64 * pl.cap * 8;
     pl.total = align_up(o, 256);
@@ -566,16 +659,14 @@ ScanPlan make_plan(int64_t N, int d, int k, int cus, const ScanVariant& v) {
     return pl;
 }
 
-struct ExactPlan { size_t off_qrow, off_qfrag_dummy, off_qeps, off_keys, off_hists, off_sel, off_nsel, total; };
+struct ExactPlan { size_t off_qrow, off_qeps, off_state, off_sel, off_keys, total; };
 ExactPlan make_exact_plan(int64_t N, int d, int k) {
     ExactPlan e{}; size_t o = 0;
     e.off_qrow = o;  o += align_up((size_t)QCHUNK * d * 2, 256);
-    e.off_qfrag_dummy = o; o += 256;
     e.off_qeps = o;  o += 256;
-    e.off_hists = o; o += 8 * 256 * 4;
-    e.off_nsel = o;  o += 256;
-    e.off_sel = o;   o += align_up((size_t)k * 8, 256);
-    e.off_keys = o;  o += align_up((size_t)(N > 0 ? N : 1) * 8, 256);
+    e.off_state = o; o += align_up((size_t)EXACT_QB * EXACT_STATE_WORDS * 4, 256);
+    e.off_sel = o;   o += align_up((size_t)EXACT_QB * k * 8, 256);
+    e.off_keys = o;  o += align_up((size_t)EXACT_QB * (size_t)(N > 0 ? N : 1) * 8, 256);
     e.total = o;
     return e;
 }
@@ -600,15 +691,22 @@ extern "C" int atlas_dbg_f64_to_f16(const double* in, uint16_t* out, int n, void
     return (int)hipGetLastError();
 }
 
-// tuning hook, deliberately not in include/atlas_hip.h: device buffer of >= 8 u64 for merge phase stamps
-void atlas_dbg_set_merge_stamps(unsigned long long* p) { g_merge_dbg = p; }
-void atlas_dbg_set_scan_stamps(unsigned long long* p) { g_scan_dbg = p; }
+#if ATLAS_TUNING
+// tuning build only (not in include/atlas_hip.h): scan variant, device buffers for cycle stamps
+void atlas_tune_set_scan_variant(int v) { g_scan_variant = v; }
+void atlas_tune_set_merge_stamps(unsigned long long* p) { g_merge_dbg = p; }
+void atlas_tune_set_scan_stamps(unsigned long long* p) { g_scan_dbg = p; }
+#endif
 
 int atlas_abi_version(void) { return ATLAS_ABI_VERSION; }
 const char* atlas_build_info(void) {
+#if ATLAS_TUNING
     static char buf[160];
-    snprintf(buf, sizeof(buf), "atlas_hip gfx950 %s " __DATE__ " " __TIME__, kVariants[scan_variant_index()].name);
+    snprintf(buf, sizeof(buf), "atlas_hip gfx950 %s " __DATE__ " " __TIME__ " tuning", kVariants[scan_variant_index()].name);
     return buf;
+#else
+    return "atlas_hip gfx950 scan_kernel<16,1,8> " __DATE__ " " __TIME__;
+#endif
 }
 
 size_t atlas_scan_topk_workspace_bytes(int64_t N, int B, int d, int k) {
@@ -704,7 +802,7 @@ int atlas_exact_topk(const void* q, int q_dtype, const void* slab_f16, int64_t N
                      void* out_score_f16, int64_t* out_idx, void* ws, size_t ws_bytes, void* stream_) {
     if (!q || (!slab_f16 && N > 0) || !out_score_f16 || !out_idx || !ws) return ATLAS_E_BADARG;
     if (B <= 0 || k <= 0 || N < 0 || d <= 0 || q_dtype < 0 || q_dtype > 2) return ATLAS_E_BADARG;
-    if (k > K_EXACT_MAX || d > 16384 || N >= (int64_t)0xffffffffll) return ATLAS_E_UNSUPPORTED;
+    if (k > K_EXACT_MAX || d > 8192 || N >= (int64_t)0xffffffffll) return ATLAS_E_UNSUPPORTED;
     const ExactPlan pl = make_exact_plan(N, d, k);
     if (ws_bytes < pl.total) return ATLAS_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
@@ -713,29 +811,37 @@ int atlas_exact_topk(const void* q, int q_dtype, const void* slab_f16, int64_t N
     int grid = (int)((N + 255) / 256);
     if (grid > cus * 8) grid = cus * 8;
     if (grid < 1) grid = 1;
-    int grid_rows = (int)((N + 3) / 4 > (int64_t)cus * 32 ? (int64_t)cus * 32 : (N + 3) / 4);
+    int grid_rows = (int)((N + 3) / 4 > (int64_t)cus * 8 ? (int64_t)cus * 8 : (N + 3) / 4);
     if (grid_rows < 1) grid_rows = 1;
+    const size_t keys_lds = align_up((size_t)EXACT_QB * d * 2, 16);
+    allow_lds(exact_keys_batch_kernel<true>);
+    allow_lds(exact_keys_batch_kernel<false>);
     for (int q0 = 0; q0 < B; q0 += QCHUNK) {
         const int nq = (B - q0 < QCHUNK) ? (B - q0) : QCHUNK;
         // prep reuses the fast path's converter (no fragment image: qfrag == nullptr)
         hipLaunchKernelGGL(prep_queries_kernel, dim3(QCHUNK), dim3(256), 0, stream, q, q_dtype, q0, nq, d, 0.f,
                            (uint16_t*)(w + pl.off_qrow), (uint16_t*)nullptr, (float*)(w + pl.off_qeps),
                            (uint32_t*)nullptr, (int32_t*)nullptr);
-        for (int j = 0; j < nq; ++j) {
-            hipError_t e = hipMemsetAsync(w + pl.off_hists, 0, 8 * 256 * 4 + 256, stream);   // hists + nsel
+        for (int j0 = 0; j0 < nq; j0 += EXACT_QB) {
+            const int nb = (nq - j0 < EXACT_QB) ? (nq - j0) : EXACT_QB;
+            hipError_t e = hipMemsetAsync(w + pl.off_state, 0, (size_t)EXACT_QB * EXACT_STATE_WORDS * 4, stream);
             if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(exact_keys_kernel, dim3(grid_rows), dim3(256), (size_t)align_up((size_t)d * 2, 16), stream,
-                               (const uint16_t*)slab_f16, N, d, (const uint16_t*)(w + pl.off_qrow) + (size_t)j * d,
-                               (uint64_t*)(w + pl.off_keys));
-            for (int pass = 0; pass < 8; ++pass)
-                hipLaunchKernelGGL(exact_hist_kernel, dim3(grid), dim3(256), 0, stream,
-                                   (const uint64_t*)(w + pl.off_keys), N, k, pass, (uint32_t*)(w + pl.off_hists));
-            hipLaunchKernelGGL(exact_collect_kernel, dim3(grid), dim3(256), 0, stream,
-                               (const uint64_t*)(w + pl.off_keys), N, k, (const uint32_t*)(w + pl.off_hists),
-                               (uint64_t*)(w + pl.off_sel), (uint32_t*)(w + pl.off_nsel));
-            hipLaunchKernelGGL(exact_emit_kernel, dim3(1), dim3(256), 0, stream, (const uint64_t*)(w + pl.off_sel),
-                               (const uint32_t*)(w + pl.off_nsel), k,
-                               (uint16_t*)out_score_f16 + (size_t)(q0 + j) * k, out_idx + (size_t)(q0 + j) * k);
+            const uint16_t* qb = (const uint16_t*)(w + pl.off_qrow) + (size_t)j0 * d;
+            if (d == D_FAST)
+                hipLaunchKernelGGL(exact_keys_batch_kernel<true>, dim3(grid_rows), dim3(256), keys_lds, stream,
+                                   (const uint16_t*)slab_f16, N, d, qb, nb, (uint64_t*)(w + pl.off_keys));
+            else
+                hipLaunchKernelGGL(exact_keys_batch_kernel<false>, dim3(grid_rows), dim3(256), keys_lds, stream,
+                                   (const uint16_t*)slab_f16, N, d, qb, nb, (uint64_t*)(w + pl.off_keys));
+            for (int pass = 0; pass < EXACT_PASSES; ++pass)
+                hipLaunchKernelGGL(exact_hist_kernel, dim3(grid, nb), dim3(256), 0, stream,
+                                   (const uint64_t*)(w + pl.off_keys), N, k, pass, (uint32_t*)(w + pl.off_state));
+            hipLaunchKernelGGL(exact_collect_kernel, dim3(grid, nb), dim3(256), 0, stream,
+                               (const uint64_t*)(w + pl.off_keys), N, k, (uint32_t*)(w + pl.off_state),
+                               (uint64_t*)(w + pl.off_sel));
+            hipLaunchKernelGGL(exact_emit_kernel, dim3(nb), dim3(256), 0, stream, (const uint64_t*)(w + pl.off_sel),
+                               (const uint32_t*)(w + pl.off_state), k,
+                               (uint16_t*)out_score_f16 + (size_t)(q0 + j0) * k, out_idx + (size_t)(q0 + j0) * k);
         }
     }
     return (int)hipGetLastError();

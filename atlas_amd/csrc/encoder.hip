@@ -34,6 +34,10 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef ATLAS_TUNING
+#define ATLAS_TUNING 0
+#endif
+
 #include "common.h"
 #include "../../include/atlas_hip.h"
 
@@ -925,7 +929,7 @@ gemm_ms_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 }
 
 // GEMM configurations. The encoder picks by worst-case token slots n * L: > 16384 -> 4, > 4096 -> 0, else 3;
-// ATLAS_GEMM_CFG=<n> forces one (tuning and the bit-equality test: every configuration gives the same bits).
+// the tuning build's atlas_tune_set_gemm_cfg(n) forces one (tuning and the bit-equality test: every configuration gives the same bits).
 //   4  gemm_pp_kernel  256 x 256, ping-pong schedule, LDS epilogue          (index refresh; FFN-1 of the 16-bit dtypes goes to 6)
 //   6  gemm_co_kernel  256 x 128, two co-resident workgroups per CU         (16-bit dtypes; every GEMM when forced)
 //   7  gemm_pp_kernel  for every GEMM                                        (A/B reference for the 4 / 6 split)
@@ -933,8 +937,15 @@ gemm_ms_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 //   0  gemm_bt_kernel  128 x 128
 //   3  gemm_ms_kernel  64 x 64, 3 (16-bit) / 4 (fp32) LDS-DMA stages        (query batches)
 //   5  gemm_bt_kernel  64 x 64, single stage                                (A/B reference for 3)
-unsigned long long* g_gemm_dbg = nullptr;    // tuning hook (atlas_dbg_set_gemm_stamps); never set in production
-int g_gemm_diag = 0;                         // tuning hook (atlas_dbg_set_gemm_diag); never set in production
+#if ATLAS_TUNING
+unsigned long long* g_gemm_dbg = nullptr;    // atlas_tune_set_gemm_stamps
+int g_gemm_diag = 0;                         // atlas_tune_set_gemm_diag
+int g_gemm_cfg = -1;                         // atlas_tune_set_gemm_cfg: -1 = by size (what the product library always does)
+#else
+constexpr unsigned long long* g_gemm_dbg = nullptr;
+constexpr int g_gemm_diag = 0;
+constexpr int g_gemm_cfg = -1;
+#endif
 
 template <class T, int EPI>
 static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, const typename T::elem* W, const typename T::elem* bias,
@@ -1393,8 +1404,7 @@ int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int
     const unsigned tok_blocks = (unsigned)((M + 3) / 4), pas_blocks = (unsigned)((n + 3) / 4);
     // configuration table: see launch_gemm. Small batches (queries) need more, smaller tiles to cover the 256 CUs: 64 queries
     // x ~20 tokens are 21 x 12 tiles of 64x64 for a 768-wide GEMM
-    const char* cfg_env = getenv("ATLAS_GEMM_CFG");
-    const int cfg = cfg_env ? atoi(cfg_env) : (M > 16384 ? 4 : (M > 4096 ? 0 : 3));
+    const int cfg = g_gemm_cfg >= 0 ? g_gemm_cfg : (M > 16384 ? 4 : (M > 4096 ? 0 : 3));
     hipLaunchKernelGGL(count_kernel, dim3(pas_blocks), dim3(256), 0, stream, attention_mask, n, L, counts);
     hipLaunchKernelGGL(pack_kernel, dim3(pas_blocks), dim3(256), 0, stream, attention_mask, n, L, counts, cu, tokinfo);
     hipLaunchKernelGGL(embed_ln_kernel<T>, dim3(tok_blocks), dim3(256), 0, stream, input_ids, token_type_ids, L, cu, n, tokinfo,
@@ -1438,8 +1448,12 @@ int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int
 
 extern "C" {
 
-void atlas_dbg_set_gemm_stamps(unsigned long long* p) { g_gemm_dbg = p; }   // tuning hook, not part of include/atlas_hip.h
-void atlas_dbg_set_gemm_diag(int d) { g_gemm_diag = d; }                     // tuning hook, not part of include/atlas_hip.h
+#if ATLAS_TUNING
+// tuning build only (libatlas_hip_tune.so; not part of include/atlas_hip.h)
+void atlas_tune_set_gemm_stamps(unsigned long long* p) { g_gemm_dbg = p; }
+void atlas_tune_set_gemm_diag(int d) { g_gemm_diag = d; }
+void atlas_tune_set_gemm_cfg(int c) { g_gemm_cfg = c; }
+#endif
 
 size_t atlas_contriever_workspace_bytes(int n, int L, int dtype) {
     if (n <= 0 || L <= 0) return 0;

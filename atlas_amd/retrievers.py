@@ -112,6 +112,7 @@ class Contriever(nn.Module):
         self.encoder = _Encoder(self.config)
         self._packed = None          # (key, BertWeights struct, tensors kept alive)
         self._ws = None
+        self._library = None         # tests / tools only: a handle of the tuning build (_lib.lib(tuning=True)) instead of the product library
 
     @classmethod
     def from_pretrained(cls, path, pooling="average", **kwargs):
@@ -216,7 +217,7 @@ class Contriever(nn.Module):
         the all-padding tail columns first (one host sync): the launch grids and the GEMM tile shape are sized by
         n*L, which for queries tokenised with padding='max_length' is ~20x the real token count."""
         dtype = self._check_accelerated()
-        L = _lib.lib()
+        L = self._library or _lib.lib()
         n, seq = input_ids.shape
         assert out.dtype == self._out_dtype() and out.is_contiguous() and tuple(out.shape) == (n, EMBEDDINGS_DIM)
         if n == 0:
@@ -262,7 +263,7 @@ class Contriever(nn.Module):
         memo[id(self)] = new
         nn.Module.__init__(new)
         for k, v in self.__dict__.items():
-            if k in ("_packed", "_ws"):
+            if k in ("_packed", "_ws", "_library"):
                 new.__dict__[k] = None
             else:
                 new.__dict__[k] = copy.deepcopy(v, memo)

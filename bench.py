@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="rows of the CPU baseline sample")
     ap.add_argument("--refresh-batches", type=int, default=6, help="timed 512-passage encoder batches for the index-refresh leg (0 = skip)")
     ap.add_argument("--refresh-len", type=int, default=128, help="tokens per passage in the refresh leg")
+    ap.add_argument("--shard-sweep", type=str, default="1000000,4000000", help="prefix sizes of the slab timed like the headline (N=1 only; '' = skip)")
+    ap.add_argument("--oracle-query", type=int, default=31, help="query of the batch held to the CPU oracle at full size in the cpu_baseline leg (-1 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -237,12 +239,70 @@ def main():
                              "padded_token_tflops_equivalent": padded_flops * args.refresh_batches / dtg / 1e12,
                              "mean_len": float(lf.mean())}
 
+    # ---- parity at the size the number is quoted on (outside every timed region): the timed results s0 / i0 against the MFMA-free
+    # exact path for 8 queries spread over the batch -- ids and score bits
+    parity_checked = None
+    if world == 1:
+        sel = torch.tensor(sorted({min(B - 1, j * 9) for j in range(8)}), device=dev)
+        es, ei = index._exact_topk(q[sel], k)
+        assert torch.equal(out_s[sel], es) and torch.equal(out_i[sel], ei), "scan disagrees with the exact path at the benchmark size"
+        parity_checked = {"rows": rows, "queries_exact": int(sel.numel()), "queries_oracle": 0}
+
+    # ---- the shard sizes an 8-GPU run actually scans (4M rows = 32M / 8) and BASELINE configs[1] (1M rows), on the first rows of the
+    # same slab, timed exactly like the headline (same step, same fence, hipEvents around the scan kernel)
+    shard_sweep = None
+    if world == 1 and args.shard_sweep:
+        shard_sweep = {}
+        for n_sub in (int(x) for x in args.shard_sweep.split(",")):
+            if n_sub >= rows:
+                continue
+            sub = HipDistributedIndex()
+            sub._set_slab(slab[:n_sub])
+            sub._compute_scores_and_indices(q, k)                   # certifies pmax for this prefix, sizes its workspace
+            ws_s, pm_s = sub._ws, float(sub._pmax)
+            steps_s = max(args.steps, 50)
+            evs_s = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps_s)]
+            for a, b_ in evs_s:
+                a.record(); b_.record()
+
+            def sub_step(ev=None):
+                rc = L.atlas_scan_topk_ex(q.data_ptr(), _lib.DT_F32, slab.data_ptr(), n_sub, B, D, k, pm_s, out_s.data_ptr(),
+                                          out_i.data_ptr(), out_st.data_ptr(), ws_s.data_ptr(), ws_s.numel(), stream,
+                                          ev[0].cuda_event if ev else None, ev[1].cuda_event if ev else None)
+                assert rc == 0, rc
+
+            for _ in range(max(args.warmup, 5)):
+                sub_step()
+            fence()
+            ts = time.perf_counter()
+            for it in range(steps_s):
+                sub_step(evs_s[it])
+            fence()
+            dts = (time.perf_counter() - ts) / steps_s
+            assert int(out_st.cpu()[_lib.ST_FLAGS]) == 0
+            k_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in evs_s]))
+            nbytes = n_sub * D * 2
+            shard_sweep[str(n_sub)] = {"ms_per_step": dts * 1e3, "queries_per_s": B / dts, "kernel_ms_mean": k_ms,
+                                       "step_frac": nbytes / dts / 1e9 / HBM_PEAK_GBS, "kernel_frac": nbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "steps": steps_s}
+            del sub
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        from oracle import ref_port   # checker/baseline only; never on the product path
+        from oracle import oracle as oracle_checker, ref_port   # checker / baseline only; never on the product path
 
         n = min(args.cpu_sample, rows)
         cpu = ref_port.time_reference_flat(slab[:n].cpu(), q.cpu(), k, args.cpu_seconds, workload_rows=args.passages)
+        # the same leg holds ONE query of the timed batch to the CPU oracle at the full size: the slab is streamed through the
+        # oracle's canonical score in 1M-row chunks (all `rows` scores of that query), then its canonical top-k
+        if args.oracle_query >= 0 and parity_checked is not None:
+            bq = min(args.oracle_query, B - 1)
+            q16 = q[bq].half().cpu().numpy()
+            full = np.concatenate([oracle_checker.score_row(q16, slab[r0 : r0 + 1_000_000].cpu().numpy()) for r0 in range(0, rows, 1_000_000)])
+            es, ei = oracle_checker.topk_row(full, k)
+            assert np.array_equal(es.view(np.uint16), s0[bq].cpu().numpy().view(np.uint16)) and np.array_equal(ei, i0[bq].cpu().numpy()), \
+                "scan disagrees with the CPU oracle at the benchmark size"
+            parity_checked["queries_oracle"] = 1
 
     if rank == 0:
         algo_bytes = rows * D * 2
@@ -251,8 +311,12 @@ def main():
         # size / kernel variant was not profiled
         traffic = None
         try:
+            import hashlib
+
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pmc.get("kernel") == L.atlas_build_info().decode().split()[2]:
+            src = hashlib.sha256(open(os.path.join(ROOT, "atlas_amd", "csrc", "scan_kernel.h"), "rb").read()).hexdigest()
+            # only a PMC pass of THIS scan kernel source counts: a pass of an older kernel says nothing about this one's re-reads
+            if pmc.get("kernel") == L.atlas_build_info().decode().split()[2] and pmc.get("scan_kernel_h_sha256") == src:
                 traffic = pmc["per_rows"].get(str(rows), {}).get("traffic_bytes")
         except Exception:
             traffic = None
@@ -284,7 +348,9 @@ def main():
             },
             "cpu_baseline": cpu,
             "refresh": refresh,
+            "shard_sweep": shard_sweep,
             "detail": {
+                "parity_checked": parity_checked,
                 "sync_call_latency_ms": lat_ms, "candidates_per_search": stats0.get("candidates"),
                 "rescored_per_search": stats0.get("rescored"), "max_err_over_eps": stats0.get("max_err_over_eps"),
                 "build": L.atlas_build_info().decode(),

@@ -11,7 +11,11 @@
  *   - every buffer is caller-owned DEVICE memory unless the name says `host`
  *   - nothing allocates, frees or synchronises; work is enqueued on `stream`
  *     (a hipStream_t passed as void*; NULL = the null stream)
- *   - re-entrant for distinct (stream, workspace) pairs; no mutable global state
+ *   - re-entrant for distinct (stream, workspace) pairs. The library has no mutable global state, reads no
+ *     environment variables and keeps no per-device caches: everything a call needs is in its arguments.
+ *     (Kernel variants, GEMM configurations and cycle stamps can only be selected in the separate TUNING build of
+ *     the same sources, libatlas_hip_tune.so = -DATLAS_TUNING=1, whose atlas_tune_* hooks are process-global and
+ *     are not part of this interface; the product never loads it.)
  *   - return value: 0 = enqueued, >0 = hipError_t from a launch, <0 = ATLAS_E_*
  *
  * Canonical result (what "top-k" means here):
@@ -103,9 +107,12 @@ int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t
 
 /* ---- search: exact reference-order path (any d, any k <= 2048) --------------------
  * Same contract and same canonical result as atlas_scan_topk, computed without MFMA:
- * every score is formed in the canonical double order and selection is exact. Slow
- * (VALU fp64, 2 slab passes); used for queries flagged ATLAS_Q_FALLBACK, for shapes
- * outside the fast path, and as the on-device cross-check in tests.
+ * every score is formed in the canonical double order and selection is exact. Slower than the
+ * scan (fp64 VALU) but bounded: ONE slab pass scores up to 8 queries (one wave per row, the 64 chains of
+ * every query reduced by the canonical tree), then a 6-pass radix select over the 48 significant key
+ * bits per query -- at 32M rows ~15 ms per 8 queries. Used for queries flagged ATLAS_Q_FALLBACK, for
+ * shapes outside the fast path (d <= 8192, k <= 2048), and as the on-device cross-check in tests.
+ * Workspace: 8 keys of 8 bytes per row (atlas_exact_topk_workspace_bytes).
  */
 size_t atlas_exact_topk_workspace_bytes(int64_t N, int B, int d, int k);
 int atlas_exact_topk(const void* q, int q_dtype, const void* slab_f16, int64_t N, int B, int d,

@@ -96,6 +96,18 @@ def search(q_f16, slab_f16, k, return_full=False):
     return out_s.view(np.float16), out_i
 
 
+def score_row(q_f16, slab_f16) -> np.ndarray:
+    """canonical fp16 scores of ONE query against every row of `slab_f16` [N, d] (OpenMP over rows); lets a caller stream a
+    slab that does not fit in host memory through the oracle chunk by chunk and finish with topk_row"""
+    q = _u16(q_f16).reshape(-1)
+    s = _u16(slab_f16)
+    N, d = s.shape
+    assert q.shape[0] == d
+    out = np.empty(N, dtype=np.uint16)
+    lib().oracle_score_row(_p(q, ctypes.c_uint16), _p(s, ctypes.c_uint16), N, d, _p(out, ctypes.c_uint16))
+    return out.view(np.float16)
+
+
 def topk_row(scores_f16, k):
     s = _u16(scores_f16)
     out_s = np.empty(k, dtype=np.uint16)

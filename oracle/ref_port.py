@@ -54,7 +54,8 @@ def time_reference_flat(slab_rows: torch.Tensor, q: torch.Tensor, topk: int, bud
     q32 = q.float()
     med32, runs32 = _time(lambda: torch.topk(torch.matmul(q32, emb32), topk, dim=1), 2, budget_s * 0.2)
     return {
-        "value": q.shape[0] / med * (n / workload_rows), "unit": "queries/s", "cores": cores, "kind": "port",
+        "value": q.shape[0] / med * (n / workload_rows), "unit": "queries/s", "cores": cores,
+        "kind": "port" if n >= workload_rows else f"port, extrapolated from {n} rows",
         "sample": f"first {n} rows of the workload x 768 fp16, {q.shape[0]} queries, top-{topk}; "
                   f"torch.matmul(fp16)+torch.topk (src/index.py:117-118) on the host, median of {runs} runs, "
                   f"{torch.get_num_threads()} threads; value = measured rate x {n}/{workload_rows} rows",

@@ -42,7 +42,7 @@ def test_default_line_carries_cpu_baseline_and_refresh():
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == "queries/s" and c["value"] > 0
+    assert (c["kind"] == "reference" or c["kind"].startswith("port")) and c["cores"] >= 1 and c["unit"] == "queries/s" and c["value"] > 0
     f = d["refresh"]
     assert f["unit"] == "passages/s" and f["roofline"]["bound"] == "mfma" and f["roofline"]["peak"] == 2500.0
     flops = 169.9e6 * f["passage_len"] + 36864.0 * f["passage_len"] ** 2

@@ -180,13 +180,18 @@ def test_bulk_gemm_kernels_agree_bit_for_bit(dtype, gpu_index_cls, monkeypatch):
     ids, mask = _batch(150, 128, seed=31)                    # 19 200 slots -> default configuration = cfg 4
     assert int(mask.sum()) % 256 != 0
     ids, mask = ids.cuda(), mask.cuda()
-    monkeypatch.delenv("ATLAS_GEMM_CFG", raising=False)
-    base = mine(ids, mask)
+    base = mine(ids, mask)                                    # the product library: configuration picked by size
     assert torch.equal(mine(ids, mask), base)
-    for cfg in ("4", "6", "7", "2", "0", "3"):
-        monkeypatch.setenv("ATLAS_GEMM_CFG", cfg)
-        assert torch.equal(mine(ids, mask), base), f"cfg {cfg} differs from the default configuration"
-    monkeypatch.delenv("ATLAS_GEMM_CFG", raising=False)
+    from atlas_amd import _lib
+    T = _lib.lib(tuning=True)                                 # the tuning build of the same sources can force a configuration
+    mine._library = T
+    try:
+        for cfg in (4, 6, 7, 2, 0, 3):
+            T.atlas_tune_set_gemm_cfg(cfg)
+            assert torch.equal(mine(ids, mask), base), f"cfg {cfg} differs from the product library's default configuration"
+    finally:
+        T.atlas_tune_set_gemm_cfg(-1)
+        mine._library = None
     want = ref.cuda()(ids, mask).float().cpu()
     err = (base.float().cpu() - want).abs().max() / want.abs().max()
     tol = {torch.float16: 4e-3, torch.bfloat16: 3e-2, torch.float32: 2e-5}[dtype]

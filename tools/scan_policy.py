@@ -3,6 +3,8 @@ full C-ABI search `reps` times; hipEvents around the scan kernel (atlas_scan_top
 
     python tools/scan_policy.py 4000000 32000000 -- 0 5 6
 """
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _tune import L  # noqa: E402  (tuning build of the library, hooks bound)
 import os
 import sys
 import numpy as np
@@ -36,7 +38,7 @@ B, k, D = 64, 40, 768
 for N in sizes:
     slab = shard(N)
     q = torch.randn((B, D), generator=torch.Generator(device="cuda").manual_seed(99), device="cuda")
-    os.environ["ATLAS_SCAN_VARIANT"] = "0"
+    L.atlas_tune_set_scan_variant(0)
     idx = HipDistributedIndex()
     idx._set_slab(slab)
     s0, i0 = idx._compute_scores_and_indices(q, k)
@@ -51,7 +53,7 @@ for N in sizes:
     torch.cuda.synchronize()
     for rnd in range(rounds):
         for v in variants:
-            os.environ["ATLAS_SCAN_VARIANT"] = str(v)
+            L.atlas_tune_set_scan_variant(int(v))
             name = L.atlas_build_info().decode().split()[2]
             for it in range(3 + reps):
                 ev = evs[it - 3] if it >= 3 else None

@@ -1,10 +1,12 @@
 """per-workgroup cycle stamps of the scan kernel (dev tool): distribution of start-up, loop and end times over the 256 CUs"""
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _tune import L  # noqa: E402  (tuning build of the library, hooks bound)
 import ctypes, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from atlas_amd import HipDistributedIndex, _lib
 import numpy as np
 L = _lib.lib()
-L.atlas_dbg_set_scan_stamps.argtypes = [ctypes.c_void_p]
+L.atlas_tune_set_scan_stamps.argtypes = [ctypes.c_void_p]
 for N in [int(a) for a in sys.argv[1:]] or [4_000_000, 1_000_000]:
     g = torch.Generator(device="cuda").manual_seed(1)
     slab = torch.empty((N, 768), dtype=torch.float16, device="cuda")
@@ -18,9 +20,9 @@ for N in [int(a) for a in sys.argv[1:]] or [4_000_000, 1_000_000]:
     res = []
     for rep in range(5):
         dbg.zero_()
-        L.atlas_dbg_set_scan_stamps(dbg.data_ptr())
+        L.atlas_tune_set_scan_stamps(dbg.data_ptr())
         idx._compute_scores_and_indices(q, 40); torch.cuda.synchronize()
-        L.atlas_dbg_set_scan_stamps(None)
+        L.atlas_tune_set_scan_stamps(None)
         t = dbg.cpu().numpy().reshape(256, 4).astype(np.float64)
         t0 = t[:, 0].min()
         res.append(t - t0)
