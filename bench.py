@@ -183,62 +183,6 @@ def main():
         index._compute_scores_and_indices(q, k)
     lat_ms = (time.perf_counter() - t1) / 5 * 1e3
 
-    # ---- index-refresh leg (second half of BASELINE.json's metric): Contriever-base passage re-embedding, fp16,
-    # synthetic token ids (no vocab on the box), random-init BERT-base weights, batches of 512 (options.py:43-48),
-    # embeddings written straight into the slab rows (atlas.py:79). FLOPs/passage = 169.9e6*L + 36864*L^2 (SURVEY §8d).
-    refresh = None
-    if args.refresh_batches > 0:
-        from atlas_amd import retrievers
-
-        torch.manual_seed(99)
-        enc = retrievers.Contriever(retrievers.BertConfigLite()).half().eval().to(dev).requires_grad_(False)
-        Lr, nb = args.refresh_len, 512
-        g = torch.Generator(device=dev).manual_seed(4321 + rank)
-        ids = torch.randint(1000, 30522, (nb, Lr), generator=g, device=dev)
-        ids[:, 0], ids[:, -1] = 101, 102
-        msk = torch.ones((nb, Lr), dtype=torch.int64, device=dev)
-        tgt = slab[: nb * (args.refresh_batches + 1)].view(-1, nb, D)
-        enc.embed_into(tgt[0], ids, msk)                                  # warm-up (also packs the weights)
-        fence()
-        t2 = time.perf_counter()
-        for i in range(args.refresh_batches):
-            enc.embed_into(tgt[1 + i], ids, msk)
-        fence()
-        dtr = time.perf_counter() - t2
-        if world > 1:
-            dtr = reduce_max(dtr)
-        pps = world * nb * args.refresh_batches / dtr
-        flops_pp = 169.9e6 * Lr + 36864.0 * Lr * Lr
-        refresh = {"metric": "index-refresh passages/sec (Contriever-base re-embed, fp16)", "value": pps, "unit": "passages/s",
-                   "passage_len": Lr, "batch": nb, "batches": args.refresh_batches, "ms_per_batch": dtr / args.refresh_batches * 1e3,
-                   "data": "synthetic token ids, random-init BERT-base weights",
-                   "roofline": {"bound": "mfma", "achieved": pps * flops_pp / world / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-                                "frac": pps * flops_pp / world / 1e12 / 2500.0, "flops_per_passage": flops_pp}}
-        # SURVEY §8d variant (b): ragged passages, lengths uniform in 64..200 padded to the longest of the batch
-        # (padding="longest"); only real tokens are computed, so the real-token FLOPs are what the MFMAs do and the
-        # padded-token FLOPs are what a padded implementation would have spent
-        lens = torch.randint(64, 201, (nb,), generator=g, device=dev)
-        Lg = int(lens.max())
-        idg = torch.randint(1000, 30522, (nb, Lg), generator=g, device=dev)
-        mkg = (torch.arange(Lg, device=dev)[None, :] < lens[:, None]).to(torch.int64)
-        idg = idg * mkg
-        enc.embed_into(tgt[0], idg, mkg)
-        fence()
-        t3 = time.perf_counter()
-        for i in range(args.refresh_batches):
-            enc.embed_into(tgt[1 + i], idg, mkg)
-        fence()
-        dtg = time.perf_counter() - t3
-        if world > 1:
-            dtg = reduce_max(dtg)
-        lf = lens.double()
-        real_flops = float((169.9e6 * lf + 36864.0 * lf * lf).sum())
-        padded_flops = nb * (169.9e6 * Lg + 36864.0 * Lg * Lg)
-        refresh["ragged"] = {"lengths": "uniform 64..200, padded to %d" % Lg, "value": world * nb * args.refresh_batches / dtg, "unit": "passages/s",
-                             "real_token_tflops": real_flops * args.refresh_batches / dtg / 1e12,
-                             "padded_token_tflops_equivalent": padded_flops * args.refresh_batches / dtg / 1e12,
-                             "mean_len": float(lf.mean())}
-
     # ---- parity at the size the number is quoted on (outside every timed region): the timed results s0 / i0 against the MFMA-free
     # exact path for 8 queries spread over the batch -- ids and score bits
     parity_checked = None
@@ -303,6 +247,62 @@ def main():
             assert np.array_equal(es.view(np.uint16), s0[bq].cpu().numpy().view(np.uint16)) and np.array_equal(ei, i0[bq].cpu().numpy()), \
                 "scan disagrees with the CPU oracle at the benchmark size"
             parity_checked["queries_oracle"] = 1
+
+    # ---- index-refresh leg (second half of BASELINE.json's metric): Contriever-base passage re-embedding, fp16,
+    # synthetic token ids (no vocab on the box), random-init BERT-base weights, batches of 512 (options.py:43-48),
+    # embeddings written straight into the slab rows (atlas.py:79). FLOPs/passage = 169.9e6*L + 36864*L^2 (SURVEY §8d).
+    refresh = None
+    if args.refresh_batches > 0:
+        from atlas_amd import retrievers
+
+        torch.manual_seed(99)
+        enc = retrievers.Contriever(retrievers.BertConfigLite()).half().eval().to(dev).requires_grad_(False)
+        Lr, nb = args.refresh_len, 512
+        g = torch.Generator(device=dev).manual_seed(4321 + rank)
+        ids = torch.randint(1000, 30522, (nb, Lr), generator=g, device=dev)
+        ids[:, 0], ids[:, -1] = 101, 102
+        msk = torch.ones((nb, Lr), dtype=torch.int64, device=dev)
+        tgt = slab[: nb * (args.refresh_batches + 1)].view(-1, nb, D)
+        enc.embed_into(tgt[0], ids, msk)                                  # warm-up (also packs the weights)
+        fence()
+        t2 = time.perf_counter()
+        for i in range(args.refresh_batches):
+            enc.embed_into(tgt[1 + i], ids, msk)
+        fence()
+        dtr = time.perf_counter() - t2
+        if world > 1:
+            dtr = reduce_max(dtr)
+        pps = world * nb * args.refresh_batches / dtr
+        flops_pp = 169.9e6 * Lr + 36864.0 * Lr * Lr
+        refresh = {"metric": "index-refresh passages/sec (Contriever-base re-embed, fp16)", "value": pps, "unit": "passages/s",
+                   "passage_len": Lr, "batch": nb, "batches": args.refresh_batches, "ms_per_batch": dtr / args.refresh_batches * 1e3,
+                   "data": "synthetic token ids, random-init BERT-base weights",
+                   "roofline": {"bound": "mfma", "achieved": pps * flops_pp / world / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                                "frac": pps * flops_pp / world / 1e12 / 2500.0, "flops_per_passage": flops_pp}}
+        # SURVEY §8d variant (b): ragged passages, lengths uniform in 64..200 padded to the longest of the batch
+        # (padding="longest"); only real tokens are computed, so the real-token FLOPs are what the MFMAs do and the
+        # padded-token FLOPs are what a padded implementation would have spent
+        lens = torch.randint(64, 201, (nb,), generator=g, device=dev)
+        Lg = int(lens.max())
+        idg = torch.randint(1000, 30522, (nb, Lg), generator=g, device=dev)
+        mkg = (torch.arange(Lg, device=dev)[None, :] < lens[:, None]).to(torch.int64)
+        idg = idg * mkg
+        enc.embed_into(tgt[0], idg, mkg)
+        fence()
+        t3 = time.perf_counter()
+        for i in range(args.refresh_batches):
+            enc.embed_into(tgt[1 + i], idg, mkg)
+        fence()
+        dtg = time.perf_counter() - t3
+        if world > 1:
+            dtg = reduce_max(dtg)
+        lf = lens.double()
+        real_flops = float((169.9e6 * lf + 36864.0 * lf * lf).sum())
+        padded_flops = nb * (169.9e6 * Lg + 36864.0 * Lg * Lg)
+        refresh["ragged"] = {"lengths": "uniform 64..200, padded to %d" % Lg, "value": world * nb * args.refresh_batches / dtg, "unit": "passages/s",
+                             "real_token_tflops": real_flops * args.refresh_batches / dtg / 1e12,
+                             "padded_token_tflops_equivalent": padded_flops * args.refresh_batches / dtg / 1e12,
+                             "mean_len": float(lf.mean())}
 
     if rank == 0:
         algo_bytes = rows * D * 2

@@ -60,6 +60,7 @@ class _Embeddings(nn.Module):
         self.position_embeddings = nn.Embedding(c.max_position_embeddings, c.hidden_size)
         self.token_type_embeddings = nn.Embedding(c.type_vocab_size, c.hidden_size)
         self.LayerNorm = BertLayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+        self.register_buffer("position_ids", torch.arange(c.max_position_embeddings).expand((1, -1)))   # modeling_bert.py:205 (persistent)
 
     def forward(self, input_ids, token_type_ids=None):      # modeling_bert.py:213-247
         L = input_ids.shape[1]

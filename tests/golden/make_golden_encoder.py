@@ -80,7 +80,7 @@ def main():
         model = ref.Contriever(config)
         bind_4_18(model)
         sd = synth_encoder.state_dict(case)
-        missing = model.load_state_dict(sd, strict=False)
+        missing = model.load_state_dict(sd, strict=True)
         assert not missing.unexpected_keys, missing
         assert all("position_ids" in k for k in missing.missing_keys), missing      # (a registered buffer, not a parameter)
         model.eval()

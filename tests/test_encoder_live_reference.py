@@ -39,7 +39,8 @@ def test_restatement_is_bit_identical_to_the_reference_run_live(layers, n, L, se
             if "LayerNorm" in name:
                 p.add_(0.1 * torch.randn_like(p))
     mine = ContrieverRef(BertConfigLite(vocab_size=vocab, num_hidden_layers=layers)).eval()
-    sd = {k: v for k, v in model.state_dict().items() if "position_ids" not in k}
+    sd = model.state_dict()
+    assert "embeddings.position_ids" in sd                  # the persistent buffer every Atlas checkpoint carries (modeling_bert.py:205)
     r = mine.load_state_dict(sd, strict=True)
     assert not r.missing_keys and not r.unexpected_keys
     g = torch.Generator().manual_seed(100 + seed)

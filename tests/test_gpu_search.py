@@ -307,7 +307,7 @@ def test_duplicated_passages_at_1m_stay_bounded(big, gpu_index_cls):
     idx, slab, q = big
     dup = slab.clone()
     rows = torch.arange(200_000, 210_000, device="cuda")
-    dup[rows] = dup[77]
+    dup[rows] = dup[77].clone()
     qq = q.clone()
     qq[:24] = dup[77].float()[None, :] * (1.0 + torch.arange(24, device="cuda")[:, None] * 0.01)    # 24 queries whose best match is the copy
     sh = gpu_index_cls()
