@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_SO = os.environ.get("ATLAS_HIP_SO") or os.path.join(HERE, "lib", "libatlas_hip.so")   # ATLAS_HIP_SO: A/B runs of two builds (dev)
 TUNE_SO = os.path.join(HERE, "lib", "libatlas_hip_tune.so")   # the -DATLAS_TUNING=1 build: lib(tuning=True), tools/ and configuration tests only
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 DT_F16, DT_F32, DT_BF16 = 0, 1, 2
 STATUS_HEADER = 8
 ST_FLAGS, ST_PMAX_BITS, ST_N_FALLBACK, ST_N_CANDIDATES, ST_N_RESCORED, ST_MAXERR_BITS = 0, 1, 2, 3, 4, 5
@@ -26,7 +26,7 @@ SYMBOLS = [
     "atlas_exact_topk_workspace_bytes", "atlas_exact_topk",
     "atlas_pack_candidates", "atlas_merge_packed",
     "atlas_pool_write", "atlas_slab_pmax",
-    "atlas_contriever_workspace_bytes", "atlas_contriever_embed",
+    "atlas_contriever_workspace_bytes", "atlas_contriever_embed", "atlas_contriever_embed_rows",
 ]
 
 BERT_MAX_LAYERS = 24
@@ -105,6 +105,8 @@ def _bind(path):
     L.atlas_contriever_workspace_bytes.argtypes = [i32, i32, i32]
     L.atlas_contriever_embed.restype = i32
     L.atlas_contriever_embed.argtypes = [ctypes.POINTER(BertWeights), vp, vp, vp, i32, i32, vp, vp, sz, vp]
+    L.atlas_contriever_embed_rows.restype = i32
+    L.atlas_contriever_embed_rows.argtypes = [ctypes.POINTER(BertWeights), vp, vp, vp, i32, i32, vp, vp, vp, sz, vp]
     L.atlas_slab_pmax.restype = i32
     L.atlas_slab_pmax.argtypes = [vp, i64, i32, vp, vp]
     if L.atlas_abi_version() != ABI_VERSION:

@@ -1342,15 +1342,16 @@ attention_f32_kernel(const float* __restrict__ qk, const float* __restrict__ vt,
 template <class T>
 __global__ void __launch_bounds__(192)
 pool_packed_kernel(const typename T::elem* __restrict__ x, const int* __restrict__ cu, const int2* __restrict__ tokinfo, int mode,
-                   void* __restrict__ out_) {
+                   void* __restrict__ out_, const int64_t* __restrict__ out_rows /* nullable: row of `out` that passage b goes to */) {
     const int b = blockIdx.x;
+    const int64_t ob = out_rows ? out_rows[b] : (int64_t)b;
     const int tb = cu[b], L = cu[b + 1] - tb;
     const typename T::elem* base = x + (size_t)tb * HID + threadIdx.x * 4;
     if (mode == ATLAS_POOL_CLS) {
         // last_hidden[:, 0] after masked_fill (retrievers.py:50, 55-56): position 0 is the first packed token if unmasked
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (L > 0 && tokinfo[tb].y == 0) load4<T>(base, v);
-        store4<T>((typename T::elem*)out_ + (size_t)b * HID + threadIdx.x * 4, v);
+        store4<T>((typename T::elem*)out_ + (size_t)ob * HID + threadIdx.x * 4, v);
         return;
     }
     double s[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1371,9 +1372,9 @@ pool_packed_kernel(const typename T::elem* __restrict__ x, const int* __restrict
         o[r] = (mode == ATLAS_POOL_SQRT) ? sum / sqrtf(cnt) : sum / cnt;              // retrievers.py:53-54 / :51-52
     }
     if (mode == ATLAS_POOL_SQRT)     // dtype tensor / fp32 tensor promotes: the reference returns fp32 here
-        *(float4*)((float*)out_ + (size_t)b * HID + threadIdx.x * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        *(float4*)((float*)out_ + (size_t)ob * HID + threadIdx.x * 4) = make_float4(o[0], o[1], o[2], o[3]);
     else
-        store4<T>((typename T::elem*)out_ + (size_t)b * HID + threadIdx.x * 4, o);
+        store4<T>((typename T::elem*)out_ + (size_t)ob * HID + threadIdx.x * 4, o);
 }
 
 // ==========================================================================================
@@ -1385,7 +1386,7 @@ inline size_t esize(int dt) { return dt == ATLAS_DT_F32 ? 4 : 2; }
 
 template <class T>
 int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids,
-                int n, int L, void* out, void* ws, hipStream_t stream) {
+                int n, int L, void* out, const int64_t* out_rows, void* ws, hipStream_t stream) {
     typedef typename T::elem E;
     const size_t es = sizeof(E);
     const int64_t M = (int64_t)n * L;                 // worst case; the packed count lives on the device (cu[n])
@@ -1441,7 +1442,7 @@ int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int
                            w->eps, x);
     }
     // rows written contiguously at out (which may point into the passage slab: slab + row_offset * 768)
-    hipLaunchKernelGGL(pool_packed_kernel<T>, dim3((unsigned)n), dim3(192), 0, stream, x, cu, tokinfo, w->pooling, out);
+    hipLaunchKernelGGL(pool_packed_kernel<T>, dim3((unsigned)n), dim3(192), 0, stream, x, cu, tokinfo, w->pooling, out, out_rows);
     return (int)hipGetLastError();
 }
 }  // namespace
@@ -1466,6 +1467,12 @@ size_t atlas_contriever_workspace_bytes(int n, int L, int dtype) {
 int atlas_contriever_embed(const atlas_bert_weights* w, const int64_t* input_ids, const int64_t* attention_mask,
                            const int64_t* token_type_ids, int n, int L, void* out, void* ws, size_t ws_bytes,
                            void* stream_) {
+    return atlas_contriever_embed_rows(w, input_ids, attention_mask, token_type_ids, n, L, out, nullptr, ws, ws_bytes, stream_);
+}
+
+int atlas_contriever_embed_rows(const atlas_bert_weights* w, const int64_t* input_ids, const int64_t* attention_mask,
+                                const int64_t* token_type_ids, int n, int L, void* out, const int64_t* out_rows, void* ws,
+                                size_t ws_bytes, void* stream_) {
     if (!w || !input_ids || !attention_mask || !out || !ws) return ATLAS_E_BADARG;
     if (n <= 0 || L <= 0) return ATLAS_E_BADARG;
     if (L > 512 || w->hidden != HID || w->n_heads != NHEAD || w->intermediate != 4 * HID || w->n_layers < 1 ||
@@ -1476,9 +1483,9 @@ int atlas_contriever_embed(const atlas_bert_weights* w, const int64_t* input_ids
     if (w->vocab_size < 1 || w->type_vocab < 1 || w->max_positions < 1 || L > w->max_positions) return ATLAS_E_BADARG;
     if (ws_bytes < atlas_contriever_workspace_bytes(n, L, w->dtype)) return ATLAS_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
-    if (w->dtype == ATLAS_DT_F16) return run_encoder<F16>(w, input_ids, attention_mask, token_type_ids, n, L, out, ws, stream);
-    if (w->dtype == ATLAS_DT_BF16) return run_encoder<BF16>(w, input_ids, attention_mask, token_type_ids, n, L, out, ws, stream);
-    return run_encoder<F32>(w, input_ids, attention_mask, token_type_ids, n, L, out, ws, stream);
+    if (w->dtype == ATLAS_DT_F16) return run_encoder<F16>(w, input_ids, attention_mask, token_type_ids, n, L, out, out_rows, ws, stream);
+    if (w->dtype == ATLAS_DT_BF16) return run_encoder<BF16>(w, input_ids, attention_mask, token_type_ids, n, L, out, out_rows, ws, stream);
+    return run_encoder<F32>(w, input_ids, attention_mask, token_type_ids, n, L, out, out_rows, ws, stream);
 }
 
 }  // extern "C"

@@ -1,14 +1,41 @@
 """Streamed index refresh: the loop of `Atlas.build_index` (src/atlas.py:61-88) as a two-stream pipeline.
 
-The reference tokenises a batch, moves it to the GPU, runs the fp16 retriever copy and scatters the embeddings into
-`index.embeddings[:, a:b]`, one batch after the other. Here tokenised batches (host tensors) are staged through pinned
-buffers and copied on a COPY stream while the encoder works on the previous batch on the compute stream; the pooled rows
-are written straight into the slab (`Contriever.embed_into`), and the host only blocks when all staging slots are in
-flight. Nothing is synchronised per batch.
+The reference formats + tokenises a batch on the host, moves it to the GPU, runs the fp16 retriever copy and scatters the
+embeddings into `index.embeddings[:, a:b]`, one batch after the other, on every refresh. Here
+
+  * the token ids come from a `TokenStore` built once (atlas_amd/token_store.py: same tokenizer call incl. the sic max_length,
+    pinned host memory, length-bucketed batches);
+  * batches are staged through pinned buffers and copied on a COPY stream while the encoder works on the previous batch on the
+    compute stream; the host only blocks when all staging slots are in flight, nothing is synchronised per batch;
+  * the pooled rows are written straight into the slab rows they belong to (`Contriever.embed_into(..., out_rows=)`);
+  * the fp16 inference copy is refreshed IN PLACE from the training weights (`HalfMirror`) instead of
+    `copy.deepcopy(retriever).half()` allocating 110M parameters anew for every refresh (atlas.py:54-59).
+
+`build_index_streamed` has the signature of `Atlas.build_index` and can be bound in its place.
 """
-from typing import Iterable, Tuple
+import copy
+from typing import Iterable, Optional, Tuple
 
 import torch
+
+from . import dist_utils
+from .token_store import TokenStore
+
+
+class HalfMirror:
+    """A persistent `.half().eval()` copy of a retriever whose parameters are re-cast in place before each refresh."""
+
+    def __init__(self, retriever: torch.nn.Module):
+        src = retriever.module if hasattr(retriever, "module") else retriever          # DDP / ShardedDDP (atlas.py:55-58)
+        self.copy = copy.deepcopy(src).half().eval().requires_grad_(False)
+
+    @torch.no_grad()
+    def sync(self, retriever: torch.nn.Module) -> torch.nn.Module:
+        src = retriever.module if hasattr(retriever, "module") else retriever
+        for (name_d, dst), (name_s, s) in zip(self.copy.named_parameters(), src.named_parameters()):
+            assert name_d == name_s and dst.shape == s.shape, (name_d, name_s)
+            dst.copy_(s)                                                                  # fp32 -> fp16 on the device, RNE = .half()
+        return self.copy
 
 
 class IndexRefresher:
@@ -18,41 +45,110 @@ class IndexRefresher:
         self.index, self.enc = index, contriever_fp16
         self.dev = index._slab.device
         self.copy_stream = torch.cuda.Stream(device=self.dev)
-        self.depth = depth
+        self.depth, self.max_batch, self.max_len = depth, max_batch, max_len
         mk = lambda: torch.empty((max_batch, max_len), dtype=torch.int64).pin_memory()     # noqa: E731
-        self._pin = [(mk(), mk()) for _ in range(depth)]
+        self._pin = [(mk(), mk(), torch.empty(max_batch, dtype=torch.int64).pin_memory()) for _ in range(depth)]
         self._dev = [(torch.empty((max_batch, max_len), dtype=torch.int64, device=self.dev),
-                      torch.empty((max_batch, max_len), dtype=torch.int64, device=self.dev)) for _ in range(depth)]
+                      torch.empty((max_batch, max_len), dtype=torch.int64, device=self.dev),
+                      torch.empty(max_batch, dtype=torch.int64, device=self.dev)) for _ in range(depth)]
         self._ready = [torch.cuda.Event() for _ in range(depth)]      # H2D of the slot finished
         self._free = [torch.cuda.Event() for _ in range(depth)]       # encoder finished reading the slot
         self._used = [False] * depth
+        self._turn = 0
+
+    def _slot(self) -> int:
+        s = self._turn % self.depth
+        self._turn += 1
+        if self._used[s]:
+            self._free[s].synchronize()                                # only when `depth` batches are already in flight
+        return s
+
+    def _launch(self, s: int, n: int, L: int, rows: Optional[bool], row_offset: int = 0) -> None:
+        """H2D of slot s on the copy stream, then the encoder on the compute stream, rows written into the slab"""
+        compute = torch.cuda.current_stream(self.dev)
+        pi, pm, pr = self._pin[s]
+        di, dm, dr = self._dev[s]
+        with torch.cuda.stream(self.copy_stream):
+            ids_d = di.view(-1)[: n * L].view(n, L)                    # contiguous [n, L] views of the staging buffers
+            mask_d = dm.view(-1)[: n * L].view(n, L)
+            ids_d.copy_(pi.view(-1)[: n * L].view(n, L), non_blocking=True)
+            mask_d.copy_(pm.view(-1)[: n * L].view(n, L), non_blocking=True)
+            if rows:
+                dr[:n].copy_(pr[:n], non_blocking=True)
+            self._ready[s].record(self.copy_stream)
+        compute.wait_event(self._ready[s])
+        if rows:
+            self.enc.embed_into(self.index._slab, ids_d, mask_d, out_rows=dr[:n])
+        else:
+            self.enc.embed_into(self.index._slab[row_offset: row_offset + n], ids_d, mask_d)
+        self._free[s].record(compute)
+        self._used[s] = True
 
     @torch.no_grad()
     def run(self, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], row_offset: int = 0) -> int:
         """batches: (input_ids, attention_mask) host tensors [n, L] (n <= max_batch, L <= max_len), in slab row order
         starting at row_offset. Returns the number of rows written. Asynchronous: call torch.cuda.synchronize() (or use
         the slab on the current stream) afterwards."""
-        compute = torch.cuda.current_stream(self.dev)
         row = row_offset
-        for i, (ids, mask) in enumerate(batches):
-            s = i % self.depth
+        for ids, mask in batches:
+            s = self._slot()
             n, L = ids.shape
-            if self._used[s]:
-                self._free[s].synchronize()                            # only when `depth` batches are already in flight
-            pi, pm = self._pin[s]
-            pi[:n, :L].copy_(ids)
-            pm[:n, :L].copy_(mask)
-            di, dm = self._dev[s]
-            with torch.cuda.stream(self.copy_stream):
-                ids_d = di.view(-1)[: n * L].view(n, L)                # contiguous [n, L] views of the staging buffers
-                mask_d = dm.view(-1)[: n * L].view(n, L)
-                ids_d.copy_(pi[:n, :L], non_blocking=True)
-                mask_d.copy_(pm[:n, :L], non_blocking=True)
-                self._ready[s].record(self.copy_stream)
-            compute.wait_event(self._ready[s])
-            self.enc.embed_into(self.index._slab[row: row + n], ids_d, mask_d)
-            self._free[s].record(compute)
-            self._used[s] = True
+            pi, pm, _ = self._pin[s]
+            pi.view(-1)[: n * L].view(n, L).copy_(ids)
+            pm.view(-1)[: n * L].view(n, L).copy_(mask)
+            self._launch(s, n, L, rows=False, row_offset=row)
             row += n
         self.index._pmax = None                                        # row norms changed: re-certify on the next search
         return row - row_offset
+
+    @torch.no_grad()
+    def run_store(self, store: TokenStore, batch_size: Optional[int] = None, bucket: bool = True, repeat: int = 1) -> int:
+        """One refresh of the whole shard from a token store (`repeat` > 1: back-to-back refreshes, for sustained-rate timing).
+        Row r of the slab receives the embedding of passage r of the store. Asynchronous like `run`."""
+        batch_size = batch_size or self.max_batch
+        assert batch_size <= self.max_batch and store.max_length <= self.max_len and len(store) == self.index._slab.shape[0]
+        plan = store.plan(batch_size, bucket)
+        for _ in range(repeat):
+            for rows in plan:
+                s = self._slot()
+                pi, pm, pr = self._pin[s]
+                L = store.fill(rows, pi, pm)
+                pr[: rows.shape[0]].copy_(torch.from_numpy(rows))
+                self._launch(s, int(rows.shape[0]), L, rows=True)
+        self.index._pmax = None
+        return len(store) * repeat
+
+
+@torch.no_grad()
+def build_index_streamed(self, index, passages, gpu_embedder_batch_size, logger=None):
+    """`Atlas.build_index` (src/atlas.py:61-88) with the streamed refresh underneath; `self` is the Atlas module
+    (`Atlas.build_index = atlas_amd.refresh.build_index_streamed`, or `types.MethodType(build_index_streamed, model)`).
+
+    First call: tokenises `passages` once into a TokenStore and builds the persistent fp16 mirror of the retriever; every later
+    call re-casts the weights in place and streams the stored tokens. Same slab as the reference's loop run on the same encoder."""
+    state = index.__dict__.setdefault("_refresh_state", {})
+    if state.get("n") != len(passages) or state.get("passages_id") != id(passages):
+        state.clear()
+        state["store"] = TokenStore.from_passages(passages, self.retriever_tokenizer, self.opt.retriever_format, self.opt.text_maxlength,
+                                                  gpu_embedder_batch_size)
+        state["n"], state["passages_id"] = len(passages), id(passages)
+    if "mirror" not in state:
+        state["mirror"] = HalfMirror(self.retriever)
+    half = state["mirror"].sync(self.retriever)
+    encoder = getattr(half, half.passage_role) if hasattr(half, "passage_role") else half
+    store = state["store"]
+    if len(store):
+        if state.get("refresher_key") != (id(encoder), gpu_embedder_batch_size):
+            state["refresher"] = IndexRefresher(index, encoder, gpu_embedder_batch_size, max(store.max_length, 1))
+            state["refresher_key"] = (id(encoder), gpu_embedder_batch_size)
+        index._check_slab()
+        state["refresher"].index = index
+        total = state["refresher"].run_store(store, gpu_embedder_batch_size)
+        torch.cuda.current_stream(index._slab.device).synchronize()
+    else:
+        total = 0
+    dist_utils.barrier()
+    if logger is not None:
+        logger.info(f"{total} passages encoded on process: {dist_utils.get_rank()}")
+    if not index.is_index_trained():
+        index.train_index()

@@ -209,9 +209,10 @@ class Contriever(nn.Module):
         return torch.float32 if self.config.pooling == "sqrt" else self.embeddings.word_embeddings.weight.dtype
 
     def embed_into(self, out: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor, token_type_ids=None,
-                   trim_padding=False):
+                   trim_padding=False, out_rows: torch.Tensor = None):
         """Encode a batch and write the (n, 768) embeddings (model dtype) into `out` (contiguous rows; for the
         fp16 copy it may be a slice of the index slab, which fuses atlas.py:79 into the pooling epilogue).
+        With `out_rows` (int64 [n] on the device) `out` is the whole (N, 768) destination and passage b lands in row out_rows[b].
 
         Only unmasked tokens are computed (packed on the device, no host sync). trim_padding=True additionally cuts
         the all-padding tail columns first (one host sync): the launch grids and the GEMM tile shape are sized by
@@ -219,7 +220,11 @@ class Contriever(nn.Module):
         dtype = self._check_accelerated()
         L = self._library or _lib.lib()
         n, seq = input_ids.shape
-        assert out.dtype == self._out_dtype() and out.is_contiguous() and tuple(out.shape) == (n, EMBEDDINGS_DIM)
+        assert out.dtype == self._out_dtype() and out.is_contiguous() and out.shape[1] == EMBEDDINGS_DIM
+        if out_rows is None:
+            assert out.shape[0] == n
+        else:
+            assert out_rows.dtype == torch.int64 and out_rows.is_cuda and out_rows.numel() == n and out_rows.is_contiguous()
         if n == 0:
             return out
         if trim_padding:
@@ -236,8 +241,9 @@ class Contriever(nn.Module):
             self._ws = None
             self._ws = torch.empty(int(need), dtype=torch.uint8, device=ids.device)
         stream = torch.cuda.current_stream(ids.device).cuda_stream
-        _lib.check(L.atlas_contriever_embed(ctypes.byref(w), ids.data_ptr(), mask.data_ptr(), tt.data_ptr() if tt is not None else None,
-                                            n, seq, out.data_ptr(), self._ws.data_ptr(), self._ws.numel(), stream),
+        _lib.check(L.atlas_contriever_embed_rows(ctypes.byref(w), ids.data_ptr(), mask.data_ptr(), tt.data_ptr() if tt is not None else None,
+                                                 n, seq, out.data_ptr(), out_rows.data_ptr() if out_rows is not None else None,
+                                                 self._ws.data_ptr(), self._ws.numel(), stream),
                    "atlas_contriever_embed")
         return out
 

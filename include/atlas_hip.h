@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ATLAS_ABI_VERSION 4
+#define ATLAS_ABI_VERSION 5
 
 /* negative return codes */
 #define ATLAS_E_BADARG     (-1)  /* null pointer, B<=0, k<=0, d unsupported ...        */
@@ -184,6 +184,12 @@ size_t atlas_contriever_workspace_bytes(int n, int L, int dtype);
 int atlas_contriever_embed(const atlas_bert_weights* w /* host struct of device pointers */, const int64_t* input_ids,
                            const int64_t* attention_mask, const int64_t* token_type_ids, int n, int L, void* out,
                            void* ws, size_t ws_bytes, void* stream);
+/* The same with a row map: passage b of the batch is written to out[out_rows[b]] (out_rows: int64 [n] on the device; NULL = b).
+ * `out` is then the BASE of the destination (the passage slab): a refresh that batches passages by length instead of by position
+ * (atlas_amd/token_store.py) still lands every embedding in its own slab row, inside the pooling epilogue (src/atlas.py:79). */
+int atlas_contriever_embed_rows(const atlas_bert_weights* w, const int64_t* input_ids, const int64_t* attention_mask,
+                                const int64_t* token_type_ids, int n, int L, void* out, const int64_t* out_rows, void* ws,
+                                size_t ws_bytes, void* stream);
 
 /* ---- slab statistics ------------------------------------------------------------
  * out_pmax (device float): max L2 norm over rows [0,N). One streaming pass; lets a caller
