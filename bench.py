@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="rows of the CPU baseline sample")
     ap.add_argument("--refresh-batches", type=int, default=6, help="timed 512-passage encoder batches for the index-refresh leg (0 = skip)")
     ap.add_argument("--refresh-len", type=int, default=128, help="tokens per passage in the refresh leg")
+    ap.add_argument("--refresh-stream-seconds", type=float, default=2.0, help="sustained streamed-refresh leg from the token store (0 = skip)")
     ap.add_argument("--shard-sweep", type=str, default="1000000,4000000", help="prefix sizes of the slab timed like the headline (N=1 only; '' = skip)")
     ap.add_argument("--oracle-query", type=int, default=31, help="query of the batch held to the CPU oracle at full size in the cpu_baseline leg (-1 = skip)")
     args = ap.parse_args()
@@ -303,6 +304,43 @@ def main():
                              "real_token_tflops": real_flops * args.refresh_batches / dtg / 1e12,
                              "padded_token_tflops_equivalent": padded_flops * args.refresh_batches / dtg / 1e12,
                              "mean_len": float(lf.mean())}
+        # the same ragged workload STREAMED -- token ids in a pinned host store built once (atlas_amd/token_store.py),
+        # length-bucketed batches staged through pinned buffers, H2D on a copy stream under the encoder, rows written into their slab
+        # rows by the pooling epilogue. Timed over whole refreshes incl. the host work and the H2D copies, >= --refresh-stream-seconds.
+        if args.refresh_stream_seconds > 0:
+            from atlas_amd import refresh as refresh_mod
+            from atlas_amd.token_store import TokenStore
+
+            n_s = nb * 32
+            rs = np.random.default_rng(4321 + rank)
+            lens_s = rs.integers(64, 201, size=n_s)
+            off = np.zeros(n_s + 1, dtype=np.int64)
+            np.cumsum(lens_s, out=off[1:])
+            store = TokenStore(torch.from_numpy(rs.integers(1000, 30522, size=int(off[-1])).astype(np.int32)), off, 200)
+            sub = HipDistributedIndex()
+            sub._set_slab(slab[:n_s])
+            rf = refresh_mod.IndexRefresher(sub, enc, max_batch=nb, max_len=200, depth=3)
+            rf.run_store(store, nb)                                     # warm-up refresh
+            fence()
+            t_one = time.perf_counter()
+            rf.run_store(store, nb)
+            fence()
+            t_one = time.perf_counter() - t_one
+            reps = max(1, int(np.ceil(args.refresh_stream_seconds / t_one)))
+            t4 = time.perf_counter()
+            rf.run_store(store, nb, repeat=reps)
+            fence()
+            dts = time.perf_counter() - t4
+            if world > 1:
+                dts = reduce_max(dts)
+            lfs = lens_s.astype(np.float64)
+            flops_s = float((169.9e6 * lfs + 36864.0 * lfs * lfs).sum()) * reps
+            refresh["streamed"] = {"value": world * n_s * reps / dts, "unit": "passages/s", "seconds": dts, "passages_per_refresh": n_s,
+                                   "refreshes": reps, "lengths": "uniform 64..200, length-bucketed batches of %d" % nb,
+                                   "includes": "host batch assembly from the pinned token store + H2D + encoder + slab-row writes",
+                                   "real_token_tflops": flops_s / dts / 1e12, "mean_len": float(lfs.mean()),
+                                   "vs_device_resident_ragged": (world * n_s * reps / dts) / refresh["ragged"]["value"]}
+            del rf, sub, store
 
     if rank == 0:
         algo_bytes = rows * D * 2

@@ -27,33 +27,8 @@ pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "src", "atl
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-# ------------------------------------------------------------------------------------------------------------------
-# stand-ins for what is not on this machine: tokenizers (no vocab files offline) and the reader
-# ------------------------------------------------------------------------------------------------------------------
-class HashTokenizer:
-    """call-compatible with the HF tokenizer calls of atlas.py:68-75, 152-158, 185-191: words -> ids by a stable hash, [CLS] ..
-    [SEP] framing, padding 'longest' / 'max_length', truncation to max_length, tensors incl. token_type_ids (BERT tokenizers
-    return them, and atlas.py:78 passes `**batch_enc` on)"""
-
-    def __init__(self, vocab_size=1000):
-        self.vocab_size = vocab_size
-        self.calls = []
-
-    def __call__(self, batch, padding=None, return_tensors=None, max_length=None, truncation=None):
-        assert return_tensors == "pt" and truncation is True
-        self.calls.append(dict(n=len(batch), padding=padding, max_length=max_length))
-        rows = []
-        for text in batch:
-            ids = [101] + [1000 % self.vocab_size + (sum(map(ord, w)) * 31 + len(w)) % (self.vocab_size - 200) + 103 for w in text.split()]
-            ids = ids[: max_length - 1] + [102]
-            rows.append(ids)
-        width = max_length if padding == "max_length" else max(len(r) for r in rows)
-        input_ids = torch.zeros((len(rows), width), dtype=torch.int64)
-        mask = torch.zeros((len(rows), width), dtype=torch.int64)
-        for i, r in enumerate(rows):
-            input_ids[i, : len(r)] = torch.tensor(r)
-            mask[i, : len(r)] = 1
-        return {"input_ids": input_ids, "token_type_ids": torch.zeros_like(input_ids), "attention_mask": mask}
+# stand-ins for what is not on this machine: the tokenizer (tests/stub_tokenizer.py: no vocab files offline) and the reader
+from stub_tokenizer import HashTokenizer  # noqa: E402
 
 
 @pytest.fixture

@@ -1,0 +1,60 @@
+"""atlas_amd.token_store.TokenStore on the host: one tokenisation with the reference's own call (src/atlas.py:66-75, incl. its
+sic `max_length = min(text_maxlength, gpu_embedder_batch_size)`), nothing but real tokens stored, batches that reproduce what the
+reference's per-batch tokenisation would have produced, and length bucketing that still covers every slab row exactly once."""
+import numpy as np
+import torch
+
+from atlas_amd.token_store import TokenStore
+from stub_tokenizer import HashTokenizer
+
+WORDS = ["alpha", "beta", "gamma", "delta", "epsilon", "zeta", "eta", "theta", "iota", "kappa", "lambda", "mu"]
+FMT = "{title} {text}"
+
+
+def _passages(n, seed=3, longest=60):
+    rng = np.random.default_rng(seed)
+    return [{"id": str(i), "title": f"t{WORDS[i % 12]}", "text": " ".join(rng.choice(WORDS, size=int(rng.integers(1, longest))))} for i in range(n)]
+
+
+def test_store_reproduces_the_reference_batches():
+    passages, tok, bs = _passages(300), HashTokenizer(), 64
+    store = TokenStore.from_passages(passages, tok, FMT, text_maxlength=40, gpu_embedder_batch_size=bs, chunk=97)
+    assert len(store) == 300 and store.max_length == 40 and all(c["padding"] == "longest" and c["max_length"] == 40 for c in tok.calls)
+    assert int(store.lengths.max()) <= 40 and int(store.lengths.min()) >= 3 and store.n_tokens == int(store.lengths.sum())
+    ref_tok = HashTokenizer()
+    for (rows, ids, mask), a in zip(store.batches(bs, bucket=False), range(0, 300, bs)):
+        want = ref_tok([FMT.format(**p) for p in passages[a : a + bs]], padding="longest", return_tensors="pt", max_length=min(40, bs), truncation=True)
+        assert rows.tolist() == list(range(a, min(300, a + bs)))
+        assert torch.equal(ids, want["input_ids"]) and torch.equal(mask, want["attention_mask"])     # the batch atlas.py:68-75 builds
+
+
+def test_the_sic_bound_is_kept():
+    """atlas.py:74: the BATCH SIZE caps the token count (gpu_embedder_batch_size = 16 -> 16 tokens) -- reproduced, not fixed"""
+    store = TokenStore.from_passages(_passages(50), HashTokenizer(), FMT, text_maxlength=512, gpu_embedder_batch_size=16)
+    assert store.max_length == 16 and int(store.lengths.max()) == 16
+
+
+def test_bucketed_plan_covers_every_row_once_and_pads_less():
+    store = TokenStore.from_passages(_passages(1000, longest=120), HashTokenizer(), FMT, 128, 512)
+    for bucket in (True, False):
+        plan = store.plan(128, bucket)
+        allrows = np.concatenate(plan)
+        assert sorted(allrows.tolist()) == list(range(1000)) and all(len(g) <= 128 for g in plan)
+    slots = lambda plan: sum(len(g) * int(store.lengths[g].max()) for g in plan)      # noqa: E731
+    by_len, by_pos = slots(store.plan(128, True)), slots(store.plan(128, False))
+    assert store.n_tokens <= by_len < 0.6 * by_pos
+    lens_sorted = [int(store.lengths[g].max()) for g in store.plan(128, True)]
+    assert lens_sorted == sorted(lens_sorted)
+
+
+def test_fill_matches_a_per_passage_loop():
+    lists = [[5, 6, 7], [9], [1, 2, 3, 4, 5, 6], [], [8, 8]]
+    store = TokenStore.from_token_lists(lists)
+    rows = np.array([2, 0, 4, 1], dtype=np.int64)
+    ids, mask = torch.full((4, 8), -1, dtype=torch.int64), torch.full((4, 8), -1, dtype=torch.int64)
+    L = store.fill(rows, ids, mask)
+    got_ids, got_mask = ids.view(-1)[: 4 * L].view(4, L), mask.view(-1)[: 4 * L].view(4, L)
+    assert L == 6
+    for j, r in enumerate(rows):
+        assert got_ids[j, : len(lists[r])].tolist() == lists[r] and not got_ids[j, len(lists[r]):].any()
+        assert got_mask[j].tolist() == [1] * len(lists[r]) + [0] * (L - len(lists[r]))
