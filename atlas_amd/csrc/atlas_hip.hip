@@ -36,6 +36,7 @@ using namespace atlas;
 #define K_FAST_MAX 256
 #define K_EXACT_MAX 2048
 #define MERGE_SMAX 2048          // max candidates rescored per query in the merge
+#define MERGE_GMAX 1024          // most scan workgroups (= threads of a merge block)
 
 
 // ------------------------------------------------------------------------------------------
@@ -44,7 +45,7 @@ using namespace atlas;
 __global__ void __launch_bounds__(256)
 prep_queries_kernel(const void* __restrict__ q, int q_dtype, int q0, int nq, int d, float pmax,
                     uint16_t* __restrict__ qrow /*[64][d]*/, uint16_t* __restrict__ qfrag /*fragment order*/,
-                    float* __restrict__ qeps /*[64]*/, uint32_t* __restrict__ scan_state /*gstat[64] | qflag[64] | dense_cnt[64] or null*/,
+                    float* __restrict__ qeps /*[64]*/, uint32_t* __restrict__ scan_state /*spare[64] | qflag[64] | spare[64] or null*/,
                     int32_t* __restrict__ out_status /*or null*/) {
     const int j = blockIdx.x;
     // also resets the per-call state words (saves two memset dispatches per search)
@@ -95,8 +96,9 @@ struct MergeParams {
     const uint16_t* slab; int64_t N; int d;
     const uint16_t* qrow;        // [64][d]
     const float* qeps;           // [64]
-    const uint2* dense; const uint32_t* dense_cnt; int dense_cap;   // [64][dense_cap] candidates per query
-    const uint32_t* gstat; const uint32_t* qflag;
+    const uint2* lists; const uint32_t* list_cnt; const uint32_t* wg_stat; int G, cap;   // the scan's per-(workgroup, query) candidate lists
+    int total_cap;               // most candidates a query may bring to the merge (more: exact path)
+    const uint32_t* qflag;
     int k, q0;                   // q0: first query of this chunk (output row offset)
     int key_cap;                 // approximate-score keys that fit in LDS
     unsigned long long* dbg;     // optional per-phase cycle stamps of block 0 (tuning only; null in production)
@@ -137,14 +139,15 @@ template <int NT>
 __global__ void __launch_bounds__(NT)
 merge_rescore_kernel(const MergeParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // layout: qs[d] u16 (padded to 16 B) | misc[64] | s_row[SMAX] | s_app[SMAX] | s_key[SMAX] u64 | keys[key_cap]
+    // layout: qs[d] u16 (padded to 16 B) | misc[64] | s_row[SMAX] | s_app[SMAX] | s_key[SMAX] u64 | s_off[MERGE_GMAX + 8] | keys[key_cap]
     uint16_t* qs = (uint16_t*)smem;
     const int qbytes = ((p.d * 2 + 15) / 16) * 16;
-    uint32_t* misc = (uint32_t*)(smem + qbytes);   // [1] kmax [2] kmin [4] maxerr bits [5] nsurv [16..63] 3 rotating x 16 bucket counts
+    uint32_t* misc = (uint32_t*)(smem + qbytes);   // [1] kmax [2] kmin [4] maxerr bits [5] nsurv [6] scan flags [7] pmax^2 bits [16..31] wave totals of the offset scan
     uint32_t* s_row = misc + 64;
     float* s_app = (float*)(s_row + MERGE_SMAX);
     uint64_t* s_key = (uint64_t*)(s_app + MERGE_SMAX);
-    uint32_t* keys = (uint32_t*)(s_key + MERGE_SMAX);
+    uint32_t* s_off = (uint32_t*)(s_key + MERGE_SMAX);            // [G + 1] exclusive offsets of the workgroups' segments
+    uint32_t* keys = s_off + MERGE_GMAX + 8;
 
     const int q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -160,27 +163,76 @@ merge_rescore_kernel(const MergeParams p) {
             atomicAdd((uint32_t*)&p.out_status[ATLAS_ST_N_FALLBACK], 1u);
         }
     };
-    if (p.qflag[q] != 0u) { fallback(); return; }   // the scan overflowed this query's band
-
     if (p.dbg && q == 0 && tid == 0) p.dbg[0] = __builtin_readcyclecounter();
     for (int i = tid; i < p.d; i += NT) qs[i] = p.qrow[(size_t)q * p.d + i];
     if (tid < 64) misc[tid] = (tid == 2) ? 0xffffffffu : 0u;
-    const uint32_t total = p.dense_cnt[q];
-    if (total > (uint32_t)p.dense_cap) { fallback(); return; }
-    const uint2* D = p.dense + (size_t)q * p.dense_cap;
-    // the first key_cap keys are cached in LDS; a longer candidate list (poor initial threshold, adversarial data) is streamed
-    // from the dense array (L2) in the two later passes instead of being handed to the exact path
-    const uint32_t ncache = total < (uint32_t)p.key_cap ? total : (uint32_t)p.key_cap;
-    auto key_at = [&](const uint32_t i) -> uint32_t { return i < ncache ? keys[i] : f32_order_key(bits_f32(D[i].x)); };
     __syncthreads();
+    // (0) the segment table: thread g takes workgroup g's list length for this query (and its norm / flag word: the scan's
+    // certification state is reduced here, the scan kernel itself ends without a single global atomic), then a block-wide exclusive scan
+    static_assert(NT >= MERGE_GMAX, "one thread per scan workgroup");
+    uint32_t cg = 0;
+    if (tid < p.G) {
+        cg = p.list_cnt[(size_t)q * p.G + tid];
+        atomicMax(&misc[7], p.wg_stat[(size_t)tid * 2 + 0]);         // non-negative floats order like their bits
+        const uint32_t f = p.wg_stat[(size_t)tid * 2 + 1];
+        if (f) atomicOr(&misc[6], f);
+    }
+    uint32_t inc = cg;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(inc, o);
+        if (lane >= o) inc += y;
+    }
+    if (lane == 63) misc[16 + wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += misc[16 + w];
+    if (tid < p.G) s_off[tid] = wbase + inc - cg;
+    if (tid == p.G - 1) s_off[p.G] = wbase + inc;
+    __syncthreads();
+    const uint32_t total = s_off[p.G];
+    // the scan flagged this query (band overflow), or it brings more candidates than the merge is sized for: exact path
+    if (p.qflag[q] != 0u || total > (uint32_t)p.total_cap) { fallback(); return; }
+    // flat candidate index -> entry: binary search in the segment table (only band members and keys beyond the LDS cache need it)
+    auto entry_at = [&](const uint32_t i) -> uint2 {
+        int lo = 0, hi = p.G;                                         // s_off[lo] <= i < s_off[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= i) lo = mid; else hi = mid; }
+        return p.lists[((size_t)q * p.G + lo) * p.cap + (i - s_off[lo])];
+    };
+    // the first key_cap keys are cached in LDS; a longer candidate list (poor initial threshold, adversarial data) is re-read
+    // from the lists (L2) in the two later passes instead of being handed to the exact path
+    const uint32_t ncache = total < (uint32_t)p.key_cap ? total : (uint32_t)p.key_cap;
+    auto key_at = [&](const uint32_t i) -> uint32_t { return i < ncache ? keys[i] : f32_order_key(bits_f32(entry_at(i).x)); };
     if (p.dbg && q == 0 && tid == 0) p.dbg[1] = __builtin_readcyclecounter();
-    // (1) keys -> LDS (coalesced), with min / max
+    // (1) keys -> LDS with min / max: a wave takes 16 segments at a time and requests all of them before it uses the first
+    // (the segments were written by workgroups of every XCD: each is its own trip to memory)
     uint32_t kmax = 0, kmin = 0xffffffffu;
-    for (uint32_t i = tid; i < total; i += NT) {
-        const uint32_t key = f32_order_key(bits_f32(D[i].x));
-        if (i < ncache) keys[i] = key;
-        kmax = key > kmax ? key : kmax;
-        kmin = key < kmin ? key : kmin;
+    constexpr int NWV = NT / 64, SEG = 16;
+    for (int g0 = wave * SEG; g0 < p.G; g0 += NWV * SEG) {
+        uint32_t longest = 0;
+#pragma unroll
+        for (int u = 0; u < SEG; ++u)
+            if (g0 + u < p.G) { const uint32_t n = s_off[g0 + u + 1] - s_off[g0 + u]; longest = n > longest ? n : longest; }
+        for (uint32_t r0 = 0; r0 < longest; r0 += 64) {
+            uint32_t sc[SEG];
+#pragma unroll
+            for (int u = 0; u < SEG; ++u) {
+                const int g = g0 + u < p.G ? g0 + u : p.G - 1;          // clamped: loads stay unconditional
+                const uint32_t n = s_off[g + 1] - s_off[g], j = r0 + lane;
+                sc[u] = p.lists[((size_t)q * p.G + g) * p.cap + (j < n ? j : 0)].x;
+            }
+#pragma unroll
+            for (int u = 0; u < SEG; ++u) {
+                if (g0 + u >= p.G) continue;
+                const uint32_t base = s_off[g0 + u], n = s_off[g0 + u + 1] - base, j = r0 + lane;
+                if (j < n) {
+                    const uint32_t key = f32_order_key(bits_f32(sc[u]));
+                    if (base + j < ncache) keys[base + j] = key;
+                    kmax = key > kmax ? key : kmax;
+                    kmin = key < kmin ? key : kmin;
+                }
+            }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -235,7 +287,7 @@ merge_rescore_kernel(const MergeParams p) {
     const uint32_t theta_key = f32_order_key(theta);
     for (uint32_t i = tid; i < total; i += NT) {
         if (key_at(i) > theta_key) {
-            const uint2 e = D[i];
+            const uint2 e = entry_at(i);
             const uint32_t sidx = atomicAdd(&misc[5], 1u);
             if (sidx < MERGE_SMAX) { s_row[sidx] = e.y; s_app[sidx] = bits_f32(e.x); }
         }
@@ -312,8 +364,8 @@ merge_rescore_kernel(const MergeParams p) {
         if (bits_f32(misc[4]) > 1.0f)
             atomicOr((uint32_t*)&p.out_status[ATLAS_ST_FLAGS], (uint32_t)ATLAS_F_EPS_VIOLATION);
         // scan-level flags / pmax (idempotent across blocks)
-        atomicOr((uint32_t*)&p.out_status[ATLAS_ST_FLAGS], p.gstat[1]);
-        atomicMax((uint32_t*)&p.out_status[ATLAS_ST_PMAX_BITS], f32_bits(sqrtf(bits_f32(p.gstat[0])) * 1.000001f));
+        if (misc[6]) atomicOr((uint32_t*)&p.out_status[ATLAS_ST_FLAGS], misc[6]);
+        atomicMax((uint32_t*)&p.out_status[ATLAS_ST_PMAX_BITS], f32_bits(sqrtf(bits_f32(misc[7])) * 1.000001f));
     }
 }
 
@@ -600,11 +652,11 @@ constexpr int scan_variant_index() { return 0; }
 struct ScanPlan {
     int G;               // workgroups
     int64_t rows_per_wg;
-    int keep_max, cap, tile, buf_cap;
+    int keep_max, cap, tile, buf_cap, flush_at;
     int S; int64_t sample_stride;     // sample pre-pass: S rows (0 = none), tile j starts at j*sample_stride
     int key_cap;
-    int dense_cap;
-    size_t off_qfrag, off_qrow, off_qeps, off_theta0, off_gstat, off_qflag, off_dense_cnt, off_sample, off_dense, off_lists, total;
+    int total_cap;
+    size_t off_qfrag, off_qrow, off_qeps, off_theta0, off_gstat, off_qflag, off_sample, off_list_cnt, off_wg_stat, off_lists, total;
     size_t scan_lds, merge_lds;
 };
 
@@ -628,8 +680,14 @@ ScanPlan make_plan(int64_t N, int d, int k, int cus, const ScanVariant& v) {
     pl.rows_per_wg = ((frags + G - 1) / G) * 16;
     pl.tile = v.nw * v.pf * 16;
     pl.keep_max = (2 * k > k + 64) ? 2 * k : k + 64;
-    pl.buf_cap = 4096;                                   // 32 KB of LDS
-    pl.cap = pl.keep_max + pl.buf_cap + pl.tile;         // a flush can land in one list
+    // LDS candidate buffer: what fits next to the 96 KiB query image. A flush into the global lists (scattered stores, the ring of slab
+    // loads drained and restarted: 15-20 us per workgroup, profiles/r02/scan_tail.txt) is requested at 3/4: a 4M-row shard collects ~2.3k
+    // candidates per workgroup and an 8M-row shard ~4.6k, both now end without one
+    pl.buf_cap = 7680;                                   // 60 KiB of LDS
+    pl.flush_at = pl.buf_cap * 3 / 4;
+    // entries per (query, workgroup) list: what survives a compaction (keep_max) plus what one flush of the buffer normally adds to ONE
+    // query (buf_cap / 64 = 120 on average). A list that overflows hands its query to the exact path (correct, slower): adversarial data only
+    pl.cap = 2048;
     // sample pre-pass: ~N/64 rows in tiles of 64, spread evenly (distinct rows: stride >= 256)
     pl.S = 0; pl.sample_stride = 0;
     if (N >= 65536) {
@@ -644,16 +702,17 @@ ScanPlan make_plan(int64_t N, int d, int k, int cus, const ScanVariant& v) {
     pl.off_qrow = o;   o += align_up((size_t)QCHUNK * d * 2, 256);
     pl.off_qeps = o;   o += 256;
     pl.off_theta0 = o; o += 256;
-    pl.off_gstat = o;  o += 256;          // gstat | qflag | dense_cnt are contiguous (prep zeroes them)
+    pl.off_gstat = o;  o += 256;          // spare | qflag | spare are contiguous (prep zeroes them)
     pl.off_qflag = o;  o += 256;
-    pl.off_dense_cnt = o; o += 256;
+    o += 256;
     pl.off_sample = o; o += (size_t)QCHUNK * SAMPLE_MAX * 4;
-    pl.dense_cap = 131072;
-    pl.off_dense = o;  o += (size_t)QCHUNK * pl.dense_cap * 8;
+    pl.off_list_cnt = o; o += align_up((size_t)pl.G * 64 * 4, 256);      // every scan workgroup overwrites its 64 words: no reset
+    pl.off_wg_stat = o;  o += align_up((size_t)pl.G * 2 * 4, 256);
+    pl.total_cap = 131072;                // most candidates of one query the merge takes on (beyond: exact path)
     pl.off_lists = o;  o += (size_t)pl.G * 64 * pl.cap * 8;
     pl.total = align_up(o, 256);
-    pl.scan_lds = (size_t)ScanSmem::buf_off + (size_t)pl.buf_cap * 8;
-    const size_t merge_fixed = align_up((size_t)d * 2, 16) + 64 * 4 + (size_t)MERGE_SMAX * (4 + 4 + 8);
+    pl.scan_lds = (size_t)ScanSmem::buf_off + (size_t)pl.buf_cap * 8 + (ATLAS_TUNING ? 1024 : 0);     // tuning build: + per-tile stamps
+    const size_t merge_fixed = align_up((size_t)d * 2, 16) + 64 * 4 + (size_t)MERGE_SMAX * (4 + 4 + 8) + (size_t)(MERGE_GMAX + 8) * 4;
     pl.key_cap = (int)((160 * 1024 - 1024 - merge_fixed) / 4);
     pl.merge_lds = merge_fixed + (size_t)pl.key_cap * 4;
     return pl;
@@ -771,10 +830,10 @@ int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t
         sp.qfrag = (const uint4*)(w + pl.off_qfrag); sp.qeps = (const float*)(w + pl.off_qeps);
         sp.theta0 = (const float*)(w + pl.off_theta0);
         sp.lists = (uint2*)(w + pl.off_lists);
-        sp.dense = (uint2*)(w + pl.off_dense); sp.dense_cnt = (uint32_t*)(w + pl.off_dense_cnt); sp.dense_cap = pl.dense_cap;
-        sp.gstat = (uint32_t*)(w + pl.off_gstat); sp.qflag = (uint32_t*)(w + pl.off_qflag);
+        sp.list_cnt = (uint32_t*)(w + pl.off_list_cnt); sp.wg_stat = (uint32_t*)(w + pl.off_wg_stat);
+        sp.qflag = (uint32_t*)(w + pl.off_qflag);
         sp.rows_per_wg = pl.rows_per_wg; sp.nq = nq; sp.k = k; sp.cap = pl.cap; sp.keep_max = pl.keep_max;
-        sp.buf_cap = pl.buf_cap;
+        sp.buf_cap = pl.buf_cap; sp.flush_at = pl.flush_at;
         sp.pmax2_hint = pmax_hint * pmax_hint;
         sp.dbg = g_scan_dbg;
         if (q0 == 0 && ev_scan_begin) (void)hipEventRecord((hipEvent_t)ev_scan_begin, stream);
@@ -783,8 +842,9 @@ int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t
         MergeParams mp{};
         mp.slab = (const uint16_t*)slab_f16; mp.N = N; mp.d = d;
         mp.qrow = (const uint16_t*)(w + pl.off_qrow); mp.qeps = sp.qeps;
-        mp.dense = sp.dense; mp.dense_cnt = sp.dense_cnt; mp.dense_cap = pl.dense_cap;
-        mp.gstat = sp.gstat; mp.qflag = sp.qflag; mp.k = k; mp.q0 = q0; mp.key_cap = pl.key_cap;
+        mp.lists = sp.lists; mp.list_cnt = sp.list_cnt; mp.wg_stat = sp.wg_stat; mp.G = pl.G; mp.cap = pl.cap;
+        mp.total_cap = pl.total_cap;
+        mp.qflag = sp.qflag; mp.k = k; mp.q0 = q0; mp.key_cap = pl.key_cap;
         mp.dbg = g_merge_dbg;
         mp.out_score = (uint16_t*)out_score_f16; mp.out_idx = out_idx; mp.out_status = out_status;
         hipLaunchKernelGGL(merge, dim3(nq), dim3(MERGE_NT), pl.merge_lds, stream, mp);

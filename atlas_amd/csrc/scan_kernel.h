@@ -6,6 +6,16 @@
 #include "common.h"
 #include "../../include/atlas_hip.h"
 
+#ifndef ATLAS_TUNING
+#define ATLAS_TUNING 0
+#endif
+// wall-clock stamps exist in the tuning build only: the product kernel carries no trace of them
+#if ATLAS_TUNING
+#define ATLAS_SCAN_STAMP(i) do { if (p.dbg && tid == 0) p.dbg[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define ATLAS_SCAN_STAMP(i) do { } while (0)
+#endif
+
 namespace atlas {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -59,17 +69,16 @@ struct ScanParams {
     const uint4* qfrag;       // [24][4][64] uint4
     const float* qeps;        // [64]
     const float* theta0;      // [64] initial per-query thresholds from the sample pre-pass (or -inf)
-    uint2* lists;             // [G][64][cap]  {f32 bits of approx score, row}
-    uint2* dense;             // [64][dense_cap] every workgroup's final candidates, per query, contiguous
-    uint32_t* dense_cnt;      // [64] entries used in dense[q] (atomicAdd by workgroups)
-    int dense_cap;
-    uint32_t* gstat;          // [0] max row sumsq (float bits, atomicMax)  [1] flags
-    uint32_t* qflag;          // [64] per-query fallback flag (band overflow)
+    uint2* lists;             // [64][G][cap]  {f32 bits of approx score, row}: the candidates of workgroup g for query q
+    uint32_t* list_cnt;       // [64][G] entries of lists[q][g] at the end of the scan (plain stores: every workgroup writes its 64)
+    uint32_t* wg_stat;        // [G][2]  per workgroup: largest row sum of squares seen (float bits) | ATLAS_F_* flags
+    uint32_t* qflag;          // [64] per-query fallback flag (band overflow; plain idempotent stores)
     int64_t rows_per_wg;
     int nq, k, cap, keep_max;
     int buf_cap;              // entries of the LDS candidate buffer
+    int flush_at;             // buffer fill at which a flush into the global lists is requested
     float pmax2_hint;
-    unsigned long long* dbg;  // tuning only (atlas_dbg_set_scan_stamps): 4 cycle stamps per workgroup; null in production
+    unsigned long long* dbg;  // tuning build only (atlas_tune_set_scan_stamps): 8 wall-clock stamps (100 MHz, common to all XCDs) per workgroup; null in production
 };
 
 struct ScanSmem {   // byte offsets into dynamic LDS
@@ -95,6 +104,7 @@ scan_kernel(const ScanParams p) {
     uint2* s_buf = (uint2*)(smem + ScanSmem::buf_off);
 
     const int tid = threadIdx.x;
+    ATLAS_SCAN_STAMP(0);        // [0] entry
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 15, lgrp = lane >> 4;
@@ -106,7 +116,10 @@ scan_kernel(const ScanParams p) {
     int64_t r_end = r_begin + p.rows_per_wg;
     if (r_end > p.N) r_end = p.N;
     const int ntiles = (r_end > r_begin) ? (int)((r_end - r_begin + TILE - 1) / TILE) : 0;   // workgroup-uniform
-    uint2* my_lists = p.lists + (size_t)blockIdx.x * 64 * p.cap;
+    // lists are [query][workgroup][cap]: everything that belongs to one query -- what its merge block gathers -- lies within G * cap
+    // entries (a few 2 MiB pages), and all workgroups' stores go to the same 64 regions
+    const size_t qstride = (size_t)gridDim.x * p.cap;
+    uint2* my_lists = p.lists + (size_t)blockIdx.x * p.cap;
 
     // Passage rows stream HBM -> VGPR through buffer loads (cdna guide T8). ONE descriptor per
     // wave spans [first row of this wave's first tile, N). The hardware bounds check covers
@@ -154,7 +167,7 @@ scan_kernel(const ScanParams p) {
 
     // the query image is copied into LDS AFTER the first ring loads are in flight (their HBM latency
     // overlaps the 96 KiB copy from L2)
-    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 0] = __builtin_readcyclecounter();
+    ATLAS_SCAN_STAMP(1);        // [1] ring prologue issued
     copy_qfrag_to_lds<NW * 64>(s_q, p.qfrag, tid);
     if (tid < 64) {
         s_theta[tid] = (tid < p.nq) ? p.theta0[tid] : pos_inf();
@@ -162,7 +175,7 @@ scan_kernel(const ScanParams p) {
     }
     if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; }
     __syncthreads();
-    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 1] = __builtin_readcyclecounter();
+    ATLAS_SCAN_STAMP(2);        // [2] query image in LDS
 
     f32x4 acc[PF][4];
 #pragma unroll
@@ -191,7 +204,7 @@ scan_kernel(const ScanParams p) {
             const uint2 e = s_buf[i];
             const uint32_t qq = e.y >> 26;
             const uint32_t gs = atomicAdd(&s_cnt[qq], 1u);
-            if (gs < (uint32_t)p.cap) my_lists[qq * (uint32_t)p.cap + gs] = make_uint2(e.x, gbase + (e.y & 0x03ffffffu));
+            if (gs < (uint32_t)p.cap) my_lists[qq * qstride + gs] = make_uint2(e.x, gbase + (e.y & 0x03ffffffu));
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);     // list stores complete before anyone reads them back
         wg_barrier_lds();
@@ -200,7 +213,7 @@ scan_kernel(const ScanParams p) {
             const uint32_t n = s_cnt[qq] < (uint32_t)p.cap ? s_cnt[qq] : (uint32_t)p.cap;
             // mid-scan: tighten every list that can be pruned; at the end only the oversized ones
             if (n <= (uint32_t)(final_flush ? p.keep_max : p.k)) continue;
-            uint2* L = my_lists + (size_t)qq * p.cap;
+            uint2* L = my_lists + (size_t)qq * qstride;
             // k-th largest approximate score: greedy bit search below the common prefix of the keys,
             // stopping 2^-15 short of exact (any lower bound of the k-th is a valid T)
             uint32_t kmax = 0, kmin = 0xffffffffu;
@@ -356,11 +369,11 @@ scan_kernel(const ScanParams p) {
                                 const uint32_t slot = atomicAdd(&s_flag[2], 1u);
                                 if (slot < (uint32_t)p.buf_cap) {
                                     s_buf[slot] = make_uint2(f32_bits(v), (qq << 26) | (rrel + (uint32_t)(pf * 16 + r)));
-                                    if (slot >= (uint32_t)(p.buf_cap / 2)) s_flag[par] = 1u;   // request a flush
+                                    if (slot >= (uint32_t)p.flush_at) s_flag[par] = 1u;   // request a flush
                                 } else {
                                     const uint32_t gs = atomicAdd(&s_cnt[qq], 1u);
                                     if (gs < (uint32_t)p.cap)
-                                        my_lists[qq * (uint32_t)p.cap + gs] =
+                                        my_lists[qq * qstride + gs] =
                                             make_uint2(f32_bits(v), gbase + rrel + (uint32_t)(pf * 16 + r));
                                     s_flag[par] = 1u;
                                     spilled = true;
@@ -379,6 +392,11 @@ scan_kernel(const ScanParams p) {
         }
 
         wg_barrier_lds();
+        if (row0 == 0) ATLAS_SCAN_STAMP(3);   // [3] first tile done
+#if ATLAS_TUNING
+        // per-tile end stamps of this workgroup, collected in LDS (no global store in the loop) and dumped after the hand-over
+        if (p.dbg && tid == 0 && row0 / TILE < 120) ((unsigned long long*)(smem + ScanSmem::buf_off + (size_t)p.buf_cap * 8))[row0 / TILE] = wall_clock64();
+#endif
         // the request word of this tile's parity cannot change until every wave has passed the next
         // barrier, so all waves take the same branch
         if (s_flag[par] != 0u) flush_and_compact(par, false);
@@ -386,61 +404,45 @@ scan_kernel(const ScanParams p) {
         par ^= 1;
     }
 
-    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 2] = __builtin_readcyclecounter();
-    // Final hand-over: each query's candidates of ALL workgroups end up contiguous in dense[q], so the
-    // merge kernel reads them with coalesced loads and needs no per-workgroup bookkeeping. Buffered
-    // entries go LDS -> dense directly; ONE global atomicAdd per (workgroup, query) reserves the range
-    // (64 lanes issue them together: one L2 round trip).
+    ATLAS_SCAN_STAMP(4);        // [4] last tile done
+    // Final hand-over, WITHOUT global atomics: the buffered candidates join this workgroup's own per-query lists (slots from the LDS
+    // counters), the 64 list lengths and the workgroup's norm / flag word go out as plain stores, and the merge kernel gathers the G
+    // segments of its query. (It used to reserve ranges of one shared per-query array with 64 atomicAdds per workgroup, plus one
+    // atomicMax per wave: 20k atomics on three cache lines as the workgroups finish. The loads of every workgroup still scanning
+    // queued behind them at that L2 channel: its last tiles took 25-45 us instead of 7-17, ~30 us of every scan whatever its size --
+    // profiles/r02/scan_wg_times_wallclock.txt, scan_tail_modes.txt.)
     {
-        uint32_t* s_base = (uint32_t*)(smem + ScanSmem::aux_off);
-        uint32_t* s_pos = s_base + 64;
-        uint32_t* s_nbuf = s_base + 128;
         wg_barrier_lds();
         const uint32_t nbuf = s_flag[2] < (uint32_t)p.buf_cap ? s_flag[2] : (uint32_t)p.buf_cap;
-        if (tid < 64) { s_pos[tid] = 0u; s_nbuf[tid] = 0u; }
-        wg_barrier_lds();
-        for (uint32_t i = tid; i < nbuf; i += NW * 64) atomicAdd(&s_nbuf[s_buf[i].y >> 26], 1u);
-        wg_barrier_lds();
-        if (tid < 64) {
-            uint32_t base = 0xffffffffu;
-            if (tid < p.nq) {
-                const uint32_t listed = s_cnt[tid] < (uint32_t)p.cap ? s_cnt[tid] : (uint32_t)p.cap;
-                const uint32_t n = s_nbuf[tid] + listed;
-                if (s_cnt[tid] > (uint32_t)p.cap) { p.qflag[tid] = 1u; }          // a list overflowed -> exact path
-                else if (n > 0) {
-                    base = atomicAdd(&p.dense_cnt[tid], n);
-                    if (base + n > (uint32_t)p.dense_cap) { p.qflag[tid] = 1u; base = 0xffffffffu; }
-                }
-            }
-            s_base[tid] = base;
-        }
-        wg_barrier_lds();
         for (uint32_t i = tid; i < nbuf; i += NW * 64) {
             const uint2 e = s_buf[i];
-            const uint32_t qq = e.y >> 26, b = s_base[qq];
-            if (b != 0xffffffffu) {
-                const uint32_t pos = atomicAdd(&s_pos[qq], 1u);
-                p.dense[(size_t)qq * p.dense_cap + b + pos] = make_uint2(e.x, gbase + (e.y & 0x03ffffffu));
-            }
+            const uint32_t qq = e.y >> 26;
+            const uint32_t gs = atomicAdd(&s_cnt[qq], 1u);
+            if (gs < (uint32_t)p.cap) my_lists[qq * qstride + gs] = make_uint2(e.x, gbase + (e.y & 0x03ffffffu));
         }
-        wg_barrier_lds();
-        for (int qq = wave; qq < p.nq; qq += NW) {       // entries flushed to the lists earlier (large shards only)
-            const uint32_t n = s_cnt[qq] < (uint32_t)p.cap ? s_cnt[qq] : (uint32_t)p.cap, b = s_base[qq];
-            if (n == 0 || b == 0xffffffffu) continue;
-            const uint2* L = my_lists + (size_t)qq * p.cap;
-            uint2* D = p.dense + (size_t)qq * p.dense_cap + b + s_nbuf[qq];
-            for (uint32_t i = lane; i < n; i += 64) D[i] = L[i];
-        }
-    }
-    // publish the largest row norm^2 seen (x1.001: v_dot2 accumulates in fp32)
+        // largest row norm^2 of the workgroup (x1.001: v_dot2 accumulates in fp32): waves -> LDS -> one word
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) pm = fmaxf(pm, __shfl_xor(pm, o));
-    if (lane == 0 && pm > 0.f) {
-        pm *= 1.001f;
-        atomicMax(&p.gstat[0], f32_bits(pm));
-        if (pm > p.pmax2_hint) atomicOr(&p.gstat[1], (uint32_t)ATLAS_F_PMAX_VIOLATION);
+        for (int o = 32; o > 0; o >>= 1) pm = fmaxf(pm, __shfl_xor(pm, o));
+        float* s_pm = (float*)(smem + ScanSmem::aux_off);
+        if (lane == 0) s_pm[wave] = pm;
+        wg_barrier_lds();
+        if (tid < 64) {
+            uint32_t c = (tid < p.nq) ? s_cnt[tid] : 0u;
+            if (c > (uint32_t)p.cap) { p.qflag[tid] = 1u; c = 0u; }          // a list overflowed -> exact path
+            p.list_cnt[(size_t)tid * gridDim.x + blockIdx.x] = c;
+        }
+        if (tid == 0) {
+            float m = 0.f;
+            for (int w = 0; w < NW; ++w) m = fmaxf(m, s_pm[w]);
+            m *= 1.001f;
+            p.wg_stat[(size_t)blockIdx.x * 2 + 0] = f32_bits(m);
+            p.wg_stat[(size_t)blockIdx.x * 2 + 1] = (m > p.pmax2_hint) ? (uint32_t)ATLAS_F_PMAX_VIOLATION : 0u;
+        }
     }
-    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 3] = __builtin_readcyclecounter();
+    ATLAS_SCAN_STAMP(5);        // [5] hand-over done
+#if ATLAS_TUNING
+    if (p.dbg && tid < 120) p.dbg[2048 + blockIdx.x * 120 + tid] = (tid < ntiles) ? ((unsigned long long*)(smem + ScanSmem::buf_off + (size_t)p.buf_cap * 8))[tid] : 0ull;
+#endif
 }
 
 

@@ -1,13 +1,17 @@
-"""per-workgroup cycle stamps of the scan kernel (dev tool): distribution of start-up, loop and end times over the 256 CUs"""
+"""Per-workgroup WALL-CLOCK stamps of the scan kernel (tuning build): when every workgroup starts, has its query image, finishes its
+first tile, its last tile and its hand-over, on the chip-wide 100 MHz clock (10 ns ticks) -- start skew, per-CU streaming rate,
+end skew, per XCD. Shows where the size-independent part of the scan time goes.
+
+    python tools/scan_wg_times.py 1000000 4000000
+"""
 import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
 from _tune import L  # noqa: E402  (tuning build of the library, hooks bound)
-import ctypes, os, sys, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-from atlas_amd import HipDistributedIndex, _lib
+import sys
 import numpy as np
-L = _lib.lib()
-L.atlas_tune_set_scan_stamps.argtypes = [ctypes.c_void_p]
-for N in [int(a) for a in sys.argv[1:]] or [4_000_000, 1_000_000]:
+import torch
+from atlas_amd import HipDistributedIndex
+
+for N in [int(a) for a in sys.argv[1:]] or [1_000_000, 4_000_000]:
     g = torch.Generator(device="cuda").manual_seed(1)
     slab = torch.empty((N, 768), dtype=torch.float16, device="cuda")
     for r0 in range(0, N, 250_000):
@@ -15,27 +19,52 @@ for N in [int(a) for a in sys.argv[1:]] or [4_000_000, 1_000_000]:
         slab[r0:r0+n] = (x / x.norm(dim=1, keepdim=True)).half()
     q = torch.randn((64, 768), device="cuda")
     idx = HipDistributedIndex(); idx._set_slab(slab)
-    for _ in range(3): idx._compute_scores_and_indices(q, 40)
-    dbg = torch.zeros(256 * 4, dtype=torch.int64, device="cuda")
+    for _ in range(5): idx._compute_scores_and_indices(q, 40)
+    dbg = torch.zeros(2048 + 256 * 120, dtype=torch.int64, device="cuda")
     res = []
-    for rep in range(5):
+    for rep in range(6):
         dbg.zero_()
         L.atlas_tune_set_scan_stamps(dbg.data_ptr())
         idx._compute_scores_and_indices(q, 40); torch.cuda.synchronize()
         L.atlas_tune_set_scan_stamps(None)
-        t = dbg.cpu().numpy().reshape(256, 4).astype(np.float64)
+        raw = dbg.cpu().numpy().astype(np.float64) * 0.01                    # microseconds
+        t = raw[:2048].reshape(256, 8)
         t0 = t[:, 0].min()
+        tiles = raw[2048:].reshape(256, 120)
         res.append(t - t0)
+        last_tiles = np.where(tiles > 0, tiles - t0, np.nan)
+    f = lambda a: "min %7.2f  p10 %7.2f  p50 %7.2f  p90 %7.2f  max %7.2f" % (a.min(), np.percentile(a, 10), np.median(a), np.percentile(a, 90), a.max())
+    for rep, t in enumerate(res[-3:]):
+        rows_wg = -(-(N // 16) // 256) * 16
+        print(f"N={N} rep {rep}: kernel span (first entry -> last hand-over) = {t[:, 5].max():.2f} us; ideal at 6.05 TB/s = {N * 1536 / 6.05e6:.2f} us")
+        print("  entry (abs)            ", f(t[:, 0]))
+        print("  ring prologue issued   ", f(t[:, 1] - t[:, 0]), "(since entry)")
+        print("  query image in LDS     ", f(t[:, 2] - t[:, 0]), "(since entry)")
+        print("  first tile done        ", f(t[:, 3] - t[:, 0]), "(since entry)")
+        print("  loop (image -> last)   ", f(t[:, 4] - t[:, 2]), "(duration)")
+        print("  per-WG stream rate GB/s", f(rows_wg * 1536 / (t[:, 4] - t[:, 2]) / 1e3))
+        print("  last tile done (abs)   ", f(t[:, 4]))
+        print("  hand-over              ", f(t[:, 5] - t[:, 4]), "(duration)")
+        print("  end (abs)              ", f(t[:, 5]))
+        print("  mean loop per XCD (wg % 8):", [round(float((t[x::8, 4] - t[x::8, 2]).mean()), 1) for x in range(8)])
+        print("  mean entry per XCD        :", [round(float(t[x::8, 0].mean()), 2) for x in range(8)])
+        order = np.argsort(t[:, 5])
+        print("  last 8 WGs to finish:", order[-8:].tolist(), "loop us:", np.round(t[order[-8:], 4] - t[order[-8:], 2], 1).tolist(),
+              "hand-over us:", np.round(t[order[-8:], 5] - t[order[-8:], 4], 1).tolist())
+        # how much of the chip is still streaming over time: number of WGs still in their loop at the p50 / p90 / max end
+        ends = np.sort(t[:, 4])
+        print("  WGs still looping at t = p50 end: %d, p90: %d; time from p50 end to last end: %.2f us" % (
+            (t[:, 4] > ends[127]).sum(), (t[:, 4] > ends[230]).sum(), ends[-1] - ends[127]))
+    # per-tile picture of the last repetition: tile period (us) of the median workgroup vs the 8 slowest, tile by tile
     t = res[-1]
-    f = lambda a: "min %7.0f  p50 %7.0f  p90 %7.0f  max %7.0f" % (a.min(), np.median(a), np.percentile(a, 90), a.max())
-    print(f"N={N}  (s_memtime ticks; kernel span = {t[:,3].max():.0f})")
-    print("  entry          ", f(t[:, 0]))
-    print("  after LDS fill ", f(t[:, 1] - t[:, 0]), "(duration)")
-    print("  loop           ", f(t[:, 2] - t[:, 1]), "(duration)")
-    print("  hand-over      ", f(t[:, 3] - t[:, 2]), "(duration)")
-    print("  end            ", f(t[:, 3]))
-    order = np.argsort(t[:, 3])
-    print("  slowest WGs", order[-8:].tolist(), "their loop durations", (t[order[-8:], 2] - t[order[-8:], 1]).astype(int).tolist())
-    byxcd = [(t[x::8, 2] - t[x::8, 1]).mean() for x in range(8)]
-    print("  mean loop duration per XCD (wg % 8):", [int(v) for v in byxcd])
-    spans = [r[:, 3].max() for r in res]; print("  spans over 5 reps:", [int(v) for v in spans], " p50 end over reps:", [int(np.median(r[:, 3])) for r in res])
+    order = np.argsort(t[:, 4])
+    nt = int(np.isfinite(last_tiles[0]).sum())
+    per = np.diff(np.concatenate([t[:, 2:3], last_tiles[:, :nt]], axis=1), axis=1)      # [wg][tile] period
+    med = np.nanmedian(per, axis=0)
+    print(f"N={N}: tile periods (us), {nt} tiles; median over workgroups:", np.round(med, 1).tolist())
+    for w in order[-6:].tolist() + order[:2].tolist():
+        print(f"   wg {w:3d} (xcd {w % 8}) loop {t[w, 4] - t[w, 2]:7.1f} us:", np.round(per[w], 1).tolist())
+    slow = order[-32:]
+    print("   mean period of the 32 slowest WGs minus the median WG, per tile:", np.round(np.nanmean(per[slow], axis=0) - med, 2).tolist())
+    del slab, idx
+    torch.cuda.empty_cache()
