@@ -94,8 +94,8 @@ prep_queries_kernel(const void* __restrict__ q, int q_dtype, int q0, int nq, int
 // ------------------------------------------------------------------------------------------
 struct MergeParams {
     const uint16_t* slab; int64_t N; int d;
-    const uint16_t* qrow;        // [64][d]
-    const float* qeps;           // [64]
+    const void* q; int q_dtype, qbase;  // the queries [.][d] (the caller's, or the fp16 rows of the sample pass): block b converts row qbase + b itself (RNE to fp16 = `.half()`)
+    float pmax;                  // eps = GAMMA |q| pmax, as in the scan
     const uint2* lists; const uint32_t* list_cnt; const uint32_t* wg_stat; int G, cap;   // the scan's per-(workgroup, query) candidate lists
     int total_cap;               // most candidates a query may bring to the merge (more: exact path)
     const uint32_t* qflag;
@@ -164,19 +164,40 @@ merge_rescore_kernel(const MergeParams p) {
         }
     };
     if (p.dbg && q == 0 && tid == 0) p.dbg[0] = __builtin_readcyclecounter();
-    for (int i = tid; i < p.d; i += NT) qs[i] = p.qrow[(size_t)q * p.d + i];
+    // this block's query, converted here (no preparation kernel), and its certified error bound
+    double ss = 0.0;
+    for (int i = tid; i < p.d; i += NT) {
+        const size_t off = (size_t)(p.qbase + q) * p.d + i;
+        uint16_t h;
+        if (p.q_dtype == ATLAS_DT_F16) h = ((const uint16_t*)p.q)[off];
+        else if (p.q_dtype == ATLAS_DT_F32) h = __builtin_bit_cast(uint16_t, (_Float16)((const float*)p.q)[off]);
+        else h = __builtin_bit_cast(uint16_t, (_Float16)bits_f32((uint32_t)((const uint16_t*)p.q)[off] << 16));
+        qs[i] = h;
+        const double v = (double)(float)__builtin_bit_cast(_Float16, h);
+        ss += v * v;
+    }
     if (tid < 64) misc[tid] = (tid == 2) ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    double* s_ss = (double*)(misc + 32);                             // [16] per-wave partial sums
     __syncthreads();
+    if (lane == 0) s_ss[wave] = ss;
     // (0) the segment table: thread g takes workgroup g's list length for this query (and its norm / flag word: the scan's
     // certification state is reduced here, the scan kernel itself ends without a single global atomic), then a block-wide exclusive scan
     static_assert(NT >= MERGE_GMAX, "one thread per scan workgroup");
-    uint32_t cg = 0;
+    uint32_t cg = 0, pmb = 0, flg = 0;
     if (tid < p.G) {
         cg = p.list_cnt[(size_t)q * p.G + tid];
-        atomicMax(&misc[7], p.wg_stat[(size_t)tid * 2 + 0]);         // non-negative floats order like their bits
-        const uint32_t f = p.wg_stat[(size_t)tid * 2 + 1];
-        if (f) atomicOr(&misc[6], f);
+        pmb = p.wg_stat[(size_t)tid * 2 + 0];                         // non-negative floats order like their bits
+        flg = p.wg_stat[(size_t)tid * 2 + 1];
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = __shfl_xor(pmb, o);
+        pmb = a > pmb ? a : pmb;
+        flg |= __shfl_xor(flg, o);
+    }
+    if (lane == 0 && wave * 64 < p.G) { atomicMax(&misc[7], pmb); if (flg) atomicOr(&misc[6], flg); }
     uint32_t inc = cg;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -244,7 +265,9 @@ merge_rescore_kernel(const MergeParams p) {
     __syncthreads();
     if (p.dbg && q == 0 && tid == 0) p.dbg[2] = __builtin_readcyclecounter();
     float theta = neg_inf();
-    const float eps = p.qeps[q];
+    double qss = 0.0;
+    for (int w = 0; w < NT / 64; ++w) qss += s_ss[w];
+    const float eps = query_eps((float)qss * 1.000001f, p.pmax);
     if (total >= (uint32_t)k) {
         // (2) a lower bound T of the k-th largest key from ONE 1024-bin histogram over [kmin, kmax]
         // (any T with count(keys >= T) >= k is valid; the bin width, (kmax-kmin)/1024, only widens the
@@ -656,7 +679,7 @@ struct ScanPlan {
     int S; int64_t sample_stride;     // sample pre-pass: S rows (0 = none), tile j starts at j*sample_stride
     int key_cap;
     int total_cap;
-    size_t off_qfrag, off_qrow, off_qeps, off_theta0, off_gstat, off_qflag, off_sample, off_list_cnt, off_wg_stat, off_lists, total;
+    size_t off_qflag, off_gran, off_q16, off_sample, off_list_cnt, off_wg_stat, off_lists, total;
     size_t scan_lds, merge_lds;
 };
 
@@ -683,7 +706,7 @@ ScanPlan make_plan(int64_t N, int d, int k, int cus, const ScanVariant& v) {
     // LDS candidate buffer: what fits next to the 96 KiB query image. A flush into the global lists (scattered stores, the ring of slab
     // loads drained and restarted: 15-20 us per workgroup, profiles/r02/scan_tail.txt) is requested at 3/4: a 4M-row shard collects ~2.3k
     // candidates per workgroup and an 8M-row shard ~4.6k, both now end without one
-    pl.buf_cap = 7680;                                   // 60 KiB of LDS
+    pl.buf_cap = ATLAS_TUNING ? 7552 : 7680;             // 60 KiB of LDS: query image + buffer + 1.3 KiB of state = 159.3 of the 160 KiB
     pl.flush_at = pl.buf_cap * 3 / 4;
     // entries per (query, workgroup) list: what survives a compaction (keep_max) plus what one flush of the buffer normally adds to ONE
     // query (buf_cap / 64 = 120 on average). A list that overflows hands its query to the exact path (correct, slower): adversarial data only
@@ -698,20 +721,16 @@ ScanPlan make_plan(int64_t N, int d, int k, int cus, const ScanVariant& v) {
         pl.sample_stride = (N / (S / 64)) & ~(int64_t)15;
     }
     size_t o = 0;
-    pl.off_qfrag = o;  o += (size_t)QFRAG_U4 * 16;
-    pl.off_qrow = o;   o += align_up((size_t)QCHUNK * d * 2, 256);
-    pl.off_qeps = o;   o += 256;
-    pl.off_theta0 = o; o += 256;
-    pl.off_gstat = o;  o += 256;          // spare | qflag | spare are contiguous (prep zeroes them)
     pl.off_qflag = o;  o += 256;
-    o += 256;
+    pl.off_gran = o;   o += 512;
+    pl.off_q16 = o;    o += (size_t)QCHUNK * D_FAST * 2;
     pl.off_sample = o; o += (size_t)QCHUNK * SAMPLE_MAX * 4;
     pl.off_list_cnt = o; o += align_up((size_t)pl.G * 64 * 4, 256);      // every scan workgroup overwrites its 64 words: no reset
     pl.off_wg_stat = o;  o += align_up((size_t)pl.G * 2 * 4, 256);
     pl.total_cap = 131072;                // most candidates of one query the merge takes on (beyond: exact path)
     pl.off_lists = o;  o += (size_t)pl.G * 64 * pl.cap * 8;
     pl.total = align_up(o, 256);
-    pl.scan_lds = (size_t)ScanSmem::buf_off + (size_t)pl.buf_cap * 8 + (ATLAS_TUNING ? 1024 : 0);     // tuning build: + per-tile stamps
+    pl.scan_lds = (size_t)ScanSmem::buf_off + (size_t)pl.buf_cap * 8 + (ATLAS_TUNING ? 1024 : 0);     // tuning build: + per-tile stamps (its buffer is 128 entries shorter)
     const size_t merge_fixed = align_up((size_t)d * 2, 16) + 64 * 4 + (size_t)MERGE_SMAX * (4 + 4 + 8) + (size_t)(MERGE_GMAX + 8) * 4;
     pl.key_cap = (int)((160 * 1024 - 1024 - merge_fixed) / 4);
     pl.merge_lds = merge_fixed + (size_t)pl.key_cap * 4;
@@ -809,26 +828,27 @@ int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t
     hipError_t e = hipSuccess;
     for (int q0 = 0; q0 < B; q0 += QCHUNK) {
         const int nq = (B - q0 < QCHUNK) ? (B - q0) : QCHUNK;
-        hipLaunchKernelGGL(prep_queries_kernel, dim3(QCHUNK), dim3(256), 0, stream, q, q_dtype, q0, nq, d,
-                           pmax_hint, (uint16_t*)(w + pl.off_qrow), (uint16_t*)(w + pl.off_qfrag),
-                           (float*)(w + pl.off_qeps), (uint32_t*)(w + pl.off_gstat), out_status);
-        // initial thresholds: certified k-th of an evenly spread sample, or -inf
+        // initial thresholds: the scan derives them from the tile maxima of an evenly spread sample; small shards
+        // start at -inf. Whoever runs first clears the per-call state (per-query fallback flags, status header).
         if (pl.S > 0) {
             SampleParams sm{};
-            sm.slab = (const uint16_t*)slab_f16; sm.N = N; sm.qfrag = (const uint4*)(w + pl.off_qfrag);
+            sm.slab = (const uint16_t*)slab_f16; sm.N = N; sm.q = q; sm.q_dtype = q_dtype; sm.q0 = q0; sm.nq = nq;
             sm.top2 = (float*)(w + pl.off_sample); sm.S = pl.S; sm.stride_rows = pl.sample_stride;
-            hipLaunchKernelGGL(sample_scores_kernel, dim3(pl.S / 64), dim3(256), (size_t)QFRAG_U4 * 16, stream, sm);
-            hipLaunchKernelGGL(sample_theta_kernel, dim3(QCHUNK / 4), dim3(256), 0, stream,
-                               (const float*)(w + pl.off_sample), pl.S / 64, k, (const float*)(w + pl.off_qeps), nq,
-                               (float*)(w + pl.off_theta0));
+            sm.qflag = (uint32_t*)(w + pl.off_qflag); sm.theta_gran = (unsigned long long*)(w + pl.off_gran); sm.q16 = (uint4*)(w + pl.off_q16); sm.out_status = out_status;
+            hipLaunchKernelGGL(sample_scores_kernel, dim3(pl.S / 64), dim3(SAMPLE_NT), (size_t)QIMG_U4 * 16, stream, sm);
         } else {
-            e = hipMemsetD32Async((hipDeviceptr_t)(w + pl.off_theta0), (int)0xff800000u, 64, stream);   // -inf
+            e = hipMemsetAsync(w + pl.off_qflag, 0, 256, stream);
+            if (e == hipSuccess && q0 == 0) e = hipMemsetAsync(out_status, 0, ATLAS_STATUS_HEADER * 4, stream);
             if (e != hipSuccess) return (int)e;
         }
         ScanParams sp{};
         sp.slab = (const uint16_t*)slab_f16; sp.N = N;
-        sp.qfrag = (const uint4*)(w + pl.off_qfrag); sp.qeps = (const float*)(w + pl.off_qeps);
-        sp.theta0 = (const float*)(w + pl.off_theta0);
+        // after a sample pass the queries of this pass exist as fp16 rows in the workspace (its blocks wrote them): half the bytes, no conversion
+        const bool have_q16 = pl.S > 0 && pl.S / 64 >= QCHUNK;
+        sp.q = have_q16 ? (const void*)(w + pl.off_q16) : q; sp.q_dtype = have_q16 ? ATLAS_DT_F16 : q_dtype; sp.q0 = have_q16 ? 0 : q0;
+        sp.pmax = pmax_hint;
+        sp.top2 = (pl.S > 0 && pl.G >= QCHUNK) ? (const float*)(w + pl.off_sample) : nullptr; sp.sample_blocks = pl.S / 64;
+        sp.theta_gran = (unsigned long long*)(w + pl.off_gran);
         sp.lists = (uint2*)(w + pl.off_lists);
         sp.list_cnt = (uint32_t*)(w + pl.off_list_cnt); sp.wg_stat = (uint32_t*)(w + pl.off_wg_stat);
         sp.qflag = (uint32_t*)(w + pl.off_qflag);
@@ -841,7 +861,7 @@ int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t
         if (q0 == 0 && ev_scan_end) (void)hipEventRecord((hipEvent_t)ev_scan_end, stream);
         MergeParams mp{};
         mp.slab = (const uint16_t*)slab_f16; mp.N = N; mp.d = d;
-        mp.qrow = (const uint16_t*)(w + pl.off_qrow); mp.qeps = sp.qeps;
+        mp.q = sp.q; mp.q_dtype = sp.q_dtype; mp.qbase = sp.q0; mp.pmax = pmax_hint;
         mp.lists = sp.lists; mp.list_cnt = sp.list_cnt; mp.wg_stat = sp.wg_stat; mp.G = pl.G; mp.cap = pl.cap;
         mp.total_cap = pl.total_cap;
         mp.qflag = sp.qflag; mp.k = k; mp.q0 = q0; mp.key_cap = pl.key_cap;

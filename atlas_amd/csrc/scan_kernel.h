@@ -12,8 +12,10 @@
 // wall-clock stamps exist in the tuning build only: the product kernel carries no trace of them
 #if ATLAS_TUNING
 #define ATLAS_SCAN_STAMP(i) do { if (p.dbg && tid == 0) p.dbg[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define ATLAS_SCAN_STAMP_LANE0(i) do { if (p.dbg && lane == 0) p.dbg[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define ATLAS_SCAN_STAMP(i) do { } while (0)
+#define ATLAS_SCAN_STAMP_LANE0(i) do { } while (0)
 #endif
 
 namespace atlas {
@@ -26,7 +28,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define D_FAST 768               // EMBEDDINGS_DIM, src/retrievers.py:13
 #define KSTEPS (D_FAST / 32)     // 24 MFMA k-steps of 32
 #define QCHUNK 64                // queries per slab pass (4 MFMA column groups of 16)
-#define QFRAG_U4 (KSTEPS * 4 * 64)   // uint4 elements of the fragment-ordered query image
+#define QROW_U4 98               // uint4 per query row of the LDS image: 96 of data + 2 of padding
+#define QIMG_U4 (QCHUNK * QROW_U4)   // 100 352 bytes
 
 static __device__ __forceinline__ float neg_inf() { return bits_f32(0xff800000u); }
 static __device__ __forceinline__ float pos_inf() { return bits_f32(0x7f800000u); }
@@ -37,27 +40,132 @@ static __device__ __forceinline__ void wg_barrier_lds() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-
-// global -> LDS copy of the 96 KiB query image with all loads of a thread in flight at once
-// (the naive loop compiles to load / s_waitcnt vmcnt(0) / ds_write per element: one L2 latency each)
-template <int NT>
-static __device__ __forceinline__ void copy_qfrag_to_lds(uint4* __restrict__ s_q, const uint4* __restrict__ g, const int tid) {
-    constexpr int PER = (QFRAG_U4 + NT - 1) / NT;      // 6 for 1024 threads, 24 for 256
-    constexpr int BATCH = PER < 12 ? PER : 12;
+// ------------------------------------------------------------------------------------------
+// The query image. Every kernel that needs the queries on the matrix cores builds it ITSELF in LDS from the caller's
+// query tensor (fp32 | fp16 | bf16, converted RNE = `.half()`, src/index.py:117): there is no preparation kernel and no
+// image in global memory. Layout: row-major fp16, one 1568-byte row per query (768 halfs + 32 bytes of padding). The MFMA B
+// operand of v_mfma_f32_16x16x32_f16 for lane l = (query l&15 of a 16-query group, k-group l>>4) at k-step s is the 16 bytes
+// at row[64 s + 16 (l>>4)]: one ds_read_b128; with the 98-uint4 row pitch the 16 lanes of every LDS service group hit 16
+// different 4-bank windows (bank = 8 (l&15) + 4 (l>>4) mod 64): conflict-free.
+// ------------------------------------------------------------------------------------------
+struct QRaw { uint4 a, b; };      // 8 consecutive query elements as loaded (fp32: both words; 16-bit types: a only)
+static __device__ __forceinline__ QRaw load_q8(const void* __restrict__ q, const int q_dtype, const size_t elem) {
+    QRaw r; r.b = make_uint4(0, 0, 0, 0);
+    if (q_dtype == ATLAS_DT_F32) { const uint4* p = (const uint4*)((const float*)q + elem); r.a = p[0]; r.b = p[1]; }
+    else r.a = *(const uint4*)((const uint16_t*)q + elem);
+    return r;
+}
+static __device__ __forceinline__ uint32_t pack_h2(const float x, const float y) {
+    return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)x) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)y) << 16);   // v_cvt_f16_f32: RNE
+}
+static __device__ __forceinline__ uint4 q8_to_f16(const QRaw r, const int q_dtype) {
+    if (q_dtype == ATLAS_DT_F16) return r.a;
+    if (q_dtype == ATLAS_DT_F32)
+        return make_uint4(pack_h2(bits_f32(r.a.x), bits_f32(r.a.y)), pack_h2(bits_f32(r.a.z), bits_f32(r.a.w)),
+                          pack_h2(bits_f32(r.b.x), bits_f32(r.b.y)), pack_h2(bits_f32(r.b.z), bits_f32(r.b.w)));
+    const uint32_t w[4] = {r.a.x, r.a.y, r.a.z, r.a.w};               // bf16 -> f32 is exact, then RNE to fp16
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = pack_h2(bits_f32(w[i] << 16), bits_f32(w[i] & 0xffff0000u));
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+// queries [q0, q0 + nq) of `q` -> s_q; rows >= nq are zero. All loads of a batch are in flight before the first conversion.
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// `after_first_loads` runs once, when the first batch of loads has been issued and before anything waits for them
+template <int NT, class Hook = NoHook>
+static __device__ __forceinline__ void fill_query_image(uint4* __restrict__ s_q, const void* __restrict__ q, const int q_dtype,
+                                                        const int q0, const int nq, const int tid, Hook after_first_loads = Hook()) {
+    constexpr int CH = QCHUNK * (D_FAST / 8);          // 6144 chunks of 8 elements
+    constexpr int PER = CH / NT;                       // 6 per thread with 1024 threads, 24 with 256
+    constexpr int BATCH = PER % 6 == 0 ? 6 : PER % 4 == 0 ? 4 : PER % 3 == 0 ? 3 : PER % 2 == 0 ? 2 : 1;   // loads in flight per thread
+    static_assert(CH % NT == 0 && PER % BATCH == 0, "chunks must divide over the threads");
 #pragma unroll 1
     for (int b0 = 0; b0 < PER; b0 += BATCH) {
-        uint4 tmp[BATCH];
+        QRaw raw[BATCH];
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            const int i = tid + (b0 + u) * NT;
-            tmp[u] = (i < QFRAG_U4) ? g[i] : make_uint4(0, 0, 0, 0);
+            const int c = tid + (b0 + u) * NT, qi = c / (D_FAST / 8), kc = c - qi * (D_FAST / 8);
+            const int qs = qi < nq ? qi : 0;                                         // clamped: loads stay unconditional
+            raw[u] = load_q8(q, q_dtype, (size_t)(q0 + qs) * D_FAST + (size_t)kc * 8);
         }
+        if (b0 == 0) after_first_loads();
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            const int i = tid + (b0 + u) * NT;
-            if (i < QFRAG_U4) s_q[i] = tmp[u];
+            const int c = tid + (b0 + u) * NT, qi = c / (D_FAST / 8), kc = c - qi * (D_FAST / 8);
+            s_q[qi * QROW_U4 + kc] = qi < nq ? q8_to_f16(raw[u], q_dtype) : make_uint4(0, 0, 0, 0);
         }
     }
+}
+// sum of squares of query row qi of the image (one wave; every lane returns the total). fp32 accumulation of 768 exact products:
+// relative error <= 768 * 2^-24 = 4.6e-5, covered by the margin in query_eps
+static __device__ __forceinline__ float image_row_sumsq(const uint4* __restrict__ s_q, const int qi, const int lane) {
+    float ss = 0.f;
+    for (int c = lane; c < D_FAST / 8; c += 64) {
+        const uint4 v = s_q[qi * QROW_U4 + c];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f16x2 h = __builtin_bit_cast(f16x2, w[i]);
+            ss = __builtin_amdgcn_fdot2(h, h, ss, false);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    return ss;
+}
+// eps = GAMMA * |q| * pmax, rounded up (common.h: the certified bound on |approximate - exact| score)
+static __device__ __forceinline__ float query_eps(const float sumsq, const float pmax) {
+    return ATLAS_GAMMA * (sqrtf(sumsq) * 1.0001f) * pmax * 1.000001f;
+}
+
+// k-th largest of KPL register keys per lane across ONE wave (keys == 0 are padding): greedy bit
+// search below the wave's common key prefix, counting with v_cmp + s_bcnt1 only (no LDS, no barrier).
+// Returns the largest v (to `res_bits` bits below the first differing bit) with count(keys >= v) >= kk.
+template <int KPL>
+static __device__ __forceinline__ uint32_t wave_kth_key(const uint32_t (&key)[KPL], const uint32_t kk, const int res_bits) {
+    uint32_t kmax = 0, kmin = 0xffffffffu;
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) { kmax = key[u] > kmax ? key[u] : kmax; kmin = key[u] < kmin ? key[u] : kmin; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = __shfl_xor(kmax, o), b = __shfl_xor(kmin, o);
+        kmax = a > kmax ? a : kmax;
+        kmin = b < kmin ? b : kmin;
+    }
+    const uint32_t diff = kmax ^ kmin;
+    const int top = diff ? 31 - __builtin_clz(diff) : -1;
+    uint32_t prefix = (top < 0) ? kmax : ((top >= 31) ? 0u : (kmax & ~((2u << top) - 1u)));
+    const int stop = top - res_bits > 0 ? top - res_bits : 0;
+    for (int bit = top; bit >= stop; --bit) {
+        const uint32_t cand = prefix | (1u << bit);
+        uint32_t c = 0;
+#pragma unroll
+        for (int u = 0; u < KPL; ++u) c += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(key[u] >= cand));
+        if (c >= kk) prefix = cand;
+    }
+    return prefix;
+}
+
+// Certified initial threshold of one query from the sample pre-pass (one wave): the k-th largest of the 2 * nblk tile maxima
+// written by sample_scores_kernel (nblk <= 256 -> 8 keys per lane), entirely in registers. All of them are approximate scores
+// of distinct slab rows, so prune_threshold(k-th, eps) is a valid threshold for the scan; fewer than k of them: -inf.
+static __device__ __forceinline__ void load_sample_maxima(const float* __restrict__ top2_q /*[nblk][2]*/, const int nblk, const int lane,
+                                                          float (&v)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = lane + u * 64; v[u] = top2_q[2 * (i < nblk ? i : nblk - 1)]; }   // unconditional (clamped): all in flight
+}
+// The k-th largest of the <= 256 tile MAXIMA (the runner-up of each tile is left out: any subset of real scores gives a valid, slightly
+// lower threshold -- the k-th of the maxima is about the (1.08 k)-th of the whole sample -- and the search is half as long), 14 bits below
+// the first bit in which they differ (a threshold 2^-14 of the score range lower lets ~0.1 % more candidates through).
+static __device__ __forceinline__ float initial_theta(const float (&v)[4], const int nblk, const int k, const float eps, const int lane) {
+    uint32_t key[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) key[u] = (lane + u * 64 < nblk && v[u] > neg_inf()) ? f32_order_key(v[u]) : 0u;   // 0 = padding, below every real key
+    uint32_t valid = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) valid += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(key[u] != 0u));
+    const uint32_t kth = wave_kth_key<4>(key, (uint32_t)k, 14);
+    return (valid >= (uint32_t)k) ? prune_threshold(f32_from_order_key(kth), eps) : neg_inf();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -66,9 +174,13 @@ static __device__ __forceinline__ void copy_qfrag_to_lds(uint4* __restrict__ s_q
 struct ScanParams {
     const uint16_t* slab;     // [N][768] fp16
     int64_t N;
-    const uint4* qfrag;       // [24][4][64] uint4
-    const float* qeps;        // [64]
-    const float* theta0;      // [64] initial per-query thresholds from the sample pre-pass (or -inf)
+    const void* q;            // the caller's queries [B][768], element type q_dtype; this pass takes rows [q0, q0 + nq)
+    int q_dtype, q0;
+    float pmax;               // upper bound on the slab's row norms (eps = GAMMA |q| pmax)
+    const float* top2;        // [64][2 * sample_blocks] tile maxima of the sample pre-pass, or null: thresholds start at -inf
+    int sample_blocks;
+    unsigned long long* theta_gran;   // [64] {tag, threshold bits}: workgroup q publishes query q's initial threshold, everybody collects
+                                      // all 64 (cleared by the sample kernel that ran before)
     uint2* lists;             // [64][G][cap]  {f32 bits of approx score, row}: the candidates of workgroup g for query q
     uint32_t* list_cnt;       // [64][G] entries of lists[q][g] at the end of the scan (plain stores: every workgroup writes its 64)
     uint32_t* wg_stat;        // [G][2]  per workgroup: largest row sum of squares seen (float bits) | ATLAS_F_* flags
@@ -82,11 +194,11 @@ struct ScanParams {
 };
 
 struct ScanSmem {   // byte offsets into dynamic LDS
-    static constexpr int q_off = 0;                       // 98304 B
-    static constexpr int theta_off = QFRAG_U4 * 16;       // 64 f32
+    static constexpr int q_off = 0;                       // 100352 B: the query image (fill_query_image)
+    static constexpr int theta_off = QIMG_U4 * 16;        // 64 f32
     static constexpr int cnt_off = theta_off + 256;       // 64 u32
     static constexpr int flag_off = cnt_off + 256;        // 64 B: [0],[1] flush/compaction request by tile parity, [2] buffer fill
-    static constexpr int aux_off = flag_off + 64;         // 3 x 64 u32: per-query base / running position / buffered count (final hand-over)
+    static constexpr int aux_off = flag_off + 64;         // 768 B: [0, 256) per-wave norm maxima (final hand-over), [256, 512) per-query eps
     static constexpr int buf_off = aux_off + 768;         // buf_cap x {u32 score bits, u32 (query<<26)|row}
 };
 
@@ -165,17 +277,71 @@ scan_kernel(const ScanParams p) {
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    // the query image is copied into LDS AFTER the first ring loads are in flight (their HBM latency
-    // overlaps the 96 KiB copy from L2)
+    // the query image is built in LDS AFTER the first ring loads are in flight (their HBM latency overlaps it), straight from the
+    // caller's tensor; then every wave derives eps and the initial threshold of its share of the queries
     ATLAS_SCAN_STAMP(1);        // [1] ring prologue issued
-    copy_qfrag_to_lds<NW * 64>(s_q, p.qfrag, tid);
-    if (tid < 64) {
-        s_theta[tid] = (tid < p.nq) ? p.theta0[tid] : pos_inf();
-        s_cnt[tid] = 0;
+    // Initial thresholds. Deriving one (the k-th largest of 512 sample maxima, a bit search with ballots) costs ~1 us for one wave --
+    // but 64 of them on every CU were 30 us of start-up (4 waves share a SIMD). So the last wave of workgroup q derives the threshold of
+    // query q alone -- its inputs (the query's row, for eps, and the sample maxima) are requested before the image loads and it works
+    // on them while those land -- and publishes it as one 8-byte {tag, value} granule (one write-through store); the last wave of every
+    // workgroup then collects the 64 granules. Workgroups 0..63 are dispatched first; the wait is bounded, and a threshold that has not
+    // arrived in time simply starts at -inf (slower, never wrong).
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    gu64* gran = (gu64*)p.theta_gran;
+    const bool exchange = p.top2 != nullptr;
+    const bool theta_wave = exchange && wave == NW - 1 && (int)blockIdx.x < p.nq;       // wave-uniform
+    float tv[4];
+    QRaw trow[2];                                       // the 768 elements of query blockIdx.x: 12 per lane = two 8-element pieces, 4 unused
+    if (theta_wave) {
+        load_sample_maxima(p.top2 + (size_t)blockIdx.x * 2 * p.sample_blocks, p.sample_blocks, lane, tv);
+        const size_t base = (size_t)(p.q0 + (int)blockIdx.x) * D_FAST;
+        trow[0] = load_q8(p.q, p.q_dtype, base + (size_t)lane * 8);                         // chunks 0..63
+        trow[1] = load_q8(p.q, p.q_dtype, base + (size_t)(64 + (lane & 31)) * 8);           // chunks 64..95 (lanes >= 32 repeat them)
     }
+    fill_query_image<NW * 64>(s_q, p.q, p.q_dtype, p.q0, p.nq, tid, [&]() {
+        if (!theta_wave) return;
+        float ss = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint4 v = q8_to_f16(trow[h], p.q_dtype);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            if (h == 0 || lane < 32) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const f16x2 x = __builtin_bit_cast(f16x2, w[i]); ss = __builtin_amdgcn_fdot2(x, x, ss, false); }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        const float th = initial_theta(tv, p.sample_blocks, p.k, query_eps(ss, p.pmax), lane);
+        if (lane == 0) __hip_atomic_store(gran + blockIdx.x, (1ull << 32) | (unsigned long long)f32_bits(th), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ATLAS_SCAN_STAMP_LANE0(6);   // [6] threshold of query blockIdx.x published
+    });
+    if (tid < 64) s_cnt[tid] = 0;
     if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; }
     __syncthreads();
-    ATLAS_SCAN_STAMP(2);        // [2] query image in LDS
+    float* s_eps = (float*)(smem + ScanSmem::aux_off + 256);
+    if (wave == NW - 1) ATLAS_SCAN_STAMP_LANE0(1);   // [1] (re-stamped) image barrier passed
+    for (int qq = wave; qq < QCHUNK; qq += NW) {
+        const float eps = qq < p.nq ? query_eps(image_row_sumsq(s_q, qq, lane), p.pmax) : 0.f;
+        if (lane == 0) s_eps[qq] = eps;
+    }
+    if (exchange) {
+        if (wave == NW - 1) {
+            unsigned long long g = 0ull;
+            const bool want = lane < p.nq;
+            for (int spin = 0; spin < 4000; ++spin) {
+                if (want && (g >> 32) == 0ull) g = __hip_atomic_load(gran + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_ballot_w64(want && (g >> 32) == 0ull) == 0ull) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            s_theta[lane] = want ? ((g >> 32) != 0ull ? bits_f32((uint32_t)g) : neg_inf()) : pos_inf();
+            ATLAS_SCAN_STAMP_LANE0(7);   // [7] all thresholds collected
+        }
+    } else if (tid < 64) {
+        s_theta[tid] = (tid < p.nq) ? neg_inf() : pos_inf();      // query slots beyond nq never collect anything
+    }
+    __syncthreads();
+    ATLAS_SCAN_STAMP(2);        // [2] query image, eps and thresholds in LDS
 
     f32x4 acc[PF][4];
 #pragma unroll
@@ -242,7 +408,7 @@ scan_kernel(const ScanParams p) {
                 }
                 if (c >= (uint32_t)p.k) prefix = cand;
             }
-            const float theta = prune_threshold(f32_from_order_key(prefix), p.qeps[qq]);
+            const float theta = prune_threshold(f32_from_order_key(prefix), s_eps[qq]);
             // in-place stable compaction of entries with score > theta
             uint32_t kept = 0;
             for (uint32_t i0 = 0; i0 < n; i0 += 64) {
@@ -277,7 +443,10 @@ scan_kernel(const ScanParams p) {
     // barrier) hangs off every RPT-th revolution.
 #pragma unroll 1
     for (int rev = 0; rev < ntiles * RPT; ++rev) {
-        const uint4* bq = s_q + lane + cstep * (4 * 64);
+        // B operands of this revolution: query rows (16 qf + lrow), 16 bytes at k-step * 64 + 16 * lgrp (two bases: the offset of
+        // query group 3 does not fit the 16-bit immediate of ds_read_b128)
+        const uint4* bq0 = s_q + lrow * QROW_U4 + lgrp + cstep * 4;
+        const uint4* bq2 = bq0 + 32 * QROW_U4;
 #pragma unroll
         for (int j = 0; j < RING; ++j) {
             // refill the slot freed by the previous step first (its loads stay in flight for
@@ -291,7 +460,7 @@ scan_kernel(const ScanParams p) {
             __builtin_amdgcn_sched_barrier(0);
             uint4 b[4];
 #pragma unroll
-            for (int qf = 0; qf < 4; ++qf) b[qf] = bq[(j * 4 + qf) * 64];
+            for (int qf = 0; qf < 4; ++qf) b[qf] = (qf < 2 ? bq0 : bq2)[(qf & 1) * 16 * QROW_U4 + j * 4];
 #pragma unroll
             for (int pf = 0; pf < PF; ++pf) {
                 const u32x4 a = abuf[j][pf];
@@ -447,45 +616,64 @@ scan_kernel(const ScanParams p) {
 
 
 // ------------------------------------------------------------------------------------------
-// sample pre-pass: approximate scores of S evenly spread rows -> sample_scores,
-// from which sample_theta_kernel derives a certified initial threshold per query. Without it
+// sample pre-pass: approximate scores of S evenly spread rows -> the two best per 64-row tile and query,
+// from which every scan workgroup derives a certified initial threshold per query (initial_theta). Without it
 // every workgroup starts at -inf and pays a "cold start" (its first tile passes entirely).
 //   grid = S/64 blocks of 256 threads; wave w of block j scores rows row(j) + 16w .. +16
 // ------------------------------------------------------------------------------------------
 struct SampleParams {
     const uint16_t* slab; int64_t N;
-    const uint4* qfrag;
+    const void* q; int q_dtype, q0, nq;   // the caller's queries: every block converts them into its own LDS image (fill_query_image)
     float* top2;              // [64][S/64][2]: the two best approximate scores of each 64-row sample tile
     int S;                    // multiple of 64
     int64_t stride_rows;      // first row of sample tile j = j * stride_rows (multiple of 16, >= 64)
+    uint32_t* qflag;          // [64] per-query fallback flags of the scan that follows: cleared here (block 0)
+    unsigned long long* theta_gran;   // [64] threshold granules of the scan that follows: cleared here (block 0)
+    uint4* q16;               // [64][96] the queries of this pass as fp16 rows: block j < 64 writes row j of its image (the scan and the
+                              // merge then read 2-byte queries whatever the caller's dtype)
+    int32_t* out_status;      // status header: cleared by block 0 when this is the first 64-query pass of the call
 };
 
-__global__ void __launch_bounds__(256)
+// 512 threads: waves 0..3 score 16 rows each, all 8 waves convert the queries (the block's 192 KiB of fp32 queries in two batches of
+// loads per thread instead of four: the conversion, not the 64 rows, is what this kernel's time is made of)
+#define SAMPLE_NT 512
+__global__ void __launch_bounds__(SAMPLE_NT)
 sample_scores_kernel(const SampleParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* s_q = (uint4*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool scorer = wave < 4;                 // wave-uniform
     const int lrow = lane & 15, lgrp = lane >> 4;
-    const int64_t row0 = (int64_t)blockIdx.x * p.stride_rows + wave * 16;
+    // per-call state of the kernels that follow (the scan sets qflag, the merge accumulates into the status header)
+    if (blockIdx.x == 0) {
+        if (tid < QCHUNK) { p.qflag[tid] = 0u; p.theta_gran[tid] = 0ull; }
+        if (p.q0 == 0 && tid < ATLAS_STATUS_HEADER) p.out_status[tid] = 0;
+    }
+    const int64_t row0 = (int64_t)blockIdx.x * p.stride_rows + (wave & 3) * 16;
     int64_t r = row0 + lrow;
     if (r >= p.N) r = p.N - 1;
     const uint4* src = (const uint4*)((const unsigned char*)p.slab + r * (int64_t)(D_FAST * 2) + lgrp * 16);
-    // all 24 fragments of this wave's 16 rows go out first (HBM latency overlaps the query copy)
+    // all 24 fragments of a scoring wave's 16 rows go out first (HBM latency overlaps the query conversion)
     uint4 a[KSTEPS];
+    if (scorer) {
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) a[s] = src[s * 4];
-    copy_qfrag_to_lds<256>(s_q, p.qfrag, tid);
+        for (int s = 0; s < KSTEPS; ++s) a[s] = src[s * 4];
+    }
+    fill_query_image<SAMPLE_NT>(s_q, p.q, p.q_dtype, p.q0, p.nq, tid);
     __syncthreads();
+    if (blockIdx.x < QCHUNK && tid < D_FAST / 8) p.q16[blockIdx.x * (D_FAST / 8) + tid] = s_q[blockIdx.x * QROW_U4 + tid];
     f32x4 acc[4];
 #pragma unroll
     for (int qf = 0; qf < 4; ++qf) acc[qf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (scorer) {
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) {
-        const f16x8 av = __builtin_bit_cast(f16x8, a[s]);
+        for (int s = 0; s < KSTEPS; ++s) {
+            const f16x8 av = __builtin_bit_cast(f16x8, a[s]);
 #pragma unroll
-        for (int qf = 0; qf < 4; ++qf)
-            acc[qf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                av, __builtin_bit_cast(f16x8, s_q[(s * 4 + qf) * 64 + lane]), acc[qf], 0, 0, 0);
+            for (int qf = 0; qf < 4; ++qf)
+                acc[qf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                    av, __builtin_bit_cast(f16x8, s_q[(qf * 16 + lrow) * QROW_U4 + s * 4 + lgrp]), acc[qf], 0, 0, 0);
+        }
     }
     // two best scores per query over this block's 64 rows: per lane (4 rows) -> across the 4 lane groups
     // that share a query column (xor 16, 32) -> across the 4 waves through LDS. Any subset of real
@@ -509,7 +697,7 @@ sample_scores_kernel(const SampleParams p) {
         merge2(t1[qf], t2[qf], __shfl_xor(t1[qf], 32), __shfl_xor(t2[qf], 32));
     }
     __syncthreads();                                  // everyone is done reading the query image
-    if (lgrp == 0) {
+    if (scorer && lgrp == 0) {
 #pragma unroll
         for (int qf = 0; qf < 4; ++qf) {
             s_t2[(wave * 64 + qf * 16 + lrow) * 2 + 0] = t1[qf];
@@ -525,58 +713,6 @@ sample_scores_kernel(const SampleParams p) {
         p.top2[((size_t)tid * nblk + blockIdx.x) * 2 + 0] = a1;
         p.top2[((size_t)tid * nblk + blockIdx.x) * 2 + 1] = a2;
     }
-}
-
-// k-th largest of KPL register keys per lane across ONE wave (keys == 0 are padding): greedy bit
-// search below the wave's common key prefix, counting with v_cmp + s_bcnt1 only (no LDS, no barrier).
-// Returns the largest v (to `res_bits` bits below the first differing bit) with count(keys >= v) >= kk.
-template <int KPL>
-static __device__ __forceinline__ uint32_t wave_kth_key(const uint32_t (&key)[KPL], const uint32_t kk, const int res_bits) {
-    uint32_t kmax = 0, kmin = 0xffffffffu;
-#pragma unroll
-    for (int u = 0; u < KPL; ++u) { kmax = key[u] > kmax ? key[u] : kmax; kmin = key[u] < kmin ? key[u] : kmin; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t a = __shfl_xor(kmax, o), b = __shfl_xor(kmin, o);
-        kmax = a > kmax ? a : kmax;
-        kmin = b < kmin ? b : kmin;
-    }
-    const uint32_t diff = kmax ^ kmin;
-    const int top = diff ? 31 - __builtin_clz(diff) : -1;
-    uint32_t prefix = (top < 0) ? kmax : ((top >= 31) ? 0u : (kmax & ~((2u << top) - 1u)));
-    const int stop = top - res_bits > 0 ? top - res_bits : 0;
-    for (int bit = top; bit >= stop; --bit) {
-        const uint32_t cand = prefix | (1u << bit);
-        uint32_t c = 0;
-#pragma unroll
-        for (int u = 0; u < KPL; ++u) c += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(key[u] >= cand));
-        if (c >= kk) prefix = cand;
-    }
-    return prefix;
-}
-
-// One wave per query (4 queries per 256-thread block): k-th largest of the 2*nblk tile maxima written by
-// sample_scores_kernel (nblk <= 256 -> 8 keys per lane), entirely in registers. All of them are scores of
-// distinct slab rows, so prune_threshold(k-th) is a certified initial threshold for the scan.
-__global__ void __launch_bounds__(256)
-sample_theta_kernel(const float* __restrict__ top2, int nblk, int k, const float* __restrict__ qeps, int nq,
-                    float* __restrict__ theta0) {
-    const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= 64) return;
-    if (q >= nq) { if (lane == 0) theta0[q] = pos_inf(); return; }
-    const int n = nblk * 2;
-    uint32_t key[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int i = lane + u * 64;
-        const float v = top2[(size_t)q * n + (i < n ? i : n - 1)];      // unconditional (clamped) loads: all in flight
-        key[u] = (i < n && v > neg_inf()) ? f32_order_key(v) : 0u;       // 0 = padding, below every real key
-    }
-    uint32_t valid = 0;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) valid += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(key[u] != 0u));
-    const uint32_t kth = wave_kth_key<8>(key, (uint32_t)k, 22);
-    if (lane == 0) theta0[q] = (valid >= (uint32_t)k) ? prune_threshold(f32_from_order_key(kth), qeps[q]) : neg_inf();
 }
 
 }  // namespace atlas

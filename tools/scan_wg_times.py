@@ -38,7 +38,9 @@ for N in [int(a) for a in sys.argv[1:]] or [1_000_000, 4_000_000]:
         rows_wg = -(-(N // 16) // 256) * 16
         print(f"N={N} rep {rep}: kernel span (first entry -> last hand-over) = {t[:, 5].max():.2f} us; ideal at 6.05 TB/s = {N * 1536 / 6.05e6:.2f} us")
         print("  entry (abs)            ", f(t[:, 0]))
-        print("  ring prologue issued   ", f(t[:, 1] - t[:, 0]), "(since entry)")
+        print("  image barrier passed   ", f(t[:, 1] - t[:, 0]), "(since entry)")
+        print("  threshold published    ", f(t[:64, 6] - t[:64, 0]), "(since entry, workgroups 0..63)")
+        print("  thresholds collected   ", f(t[:, 7] - t[:, 0]), "(since entry)")
         print("  query image in LDS     ", f(t[:, 2] - t[:, 0]), "(since entry)")
         print("  first tile done        ", f(t[:, 3] - t[:, 0]), "(since entry)")
         print("  loop (image -> last)   ", f(t[:, 4] - t[:, 2]), "(duration)")
