@@ -11,4 +11,4 @@ print("32M: %.1f q/s step %.3f ms kernel %.3f ms frac %.3f" % (d["value"], d["ms
 for n, v in d["shard_sweep"].items(): print(n, {k: round(x, 4) for k, x in v.items()})
 print(d["detail"])
 PY
-timeout 300 python tools/merge_phases.py 1000000 4000000 > $OUT/merge_phases.txt 2>&1; tail -2 $OUT/merge_phases.txt; timeout 300 python tools/scan_wg_times.py 1000000 > $OUT/scan_wg_times.txt 2>&1; grep -E "kernel span|image barrier|published|collected|query image|first tile" $OUT/scan_wg_times.txt | head -7
+timeout 300 python tools/merge_phases.py 1000000 4000000 > $OUT/merge_phases.txt 2>&1; tail -2 $OUT/merge_phases.txt; timeout 300 python tools/scan_wg_times.py 1000000 4000000 > $OUT/scan_wg_times.txt 2>&1; grep -E "kernel span|WGs still|mean loop per XCD" $OUT/scan_wg_times.txt
