@@ -3,8 +3,9 @@
 Replaces the hot-path use of src/dist_utils.py (varsize_all_gather :46-69, varsize_gather :72-99,
 get_varsize :102-113). The reference issues 3 + 4*W collectives per search_knn call (SURVEY §2.3
 C1-C5); here a search is: one size all_gather + one padded fp16 query all_gather (C1+C2, C3 is
-redundant and dropped), one all_gather of packed (score,id) candidates (replaces C4+C5), and one
-object all_gather of the winning passages.
+redundant and dropped), one all_gather of packed (score,id) candidates (replaces C4+C5), and a
+personalised exchange of the winning passages (every rank receives the k winners of ITS OWN queries
+only; no text collective at all with a node-local passage store attached).
 
 `backend="nccl"` on PyTorch-ROCm is RCCL; tensors handed to a collective live on the device the
 process group's backend expects (cuda for nccl, cpu for gloo) — callers pass device tensors.
@@ -69,6 +70,38 @@ def all_gather_packed(packed: torch.Tensor) -> torch.Tensor:
     out = torch.empty((W * B, k), dtype=packed.dtype, device=packed.device)   # concatenation along dim 0
     dist.all_gather_into_tensor(out, packed.contiguous())
     return out.view(W, B, k)
+
+
+def _collective_device() -> torch.device:
+    """where tensors handed to a collective must live: the GPU for nccl (= RCCL), the host for gloo"""
+    if dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def exchange_objects(per_dst: list) -> list:
+    """Personalised all-to-all of python objects: rank r receives [per_dst[r] of rank 0, ..., of rank W-1]. Two collectives
+    (sizes, then the pickled bytes with uneven splits): every rank gets exactly what was addressed to it, nothing else."""
+    if not is_initialized():
+        return [per_dst[0]]
+    import pickle
+
+    W, dev = dist.get_world_size(), _collective_device()
+    assert len(per_dst) == W
+    blobs = [pickle.dumps(o, protocol=pickle.HIGHEST_PROTOCOL) for o in per_dst]
+    send_sizes = torch.tensor([len(b) for b in blobs], dtype=torch.int64, device=dev)
+    recv_sizes = torch.empty(W, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(recv_sizes, send_sizes)
+    recv_sizes = recv_sizes.tolist()
+    payload = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).to(dev) if sum(len(b) for b in blobs) else torch.empty(0, dtype=torch.uint8, device=dev)
+    inbox = torch.empty(int(sum(recv_sizes)), dtype=torch.uint8, device=dev)
+    dist.all_to_all_single(inbox, payload, output_split_sizes=recv_sizes, input_split_sizes=[len(b) for b in blobs])
+    raw = inbox.cpu().numpy().tobytes()
+    out, at = [], 0
+    for n in recv_sizes:
+        out.append(pickle.loads(raw[at: at + n]))
+        at += n
+    return out
 
 
 def all_gather_object(obj) -> list:

@@ -17,11 +17,12 @@ What differs underneath:
     lowest passage id — the summation-order / tie-order independent member of the family of
     results the reference's backend may produce (include/atlas_hip.h);
   * the distributed search uses one packed (score,id) all-gather instead of 4*W pickled
-    gathers, and ships passage text only for the k winners of each query.
+    gathers, and ships passage text only for the k winners of each query, to the rank that asked.
 
 There is no CPU path: every compute call goes through atlas_amd/_lib.py and raises if the HIP
 library is missing or the slab is not on a GPU.
 """
+import logging
 import os
 import pickle
 from typing import List, Optional, Tuple
@@ -32,6 +33,7 @@ import torch
 from . import _lib, dist_utils
 
 EMBEDDINGS_DIM: int = 768  # src/retrievers.py:13
+logger = logging.getLogger(__name__)
 
 _GID_BITS = 47
 _GID_MASK = (1 << _GID_BITS) - 1
@@ -85,6 +87,7 @@ class HipDistributedIndex(object):
         self._gid_offset = 0
         self._gid_bounds = None         # contiguous mode: cumulative shard sizes of all ranks
         self._passage_store = None      # optional node-local PassageStore (attach_passage_store)
+        self._warned_exact = set()
         self.last_search_stats = {}
 
     def attach_passage_store(self, store) -> None:
@@ -279,6 +282,10 @@ class HipDistributedIndex(object):
         if d != _lib.D_FAST or k > _lib.K_FAST_MAX:
             if k > _lib.K_EXACT_MAX:
                 raise _lib.AtlasHipError(f"topk={k} exceeds the supported maximum {_lib.K_EXACT_MAX}")
+            if (d, k) not in self._warned_exact:       # same canonical result, but one fp64 slab pass per 8 queries instead of the MFMA scan
+                self._warned_exact.add((d, k))
+                logger.warning("topk=%d / d=%d is outside the fused scan (d == %d, k <= %d): whole batches take the exact path "
+                               "(~15 ms per 8 queries at 32M rows)", k, d, _lib.D_FAST, _lib.K_FAST_MAX)
             s, i = self._exact_topk(q, k)
             self.last_search_stats = {"path": "exact"}
             return s, i, s.cpu().numpy(), i.cpu().numpy()
@@ -375,11 +382,17 @@ class HipDistributedIndex(object):
             out_scores = [[float(s) for s, g in zip(m_scores[b], m_gid[b]) if g >= 0] for b in range(lo, hi)]
             return docs, out_scores
         owner, local = self._gid_owner(np.maximum(m_gid, 0))
-        # passage text: each rank contributes the winners it owns (k per query, not W*k)
+        # passage text: for every rank, the winners of ITS queries that live in this shard (k per query and destination, not
+        # W*k, and nothing a rank did not ask for), in one personalised exchange
+        W = dist_utils.get_world_size()
         mine = (owner == rank) & (m_gid >= 0)
-        contrib = {int(g): self.doc_map[int(l)] for g, l in zip(m_gid[mine], local[mine])}
+        outbox = []
+        for dst in range(W):
+            rows = slice(int(bounds[dst]), int(bounds[dst + 1]))
+            sel = mine[rows]
+            outbox.append({int(g): self.doc_map[int(l)] for g, l in zip(m_gid[rows][sel], local[rows][sel])})
         table = {}
-        for part in dist_utils.all_gather_object(contrib):
+        for part in dist_utils.exchange_objects(outbox):
             table.update(part)
         docs = [[table[int(g)] for g in m_gid[b] if g >= 0] for b in range(lo, hi)]
         out_scores = [[float(s) for s, g in zip(m_scores[b], m_gid[b]) if g >= 0] for b in range(lo, hi)]

@@ -49,8 +49,20 @@ def _worker(rank, W, port, N, batches, k, out_dir, mode):
             du.get_rank, du.get_world_size = r, w
         dist.barrier()
         idx.load_index(out_dir, 2 * W)
+    import atlas_amd.dist_utils as du0
+    real_exchange, received = du0.exchange_objects, []
+
+    def counting_exchange(per_dst):
+        got = real_exchange(per_dst)
+        received.append(sum(len(part) for part in got))
+        return got
+
+    du0.exchange_objects = counting_exchange
     for rep in range(2):                                    # search_knn is a collective: call it twice
         docs, scores = idx.search_knn(Q, k)
+    du0.exchange_objects = real_exchange
+    # the text exchange is personalised: a rank receives the k winners of each of ITS OWN queries and nothing else
+    assert received == [batches[rank] * k] * 2, (received, batches[rank] * k)
     # the same search with a node-local passage store attached: no text collective, same documents
     from atlas_amd.passage_store import PassageStore
     spath = os.path.join(out_dir, "store_" + mode)
@@ -62,9 +74,11 @@ def _worker(rank, W, port, N, batches, k, out_dir, mode):
     idx.attach_passage_store(store)
     import atlas_amd.dist_utils as du2
     real_gather = du2.all_gather_object
+    real_x = du2.exchange_objects
     du2.all_gather_object = lambda obj: (_ for _ in ()).throw(AssertionError("text collective used despite the passage store"))
+    du2.exchange_objects = lambda per_dst: (_ for _ in ()).throw(AssertionError("text collective used despite the passage store"))
     docs2, scores2 = idx.search_knn(Q, k)
-    du2.all_gather_object = real_gather
+    du2.all_gather_object, du2.exchange_objects = real_gather, real_x
     assert docs2 == docs and scores2 == scores
     ids = np.array([[int(d["id"]) for d in row] for row in docs], dtype=np.int64).reshape(len(docs), k)
     assert all(d["text"] == f"p{d['id']}" for row in docs for d in row)

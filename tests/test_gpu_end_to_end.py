@@ -241,13 +241,14 @@ def test_save_load_search_and_passage_store_over_rccl(gpu_index_cls, oracle_mod,
         idx2.load_index(str(tmp_path), 8)
         store = PassageStore.open_shared(str(tmp_path / "store"), lambda: PassageStore.iter_saved_index(str(tmp_path), 8), signature="t")
         idx2.attach_passage_store(store)
-        real = dist_utils.all_gather_object
+        real, real_x = dist_utils.all_gather_object, dist_utils.exchange_objects
         calls = []
         dist_utils.all_gather_object = lambda obj: calls.append(1) or real(obj)
+        dist_utils.exchange_objects = lambda per_dst: calls.append(1) or real_x(per_dst)
         try:
             docs2, scores2 = idx2.search_knn(torch.from_numpy(Q).cuda(), k)
         finally:
-            dist_utils.all_gather_object = real
+            dist_utils.all_gather_object, dist_utils.exchange_objects = real, real_x
         assert not calls, "text collective used despite the passage store"
         assert docs2 == docs and scores2 == scores
     finally:
