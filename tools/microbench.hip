@@ -1,5 +1,5 @@
 // microbench.hip — tuning harness (NOT part of the product library): streams the slab with different
-// access patterns and runs scan_kernel variants, timing each with hipEvents.
+// access patterns timing each with hipEvents (the scan-variant half moved to the tuning build of the library: tools/scan_policy.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -84,47 +84,5 @@ extern "C" float mb_stream(int pattern, int ring, const void* slab, int64_t N, u
     if (pattern == 1 && ring == 24) return go(stream_kernel<1, 4, 24>);
     if (pattern == 2 && ring == 4) return go(stream_kernel<2, 4, 4>);
     if (pattern == 2 && ring == 12) return go(stream_kernel<2, 4, 12>);
-    return -1.f;
-}
-
-// ---- scan_kernel variants ----
-struct Plan { int G; int64_t rows_per_wg; int keep_max, cap, buf_cap; size_t lds; };
-template <int NW, int PF>
-static Plan plan(int64_t N, int k) {
-    Plan p; int64_t frags = (N + 15) / 16; int64_t G = 256;
-    if (G > (frags + NW - 1) / NW) G = (frags + NW - 1) / NW; if (G < 1) G = 1;
-    p.G = (int)G; p.rows_per_wg = ((frags + G - 1) / G) * 16;
-    p.keep_max = (2 * k > k + 64) ? 2 * k : k + 64; p.buf_cap = 4096; p.cap = p.keep_max + p.buf_cap + NW * PF * 16;
-    p.lds = (size_t)ScanSmem::buf_off + (size_t)p.buf_cap * 8;
-    return p;
-}
-
-template <int NW, int PF, int RING>
-static float run_scan(const void* slab, int64_t N, const void* qfrag, const void* qeps, const void* theta0, void* ws, int nq, int k, int iters) {
-    Plan pl = plan<NW, PF>(N, k);
-    unsigned char* w = (unsigned char*)ws;
-    ScanParams sp{};
-    sp.slab = (const uint16_t*)slab; sp.N = N; sp.qfrag = (const uint4*)qfrag; sp.qeps = (const float*)qeps; sp.theta0 = (const float*)theta0;
-    sp.gstat = (uint32_t*)w; sp.qflag = (uint32_t*)(w + 256); sp.dense_cnt = (uint32_t*)(w + 512);
-    sp.dense = (uint2*)(w + 1024); sp.dense_cap = 32768;
-    sp.lists = (uint2*)(w + 1024 + 64 * 32768 * 8);
-    sp.rows_per_wg = pl.rows_per_wg; sp.nq = nq; sp.k = k; sp.cap = pl.cap; sp.keep_max = pl.keep_max; sp.buf_cap = pl.buf_cap; sp.pmax2_hint = 4.0f;
-    auto kern = scan_kernel<NW, PF, RING>;
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    return time_ms([&] { hipMemsetAsync(w, 0, 1024, 0); hipLaunchKernelGGL(kern, dim3(pl.G), dim3(NW * 64), pl.lds, 0, sp); }, iters);
-}
-
-extern "C" float mb_scan(int variant, const void* slab, int64_t N, const void* qfrag, const void* qeps, const void* theta0, void* ws, int nq, int k, int iters) {
-    switch (variant) {
-        case 0: return run_scan<8, 4, 4>(slab, N, qfrag, qeps, theta0, ws, nq, k, iters);
-        case 1: return run_scan<8, 4, 3>(slab, N, qfrag, qeps, theta0, ws, nq, k, iters);
-        case 2: return run_scan<8, 4, 6>(slab, N, qfrag, qeps, theta0, ws, nq, k, iters);
-        case 3: return run_scan<8, 2, 4>(slab, N, qfrag, qeps, theta0, ws, nq, k, iters);
-        case 4: return run_scan<8, 2, 8>(slab, N, qfrag, qeps, theta0, ws, nq, k, iters);
-        case 5: return run_scan<12, 2, 4>(slab, N, qfrag, qeps, theta0, ws, nq, k, iters);
-        case 6: return run_scan<16, 2, 4>(slab, N, qfrag, qeps, theta0, ws, nq, k, iters);
-        case 7: return run_scan<16, 1, 8>(slab, N, qfrag, qeps, theta0, ws, nq, k, iters);
-        case 8: return run_scan<4, 4, 6>(slab, N, qfrag, qeps, theta0, ws, nq, k, iters);
-    }
     return -1.f;
 }
