@@ -98,7 +98,8 @@ struct MergeParams {
     float pmax;                  // eps = GAMMA |q| pmax, as in the scan
     const uint2* lists; const uint32_t* list_cnt; const uint32_t* wg_stat; int G, cap;   // the scan's per-(workgroup, query) candidate lists
     int total_cap;               // most candidates a query may bring to the merge (more: exact path)
-    const uint32_t* qflag;
+    uint32_t* epoch;             // per-workspace call counter: block 0 bumps it (the next scan's granule tag)
+    uint32_t* qflag;             // read, then cleared for the next call by the block that owns the query
     int k, q0;                   // q0: first query of this chunk (output row offset)
     int key_cap;                 // approximate-score keys that fit in LDS
     unsigned long long* dbg;     // optional per-phase cycle stamps of block 0 (tuning only; null in production)
@@ -177,11 +178,18 @@ merge_rescore_kernel(const MergeParams p) {
         ss += v * v;
     }
     if (tid < 64) misc[tid] = (tid == 2) ? 0xffffffffu : 0u;
+    uint32_t flagged = 0u;
+    if (tid == 0) {                      // per-call state kept in the workspace is put back for the next call here: this block is the only
+        flagged = p.qflag[q];            // reader of its query's flag, and every scan workgroup has finished
+        p.qflag[q] = 0u;
+        if (q == 0) *p.epoch = *p.epoch + 1u;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     double* s_ss = (double*)(misc + 32);                             // [16] per-wave partial sums
     __syncthreads();
     if (lane == 0) s_ss[wave] = ss;
+    if (tid == 0) misc[8] = flagged;
     // (0) the segment table: thread g takes workgroup g's list length for this query (and its norm / flag word: the scan's
     // certification state is reduced here, the scan kernel itself ends without a single global atomic), then a block-wide exclusive scan
     static_assert(NT >= MERGE_GMAX, "one thread per scan workgroup");
@@ -213,7 +221,7 @@ merge_rescore_kernel(const MergeParams p) {
     __syncthreads();
     const uint32_t total = s_off[p.G];
     // the scan flagged this query (band overflow), or it brings more candidates than the merge is sized for: exact path
-    if (p.qflag[q] != 0u || total > (uint32_t)p.total_cap) { fallback(); return; }
+    if (misc[8] != 0u || total > (uint32_t)p.total_cap) { fallback(); return; }
     // flat candidate index -> entry: binary search in the segment table (only band members and keys beyond the LDS cache need it)
     auto entry_at = [&](const uint32_t i) -> uint2 {
         int lo = 0, hi = p.G;                                         // s_off[lo] <= i < s_off[hi]
@@ -666,10 +674,13 @@ int g_scan_variant = 0;                      // atlas_tune_set_scan_variant
 unsigned long long* g_merge_dbg = nullptr;   // atlas_tune_set_merge_stamps
 unsigned long long* g_scan_dbg = nullptr;    // atlas_tune_set_scan_stamps
 int scan_variant_index() { return (g_scan_variant >= 0 && g_scan_variant < kNumVariants) ? g_scan_variant : 0; }
+int g_scan_coop = 1;                         // atlas_tune_set_scan_coop: 0 = sample kernel + early threshold exchange (A/B)
+bool scan_coop_enabled() { return g_scan_coop != 0; }
 #else
 constexpr unsigned long long* g_merge_dbg = nullptr;
 constexpr unsigned long long* g_scan_dbg = nullptr;
 constexpr int scan_variant_index() { return 0; }
+constexpr bool scan_coop_enabled() { return true; }
 #endif
 
 struct ScanPlan {
@@ -679,7 +690,7 @@ struct ScanPlan {
     int S; int64_t sample_stride;     // sample pre-pass: S rows (0 = none), tile j starts at j*sample_stride
     int key_cap;
     int total_cap;
-    size_t off_qflag, off_gran, off_q16, off_sample, off_list_cnt, off_wg_stat, off_lists, total;
+    size_t off_qflag, off_epoch, off_gran, off_gmax, off_q16, off_sample, off_list_cnt, off_wg_stat, off_lists, total;
     size_t scan_lds, merge_lds;
 };
 
@@ -721,8 +732,12 @@ ScanPlan make_plan(int64_t N, int d, int k, int cus, const ScanVariant& v) {
         pl.sample_stride = (N / (S / 64)) & ~(int64_t)15;
     }
     size_t o = 0;
+    // state that lives across calls (zero before the first use of a workspace, ATLAS_WS_STATE_BYTES): the per-query fallback flags
+    // (cleared again by the merge block that reads them) and the call counter that tags the granules of coop scans
     pl.off_qflag = o;  o += 256;
+    pl.off_epoch = o;  o += 256;
     pl.off_gran = o;   o += 512;
+    pl.off_gmax = o;   o += (size_t)QCHUNK * 1024 * 8;
     pl.off_q16 = o;    o += (size_t)QCHUNK * D_FAST * 2;
     pl.off_sample = o; o += (size_t)QCHUNK * SAMPLE_MAX * 4;
     pl.off_list_cnt = o; o += align_up((size_t)pl.G * 64 * 4, 256);      // every scan workgroup overwrites its 64 words: no reset
@@ -772,6 +787,7 @@ extern "C" int atlas_dbg_f64_to_f16(const double* in, uint16_t* out, int n, void
 #if ATLAS_TUNING
 // tuning build only (not in include/atlas_hip.h): scan variant, device buffers for cycle stamps
 void atlas_tune_set_scan_variant(int v) { g_scan_variant = v; }
+void atlas_tune_set_scan_coop(int c) { g_scan_coop = c; }
 void atlas_tune_set_merge_stamps(unsigned long long* p) { g_merge_dbg = p; }
 void atlas_tune_set_scan_stamps(unsigned long long* p) { g_scan_dbg = p; }
 #endif
@@ -830,7 +846,11 @@ int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t
         const int nq = (B - q0 < QCHUNK) ? (B - q0) : QCHUNK;
         // initial thresholds: the scan derives them from the tile maxima of an evenly spread sample; small shards
         // start at -inf. Whoever runs first clears the per-call state (per-query fallback flags, status header).
-        if (pl.S > 0) {
+        // coop scan: the workgroups' first tiles are the sample (one launch less); needs one granule per (query, workgroup) lane slot
+        const bool coop = pl.S > 0 && pl.G >= QCHUNK && pl.G <= 256 && scan_coop_enabled();
+        if (coop) {
+            // nothing to launch: workgroup 0 of the scan clears the status header, the flags were cleared by the previous merge
+        } else if (pl.S > 0) {
             SampleParams sm{};
             sm.slab = (const uint16_t*)slab_f16; sm.N = N; sm.q = q; sm.q_dtype = q_dtype; sm.q0 = q0; sm.nq = nq;
             sm.top2 = (float*)(w + pl.off_sample); sm.S = pl.S; sm.stride_rows = pl.sample_stride;
@@ -844,11 +864,13 @@ int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t
         ScanParams sp{};
         sp.slab = (const uint16_t*)slab_f16; sp.N = N;
         // after a sample pass the queries of this pass exist as fp16 rows in the workspace (its blocks wrote them): half the bytes, no conversion
-        const bool have_q16 = pl.S > 0 && pl.S / 64 >= QCHUNK;
+        const bool have_q16 = !coop && pl.S > 0 && pl.S / 64 >= QCHUNK;
         sp.q = have_q16 ? (const void*)(w + pl.off_q16) : q; sp.q_dtype = have_q16 ? ATLAS_DT_F16 : q_dtype; sp.q0 = have_q16 ? 0 : q0;
         sp.pmax = pmax_hint;
-        sp.top2 = (pl.S > 0 && pl.G >= QCHUNK) ? (const float*)(w + pl.off_sample) : nullptr; sp.sample_blocks = pl.S / 64;
+        sp.top2 = (!coop && pl.S > 0 && pl.G >= QCHUNK) ? (const float*)(w + pl.off_sample) : nullptr; sp.sample_blocks = pl.S / 64;
         sp.theta_gran = (unsigned long long*)(w + pl.off_gran);
+        sp.coop = coop ? 1 : 0; sp.gran_max = (unsigned long long*)(w + pl.off_gmax); sp.epoch = (const uint32_t*)(w + pl.off_epoch);
+        sp.out_status = out_status;
         sp.lists = (uint2*)(w + pl.off_lists);
         sp.list_cnt = (uint32_t*)(w + pl.off_list_cnt); sp.wg_stat = (uint32_t*)(w + pl.off_wg_stat);
         sp.qflag = (uint32_t*)(w + pl.off_qflag);
@@ -863,7 +885,7 @@ int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t
         mp.slab = (const uint16_t*)slab_f16; mp.N = N; mp.d = d;
         mp.q = sp.q; mp.q_dtype = sp.q_dtype; mp.qbase = sp.q0; mp.pmax = pmax_hint;
         mp.lists = sp.lists; mp.list_cnt = sp.list_cnt; mp.wg_stat = sp.wg_stat; mp.G = pl.G; mp.cap = pl.cap;
-        mp.total_cap = pl.total_cap;
+        mp.total_cap = pl.total_cap; mp.epoch = (uint32_t*)(w + pl.off_epoch);
         mp.qflag = sp.qflag; mp.k = k; mp.q0 = q0; mp.key_cap = pl.key_cap;
         mp.dbg = g_merge_dbg;
         mp.out_score = (uint16_t*)out_score_f16; mp.out_idx = out_idx; mp.out_status = out_status;

@@ -180,7 +180,11 @@ struct ScanParams {
     const float* top2;        // [64][2 * sample_blocks] tile maxima of the sample pre-pass, or null: thresholds start at -inf
     int sample_blocks;
     unsigned long long* theta_gran;   // [64] {tag, threshold bits}: workgroup q publishes query q's initial threshold, everybody collects
-                                      // all 64 (cleared by the sample kernel that ran before)
+                                      // all 64 (two-kernel mode: cleared by the sample kernel that ran before; tag = 1)
+    int coop;                 // 1: no sample kernel -- the workgroups' own FIRST TILES are the sample (see first_tile_exchange below)
+    unsigned long long* gran_max;     // coop: [64][G] {tag, tile maximum bits}: workgroup g's best first-tile score for query q
+    const uint32_t* epoch;    // coop: per-workspace call counter (bumped by the merge kernel); granules of this call carry tag = epoch + 1
+    int32_t* out_status;      // coop: workgroup 0 clears the status header of the call's first 64-query pass
     uint2* lists;             // [64][G][cap]  {f32 bits of approx score, row}: the candidates of workgroup g for query q
     uint32_t* list_cnt;       // [64][G] entries of lists[q][g] at the end of the scan (plain stores: every workgroup writes its 64)
     uint32_t* wg_stat;        // [G][2]  per workgroup: largest row sum of squares seen (float bits) | ATLAS_F_* flags
@@ -288,7 +292,9 @@ scan_kernel(const ScanParams p) {
     // arrived in time simply starts at -inf (slower, never wrong).
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     gu64* gran = (gu64*)p.theta_gran;
-    const bool exchange = p.top2 != nullptr;
+    const bool exchange = p.top2 != nullptr && !p.coop;
+    const uint32_t tag = p.coop ? *p.epoch + 1u : 1u;              // (uniform: a scalar load)
+    if (p.coop && blockIdx.x == 0 && p.q0 == 0 && tid < ATLAS_STATUS_HEADER) p.out_status[tid] = 0;   // the merge accumulates into it
     const bool theta_wave = exchange && wave == NW - 1 && (int)blockIdx.x < p.nq;       // wave-uniform
     float tv[4];
     QRaw trow[2];                                       // the 768 elements of query blockIdx.x: 12 per lane = two 8-element pieces, 4 unused
@@ -438,6 +444,67 @@ scan_kernel(const ScanParams p) {
         wg_barrier_lds();
     };
 
+    // coop mode -- the sample is the scan's own first tiles (256 workgroups x 256 rows = 65 536 evenly spread rows, no extra bytes, no
+    // extra kernel). At the end of its first tile a workgroup publishes its best score per query (64 granules {tag, value}); workgroup q
+    // collects the G maxima of query q, takes their k-th largest (scores of distinct rows -> a certified threshold) and publishes it; every
+    // workgroup collects the 64 thresholds, then filters the tile it is still holding in registers. Two hops of ~3 us. Every wait is
+    // bounded: a maximum or threshold that has not arrived counts as -inf (slower, never wrong), so nothing depends on co-residency.
+    auto first_tile_exchange = [&](const float (&tm)[4]) {
+        float* s_tmax = (float*)s_buf;                     // [NW][64] scratch: the candidate buffer is still empty
+        gu64* gmax = (gu64*)p.gran_max;
+        const uint32_t G = gridDim.x;
+        if (lgrp == 0) {
+#pragma unroll
+            for (int qf = 0; qf < 4; ++qf) s_tmax[wave * 64 + qf * 16 + lrow] = tm[qf];
+        }
+        wg_barrier_lds();
+        if (tid < p.nq) {
+            float m = s_tmax[tid];
+            for (int w = 1; w < NW; ++w) m = fmaxf(m, s_tmax[w * 64 + tid]);
+            __hip_atomic_store(gmax + (size_t)tid * G + blockIdx.x, ((unsigned long long)tag << 32) | (unsigned long long)f32_bits(m),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (wave == NW - 1) {
+            if ((int)blockIdx.x < p.nq) {                  // this workgroup derives the threshold of query blockIdx.x
+                const int qq = blockIdx.x;
+                unsigned long long g[4] = {0ull, 0ull, 0ull, 0ull};
+                for (int spin = 0; spin < 4000; ++spin) {
+                    bool missing = false;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t i = (uint32_t)lane + 64u * u;
+                        if (i < G && (uint32_t)(g[u] >> 32) != tag) {
+                            g[u] = __hip_atomic_load(gmax + (size_t)qq * G + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            missing |= (uint32_t)(g[u] >> 32) != tag;
+                        }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(missing) == 0ull) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = ((uint32_t)(g[u] >> 32) == tag) ? bits_f32((uint32_t)g[u]) : neg_inf();
+                const float th = initial_theta(v, (int)G, p.k, s_eps[qq], lane);
+                if (lane == 0) __hip_atomic_store(gran + qq, ((unsigned long long)tag << 32) | (unsigned long long)f32_bits(th), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ATLAS_SCAN_STAMP_LANE0(6);   // [6] threshold of query blockIdx.x published
+            }
+            unsigned long long g = 0ull;
+            const bool want = lane < p.nq;
+            for (int spin = 0; spin < 4000; ++spin) {
+                if (want && (uint32_t)(g >> 32) != tag) g = __hip_atomic_load(gran + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_ballot_w64(want && (uint32_t)(g >> 32) != tag) == 0ull) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            s_theta[lane] = want ? ((uint32_t)(g >> 32) == tag ? bits_f32((uint32_t)g) : neg_inf()) : pos_inf();
+            ATLAS_SCAN_STAMP_LANE0(7);   // [7] all thresholds collected
+        }
+        wg_barrier_lds();
+    };
+    if (p.coop && ntiles == 0) {               // a workgroup without rows still owes the others its (empty) maxima
+        const float none[4] = {neg_inf(), neg_inf(), neg_inf(), neg_inf()};
+        first_tile_exchange(none);
+    }
+
     // One flat loop over ring revolutions of all tiles: the ring rotation is the same every
     // iteration (no register shuffling at tile boundaries), and the per-tile work (filter,
     // barrier) hangs off every RPT-th revolution.
@@ -487,7 +554,8 @@ scan_kernel(const ScanParams p) {
 
         // ------------------------- end of a tile: filter --------------------------------
         cstep = 0;
-        if (row0 < nrows) {        // wave-uniform
+        const bool have_rows = row0 < nrows;        // wave-uniform
+        if (have_rows) {
             // full row norms: the 4 lanes {l, l+16, l+32, l+48} hold the 4 k-groups of row l&15
 #pragma unroll
             for (int pf = 0; pf < PF; ++pf) {
@@ -507,6 +575,24 @@ scan_kernel(const ScanParams p) {
                             for (int qf = 0; qf < 4; ++qf) acc[pf][qf][r] = neg_inf();
                         }
             }
+        }
+        if (p.coop && row0 < TILE) {           // workgroup-uniform: the end of every wave's FIRST tile
+            float tm[4];
+#pragma unroll
+            for (int qf = 0; qf < 4; ++qf) {
+                float m = neg_inf();
+                if (have_rows) {
+#pragma unroll
+                    for (int pf = 0; pf < PF; ++pf)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[pf][qf][r]);
+                }
+                m = fmaxf(m, __shfl_xor(m, 16));
+                tm[qf] = fmaxf(m, __shfl_xor(m, 32));
+            }
+            first_tile_exchange(tm);
+        }
+        if (have_rows) {
             // threshold filter: lane l owns query 16*qf + (l&15) in acc[.][qf]
             float th[4];
 #pragma unroll

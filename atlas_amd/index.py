@@ -221,7 +221,8 @@ class HipDistributedIndex(object):
         attr = "_ws_exact" if exact else "_ws"
         ws = getattr(self, attr)
         if ws is None or ws.numel() < nbytes or ws.device != self._slab.device:
-            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self._slab.device)
+            # zero-filled once: the head of a scan workspace holds state that lives across calls (include/atlas_hip.h)
+            ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=self._slab.device)
             setattr(self, attr, ws)
         return ws
 
