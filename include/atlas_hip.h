@@ -39,6 +39,8 @@ extern "C" {
 
 #define ATLAS_ABI_VERSION 5
 
+#define ATLAS_WS_STATE_BYTES (1u << 20)   /* head of a scan workspace that must be zero before the workspace's first use */
+
 /* negative return codes */
 #define ATLAS_E_BADARG     (-1)  /* null pointer, B<=0, k<=0, d unsupported ...        */
 #define ATLAS_E_WORKSPACE  (-2)  /* ws_bytes smaller than *_workspace_bytes()          */
@@ -87,11 +89,20 @@ const char* atlas_build_info(void);          /* "gfx950 <compile date> ..." */
  *   out_score  [B x k] fp16, canonical scores, descending
  *   out_idx    [B x k] int64 shard-local passage rows (same meaning as torch.topk indices)
  *   out_status int32[ATLAS_STATUS_HEADER + B]
- *   ws         workspace of >= atlas_scan_topk_workspace_bytes(N,B,d,k) bytes, 256-B aligned
+ *   ws         workspace of >= atlas_scan_topk_workspace_bytes(N,B,d,k) bytes, 256-B aligned. ZERO-FILL IT ONCE before its
+ *              first use (hipMemset); from then on it belongs to the library between calls: its first
+ *              ATLAS_WS_STATE_BYTES hold per-query fallback flags (cleared again by the kernel that reads them), a call
+ *              counter and the 8-byte {tag = counter + 1, value} granules of the in-kernel threshold exchange (a stale or
+ *              garbage granule must not carry the current tag). One workspace serves one stream at a time.
  *
  * Fast path requires d == 768 (EMBEDDINGS_DIM, src/retrievers.py:13) and k <= 256;
  * otherwise returns ATLAS_E_UNSUPPORTED (callers then use atlas_exact_topk).
  * Any B >= 1 is accepted (processed in chunks of 64 queries, one slab pass per chunk).
+ *
+ * One 64-query pass is two launches: the scan (which converts the queries itself, takes its initial pruning thresholds
+ * from its own first tiles -- the workgroups exchange 8-byte granules inside the kernel; every wait is bounded, a value
+ * that does not arrive in time only loosens a threshold -- and leaves per-workgroup candidate lists) and the merge
+ * (exact rescoring of the candidate band, canonical order). Shards below 65 536 rows start without thresholds.
  */
 size_t atlas_scan_topk_workspace_bytes(int64_t N, int B, int d, int k);
 int atlas_scan_topk(const void* q, int q_dtype, const void* slab_f16, int64_t N, int B, int d,

@@ -7,7 +7,7 @@ embeddings for the fp32 model and for its `.half()` inference copy, both compute
 Tolerances: the restatement performs the same torch ops in the same order, so on the machine that generated the fixtures
 it is bit-identical (asserted when torch reports the generating version and the bits agree; otherwise bounded): fp32
 1e-5 * max|e|, fp16 2e-3 * max|e| (other CPUs / BLAS kernels may sum GEMMs in another order). HIP encoder vs reference:
-the tolerances of tests/test_gpu_encoder.py (fp32 2e-5, fp16 4e-3 of max|e|)."""
+the tolerances of tests/test_gpu_encoder.py (fp32 2e-5, fp16 2e-3 of max|e|)."""
 import os
 
 import numpy as np
@@ -70,7 +70,7 @@ def test_hip_encoder_matches_reference_outputs(case, gpu_index_cls):
     c = synth_encoder.config_dict(case)
     want32, want16 = torch.from_numpy(z["emb_fp32"]), torch.from_numpy(z["emb_fp16"]).float()
     scale = want32.abs().max()
-    for dtype, want, tol in ((torch.float32, want32, 2e-5), (torch.float16, want16, 4e-3)):
+    for dtype, want, tol in ((torch.float32, want32, 2e-5), (torch.float16, want16, 2e-3)):
         m = retrievers.Contriever(retrievers.BertConfigLite(vocab_size=c["vocab_size"], num_hidden_layers=c["num_hidden_layers"]))
         m.load_state_dict(sd, strict=True)
         m = m.to(dtype).eval().cuda().requires_grad_(False)

@@ -3,7 +3,7 @@ restatement of the reference module (oracle/contriever_ref.py) run with the same
 
 Floating point: both sides round to fp16 at the same places; they differ only in fp32 summation order inside GEMMs /
 reductions, and every one of the ~100 op boundaries can turn such a difference into one fp16 ulp. Tolerance (written
-here, per the north_star's 1e-3-class bound): |emb_hip - emb_ref| <= 4e-3 * max|emb_ref| elementwise and cosine >=
+here, per the north_star's 1e-3-class bound): |emb_hip - emb_ref| <= 2e-3 * max|emb_ref| elementwise and cosine >=
 0.99999; the measured maxima are printed."""
 import numpy as np
 import pytest
@@ -48,7 +48,7 @@ def test_encoder_matches_reference_restatement(n, L, layers, gpu_index_cls):
         cos = torch.nn.functional.cosine_similarity(got, want, dim=1).min()
         print(f"n={n} L={L} layers={layers} vs {name}: max|d|/max|e| = {err:.2e}, min cos = {cos:.7f}; "
               f"torch cpu vs torch gpu: {((want_cpu - want_gpu).abs().max() / scale):.2e}")
-        assert err <= 4e-3 and cos >= 0.99999, (name, float(err), float(cos))
+        assert err <= 2e-3 and cos >= 0.99999, (name, float(err), float(cos))
 
 
 def test_encoder_writes_into_the_slab(gpu_index_cls):
@@ -78,18 +78,18 @@ def test_deepcopy_half_eval_like_atlas(gpu_index_cls):
         r16 = copy.deepcopy(r).half().eval()
         e = r16(input_ids=ids.cuda(), attention_mask=mask.cuda(), is_passages=True)   # atlas.py:78 passes **batch_enc
     want = ref.cuda()(ids.cuda(), mask.cuda())
-    assert (e.float() - want.float()).abs().max() / want.float().abs().max() <= 4e-3
+    assert (e.float() - want.float()).abs().max() / want.float().abs().max() <= 2e-3
     with pytest.raises(Exception, match="autograd"):
         r(ids.cuda(), mask.cuda())                              # training forward (needs grad): not provided, and says so
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.2e-2)])
 @pytest.mark.parametrize("n,L,layers", [(6, 40, 12), (3, 200, 2), (64, 512, 2)])
 def test_query_embedding_in_model_precision(dtype, tol, n, L, layers, gpu_index_cls):
     """atlas.py:104: the query side runs the retriever in --precision (fp32 default, bf16 for the large models).
     Oracle = the torch restatement in that dtype on the same device (fp32: also against torch CPU).
     Tolerance: fp32 differs by accumulation order only (2e-5 of max|e|); bf16 has 8 significant bits and every one
-    of the ~100 rounding points can flip, measured ~1e-2 -> 3e-2, cosine >= 0.9995."""
+    of the ~100 rounding points can flip, measured 4.5e-3 .. 8e-3 -> 1.2e-2, cosine >= 0.9995."""
     from atlas_amd import retrievers
     from oracle.contriever_ref import BertConfigLite, ContrieverRef
 
@@ -128,13 +128,13 @@ def test_masks_with_holes_and_query_like_padding(gpu_index_cls):
     mask[:, 0] = 1
     want = ref.cuda()(ids.cuda(), mask.cuda()).float().cpu()
     got = mine(ids.cuda(), mask.cuda()).float().cpu()
-    assert (got - want).abs().max() / want.abs().max() <= 4e-3
+    assert (got - want).abs().max() / want.abs().max() <= 2e-3
     ids, mask = _batch(4, 512, 12)
     mask[:, 20:] = 0
     mask[2, 5:] = 0
     want = ref.cuda()(ids.cuda(), mask.cuda()).float().cpu()
     got = mine(ids.cuda(), mask.cuda()).float().cpu()
-    assert (got - want).abs().max() / want.abs().max() <= 4e-3
+    assert (got - want).abs().max() / want.abs().max() <= 2e-3
 
 
 def test_padding_invariance_is_bit_exact(gpu_index_cls):
@@ -160,7 +160,7 @@ def test_fully_masked_passage_gives_nan_like_torch(gpu_index_cls):
     got = mine(ids.cuda(), mask.cuda()).float().cpu()
     want = ref.cuda()(ids.cuda(), mask.cuda()).float().cpu()
     assert torch.isnan(got[1]).all() and torch.isnan(want[1]).all()
-    assert (got[[0, 2]] - want[[0, 2]]).abs().max() / want[[0, 2]].abs().max() <= 4e-3
+    assert (got[[0, 2]] - want[[0, 2]]).abs().max() / want[[0, 2]].abs().max() <= 2e-3
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
@@ -194,7 +194,7 @@ def test_bulk_gemm_kernels_agree_bit_for_bit(dtype, gpu_index_cls, monkeypatch):
         mine._library = None
     want = ref.cuda()(ids, mask).float().cpu()
     err = (base.float().cpu() - want).abs().max() / want.abs().max()
-    tol = {torch.float16: 4e-3, torch.bfloat16: 3e-2, torch.float32: 2e-5}[dtype]
+    tol = {torch.float16: 2e-3, torch.bfloat16: 1.2e-2, torch.float32: 2e-5}[dtype]
     print(f"{dtype} bulk: max|d|/max|e| = {err:.2e}")
     assert err <= tol
 
@@ -211,7 +211,7 @@ def test_token_type_ids_and_rerank_call_shape(gpu_index_cls):
     enc = {"input_ids": ids.cuda(), "token_type_ids": tt.cuda(), "attention_mask": mask.cuda()}
     got = r16(**enc, is_passages=True).float().cpu()
     want = ref.cuda()(ids.cuda(), mask.cuda(), token_type_ids=tt.cuda()).float().cpu()
-    assert (got - want).abs().max() / want.abs().max() <= 4e-3
+    assert (got - want).abs().max() / want.abs().max() <= 2e-3
     without = r16(input_ids=ids.cuda(), attention_mask=mask.cuda(), is_passages=True).float().cpu()
     assert (got - without).abs().max() > 1e-2 * want.abs().max()        # the token types did change the result
     # the rerank arithmetic that follows (atlas.py:170-171) on these embeddings
