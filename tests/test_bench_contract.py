@@ -9,12 +9,12 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = ["bench_default_32m.json", "bench_4m.json", "bench_1m.json"]
+LINES = ["r01/bench_default_32m.json", "r01/bench_4m.json", "r01/bench_1m.json", "r02/bench_default_32m_sessionF.json"]
 
 
 @pytest.mark.parametrize("name", LINES)
 def test_committed_bench_line_has_the_contract_fields(name):
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r01", name)).read().strip().splitlines()[-1])
+    d = json.loads(open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -37,8 +37,9 @@ def test_committed_bench_line_has_the_contract_fields(name):
     assert d["ms_per_step"] >= r["kernel_ms_min"]
 
 
-def test_default_line_carries_cpu_baseline_and_refresh():
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r01", LINES[0])).read().strip().splitlines()[-1])
+@pytest.mark.parametrize("name", [LINES[0], LINES[3]])
+def test_default_line_carries_cpu_baseline_and_refresh(name):
+    d = json.loads(open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1])
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -48,6 +49,24 @@ def test_default_line_carries_cpu_baseline_and_refresh():
     flops = 169.9e6 * f["passage_len"] + 36864.0 * f["passage_len"] ** 2
     assert abs(f["roofline"]["flops_per_passage"] - flops) < 1.0
     assert abs(f["roofline"]["achieved"] - f["value"] * flops / 1e12) <= 1e-6 * f["roofline"]["achieved"]
+
+
+def test_round2_line_carries_parity_sweep_and_streamed_refresh():
+    """what round 2 added to the line: parity at the benchmark size, the 1M / 4M shard sweep timed like the headline, the refresh
+    streamed from the token store"""
+    d = json.loads(open(os.path.join(ROOT, "profiles", LINES[3])).read().strip().splitlines()[-1])
+    pc = d["detail"]["parity_checked"]
+    assert pc["rows"] == d["config"]["passages_per_gpu"] and pc["queries_exact"] >= 8 and pc["queries_oracle"] >= 1
+    for n, v in d["shard_sweep"].items():
+        nbytes = int(n) * 768 * 2
+        assert abs(v["step_frac"] - nbytes / (v["ms_per_step"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+        assert abs(v["kernel_frac"] - nbytes / (v["kernel_ms_mean"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+        assert v["ms_per_step"] >= v["kernel_ms_mean"] * 0.98 and v["steps"] >= 50
+    assert set(d["shard_sweep"]) == {"1000000", "4000000"}
+    st = d["refresh"]["streamed"]
+    assert st["unit"] == "passages/s" and st["seconds"] >= 2.0 and abs(st["value"] - st["passages_per_refresh"] * st["refreshes"] / st["seconds"]) <= 1e-6 * st["value"]
+    assert st["vs_device_resident_ragged"] >= 0.95                       # VERDICT r01 #6: within 5 % of the device-resident rate
+    assert d["cpu_baseline"]["kind"].startswith("port, extrapolated from")
 
 
 def test_bench_refuses_to_run_without_a_gpu():
