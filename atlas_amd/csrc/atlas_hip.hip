@@ -228,13 +228,16 @@ merge_rescore_kernel(const MergeParams p) {
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= i) lo = mid; else hi = mid; }
         return p.lists[((size_t)q * p.G + lo) * p.cap + (i - s_off[lo])];
     };
-    // the first key_cap keys are cached in LDS; a longer candidate list (poor initial threshold, adversarial data) is re-read
-    // from the lists (L2) in the two later passes instead of being handed to the exact path
-    const uint32_t ncache = total < (uint32_t)p.key_cap ? total : (uint32_t)p.key_cap;
+    // the first key_cap / 2 candidates are cached in LDS, key and row; a longer candidate list (poor initial threshold, adversarial
+    // data, 32M-row shards) is re-read from the lists (L2) in the two later passes instead of being handed to the exact path
+    const uint32_t kc2 = (uint32_t)p.key_cap / 2u;
+    uint32_t* rows_l = keys + kc2;
+    const uint32_t ncache = total < kc2 ? total : kc2;
     auto key_at = [&](const uint32_t i) -> uint32_t { return i < ncache ? keys[i] : f32_order_key(bits_f32(entry_at(i).x)); };
     if (p.dbg && q == 0 && tid == 0) p.dbg[1] = __builtin_readcyclecounter();
-    // (1) keys -> LDS with min / max: a wave takes 16 segments at a time and requests all of them before it uses the first
-    // (the segments were written by workgroups of every XCD: each is its own trip to memory)
+    // (1) keys (+ rows) -> LDS with min / max: a wave takes 16 segments at a time and requests all of them before it uses the first
+    // (the segments were written by workgroups of every XCD: each is its own trip to memory). Requesting the segment heads
+    // speculatively together with the lengths (one trip instead of two) was measured: slower (128 KiB over-read per block)
     uint32_t kmax = 0, kmin = 0xffffffffu;
     constexpr int NWV = NT / 64, SEG = 16;
     for (int g0 = wave * SEG; g0 < p.G; g0 += NWV * SEG) {
@@ -243,20 +246,20 @@ merge_rescore_kernel(const MergeParams p) {
         for (int u = 0; u < SEG; ++u)
             if (g0 + u < p.G) { const uint32_t n = s_off[g0 + u + 1] - s_off[g0 + u]; longest = n > longest ? n : longest; }
         for (uint32_t r0 = 0; r0 < longest; r0 += 64) {
-            uint32_t sc[SEG];
+            uint2 sc[SEG];
 #pragma unroll
             for (int u = 0; u < SEG; ++u) {
                 const int g = g0 + u < p.G ? g0 + u : p.G - 1;          // clamped: loads stay unconditional
                 const uint32_t n = s_off[g + 1] - s_off[g], j = r0 + lane;
-                sc[u] = p.lists[((size_t)q * p.G + g) * p.cap + (j < n ? j : 0)].x;
+                sc[u] = p.lists[((size_t)q * p.G + g) * p.cap + (j < n ? j : 0)];
             }
 #pragma unroll
             for (int u = 0; u < SEG; ++u) {
                 if (g0 + u >= p.G) continue;
                 const uint32_t base = s_off[g0 + u], n = s_off[g0 + u + 1] - base, j = r0 + lane;
                 if (j < n) {
-                    const uint32_t key = f32_order_key(bits_f32(sc[u]));
-                    if (base + j < ncache) keys[base + j] = key;
+                    const uint32_t key = f32_order_key(bits_f32(sc[u].x));
+                    if (base + j < ncache) { keys[base + j] = key; rows_l[base + j] = sc[u].y; }
                     kmax = key > kmax ? key : kmax;
                     kmin = key < kmin ? key : kmin;
                 }
@@ -318,7 +321,7 @@ merge_rescore_kernel(const MergeParams p) {
     const uint32_t theta_key = f32_order_key(theta);
     for (uint32_t i = tid; i < total; i += NT) {
         if (key_at(i) > theta_key) {
-            const uint2 e = entry_at(i);
+            const uint2 e = i < ncache ? make_uint2(f32_bits(f32_from_order_key(keys[i])), rows_l[i]) : entry_at(i);
             const uint32_t sidx = atomicAdd(&misc[5], 1u);
             if (sidx < MERGE_SMAX) { s_row[sidx] = e.y; s_app[sidx] = bits_f32(e.x); }
         }
