@@ -1,4 +1,4 @@
-"""Scan-kernel variants in one process: the slab is built once, every variant (ATLAS_SCAN_VARIANT is read per call) runs the
+"""Scan-kernel variants in one process: the slab is built once, every variant (atlas_tune_set_scan_variant, tuning build) runs the
 full C-ABI search `reps` times; hipEvents around the scan kernel (atlas_scan_topk_ex), results must be bit-identical.
 
     python tools/scan_policy.py 4000000 32000000 -- 0 5 6
