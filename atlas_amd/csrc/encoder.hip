@@ -928,6 +928,131 @@ gemm_ms_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     gemm_epilogue<T, EPI, FA, FB>(acc, m0, n0, wi, wj, lr, lg, M, N, bias, R, C, VT, cu, tokinfo, Lp);
 }
 
+// ------------------------------------------------------------------------------------------
+// gemm_wr_kernel: the bulk GEMM with the WEIGHT operand loaded straight into registers and only the activations staged in LDS.
+// What holds the 256 x 256 kernels above at ~1 190 TFLOP/s in the k-loop is feeding LDS: 64 KiB of LDS-DMA per k-tile, whose pieces
+// take ~3 000 cycles to land with one k-tile in flight (profiles/r01/gemm_phases.txt), against 2 100 cycles of MFMA issue. Plain
+// 16-byte loads to registers run at 64-87 B/clk/CU, the LDS-DMA path at 43-48. So: 8 waves side by side along the COLUMNS -- wave w owns
+// columns [32 w, 32 w + 32) of the 256-column tile for all 256 tokens (2 x 16 fragments, the same 128 accumulator registers). A weight
+// row is then needed by exactly one wave: its MFMA A fragments (row l & 15, 16 bytes at k-group l >> 4) are 16-byte loads from the
+// row-major weight matrix, no LDS, no redundancy, prefetched two k-tiles ahead in registers. Only the activation tile (32 KiB per
+// k-tile, half the LDS-DMA bytes and half the pieces to issue) goes through LDS, in FOUR stages (three k-tiles in flight behind
+// counted vmcnt waits), one barrier per k-tile. Same k order per element as every other configuration: identical bits.
+// ------------------------------------------------------------------------------------------
+template <class T, int EPI>
+__global__ void __launch_bounds__(512)
+gemm_wr_kernel(const typename T::elem* __restrict__ A, const typename T::elem* __restrict__ W, const typename T::elem* __restrict__ bias,
+               const typename T::elem* __restrict__ R, typename T::elem* __restrict__ C, typename T::elem* __restrict__ VT,
+               const int* __restrict__ cu, int n, const int2* __restrict__ tokinfo, int N, int K, int Lp, int diag) {
+    typedef typename T::elem E;
+    static_assert(sizeof(E) == 2, "16-bit dtypes only");
+    constexpr int BCOL = 256, BTOK = 256, FA = 2, FB = 16, ST = 4;
+    constexpr int EPC = 8;
+    constexpr uint32_t STG = 256 * 128;                              // bytes per activation stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // ST activation stages
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t M = cu[n];
+    const int ncol = N / BCOL;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int ctile = jj % ncol;
+    const int64_t ttile = (int64_t)(jj / ncol) * 8 + xcd;
+    if (ttile * BTOK >= M) return;
+    const int n0 = ctile * BCOL;
+    const int64_t m0 = ttile * BTOK;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int nk = K / (8 * EPC);
+
+    // activations: this wave's 4 DMA pieces per k-tile (8 rows x 128 B each, source-side XOR swizzle as in gemm_bt_kernel)
+    const int ch = (lane & 7) ^ (lane >> 3);
+    const E* ga[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int64_t ar = m0 + wave * 32 + i * 8 + (lane >> 3);
+        if (ar >= M) ar = M - 1;                                   // clamped: tail rows are never stored
+        ga[i] = A + (size_t)ar * K + ch * EPC;
+    }
+    auto stage = [&](const int kt) {
+        const uint32_t so = (uint32_t)(kt % ST) * STG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + kt * (8 * EPC)),
+                                             (__attribute__((address_space(3))) void*)(smem_raw + so + (wave * 32 + i * 8) * 128), 16, 0, 0);
+    };
+    // weights: lane's 16 bytes of fragment a (rows n0 + 32 wave + 16 a + lr), k-step ks of k-tile kt
+    const E* gw = W + (size_t)(n0 + wave * 32 + lr) * K + lg * EPC;
+    auto load_w = [&](u4v (&w)[2][2], const int kt) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) w[ks][a] = *(const u4v*)(gw + (size_t)a * 16 * K + kt * (8 * EPC) + ks * 4 * EPC);
+    };
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+    const uint32_t aa0 = lds0 + lr * 128 + ((0 + lg) ^ (lr & 7)) * 16;          // fragment b adds b * 2048 (rows 16 apart keep row & 7)
+    const uint32_t aa1 = lds0 + lr * 128 + ((4 + lg) ^ (lr & 7)) * 16;
+
+    f4 acc[FA][FB];
+#pragma unroll
+    for (int a = 0; a < FA; ++a)
+#pragma unroll
+        for (int b = 0; b < FB; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    // prologue: weights of k-tiles 0 and 1 and activation stages 0, 1, 2 in flight (issue order = the order the waits below count on)
+    u4v w0[2][2], w1[2][2], w2[2][2];
+    load_w(w0, 0);
+    stage(0);
+    if (nk > 1) load_w(w1, 1); else load_w(w1, 0);
+    if (nk > 1) stage(1);
+    if (nk > 2) stage(2);
+    // steady state at the top of iteration kt, oldest -> newest: W(kt) A(kt) W(kt+1) A(kt+1) A(kt+2); the iteration issues W(kt+2), A(kt+3)
+    auto body = [&](const int kt, u4v (&wc)[2][2], u4v (&wn2)[2][2]) {
+        if (kt + 2 < nk) load_w(wn2, kt + 2);
+        // W(kt) and every wave's A(kt) have landed: at most the 4 + 4 + 4 (+ 4) younger operations of this wave may still be in flight
+        if (kt + 2 < nk) wait_vmcnt<16>(); else if (kt + 1 < nk) wait_vmcnt<8>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                  // ... everybody's pieces of A(kt); and everybody is past its reads of stage (kt - 1) % ST
+        if (kt + 3 < nk) stage(kt + 3);                // into the stage k-tile kt - 1 occupied
+        const uint32_t so = (uint32_t)(kt % ST) * STG;
+        // 4 token fragments (8 ds_read_b128) per group; the reads of group g + 1 are in flight under the 16 MFMAs of group g (two
+        // register sets; the waits are counted by hand: the compiler does not see inline-asm LDS reads)
+        u4v fx[8], fy[8];
+        auto issue = [&](u4v (&f)[8], const int b) {
+            asm volatile(
+                "ds_read_b128 %0, %8\n ds_read_b128 %1, %8 offset:2048\n ds_read_b128 %2, %8 offset:4096\n ds_read_b128 %3, %8 offset:6144\n"
+                "ds_read_b128 %4, %9\n ds_read_b128 %5, %9 offset:2048\n ds_read_b128 %6, %9 offset:4096\n ds_read_b128 %7, %9 offset:6144"
+                : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]), "=&v"(f[6]), "=&v"(f[7])
+                : "v"(aa0 + so + b * 2048), "v"(aa1 + so + b * 2048)
+                : "memory");
+        };
+        auto landed = [&](u4v (&f)[8], const bool younger_in_flight) {       // the 8 reads into f have completed (8 younger ones may still fly)
+            if (younger_in_flight)
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) :: "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) :: "memory");
+        };
+        auto multiply = [&](const u4v (&f)[8], const int b) {
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+                for (int a = 0; a < FA; ++a) {
+                    acc[a][b + bb] = T::mma(wc[0][a], f[bb], acc[a][b + bb]);
+                    acc[a][b + bb] = T::mma(wc[1][a], f[4 + bb], acc[a][b + bb]);
+                }
+        };
+        issue(fx, 0);
+        issue(fy, 4);  landed(fx, true);  multiply(fx, 0);
+        issue(fx, 8);  landed(fy, true);  multiply(fy, 4);
+        issue(fy, 12); landed(fx, true);  multiply(fx, 8);
+        landed(fy, false); multiply(fy, 12);
+    };
+    for (int kt = 0; kt < nk; kt += 3) {               // the three weight register sets rotate by name: no copies
+        body(kt, w0, w2);
+        if (kt + 1 < nk) body(kt + 1, w1, w0);
+        if (kt + 2 < nk) body(kt + 2, w2, w1);
+    }
+    if (diag & 1) { if (acc[0][0][0] == 12345.678f) C[0] = 0; return; }
+    gemm_epilogue<T, EPI, FA, FB>(acc, m0, n0, wave, 0, lr, lg, M, N, bias, R, C, VT, cu, tokinfo, Lp);
+}
+
 // GEMM configurations. The encoder picks by worst-case token slots n * L: > 16384 -> 4, > 4096 -> 0, else 3;
 // the tuning build's atlas_tune_set_gemm_cfg(n) forces one (tuning and the bit-equality test: every configuration gives the same bits).
 //   4  gemm_pp_kernel  256 x 256, ping-pong schedule, LDS epilogue          (index refresh; FFN-1 of the 16-bit dtypes goes to 6)
@@ -971,6 +1096,14 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
             (void)hipFuncSetAttribute((const void*)gemm_co_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             const unsigned mtiles = (unsigned)((Mmax + 127) / 128);
             hipLaunchKernelGGL((gemm_co_kernel<T, EPI>), dim3((mtiles + 7) / 8 * 8 * (N / 256)), dim3(256), 64 * 1024 + 512, stream, A, W, bias, R, C,
+                               VT, cu, n, tokinfo, N, K, Lp, g_gemm_diag);
+        } else go(gemm_bt_kernel<T, EPI, 256, 256, 2, 4>, 256, 256, 512);
+    }
+    else if (cfg == 8) {                               // weights in registers, activations through four LDS stages
+        if constexpr (sizeof(typename T::elem) == 2) {
+            (void)hipFuncSetAttribute((const void*)gemm_wr_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            const unsigned mtiles = (unsigned)((Mmax + 255) / 256);
+            hipLaunchKernelGGL((gemm_wr_kernel<T, EPI>), dim3((mtiles + 7) / 8 * 8 * (N / 256)), dim3(512), 4 * 256 * 128, stream, A, W, bias, R, C,
                                VT, cu, n, tokinfo, N, K, Lp, g_gemm_diag);
         } else go(gemm_bt_kernel<T, EPI, 256, 256, 2, 4>, 256, 256, 512);
     }

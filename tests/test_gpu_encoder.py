@@ -186,7 +186,7 @@ def test_bulk_gemm_kernels_agree_bit_for_bit(dtype, gpu_index_cls, monkeypatch):
     T = _lib.lib(tuning=True)                                 # the tuning build of the same sources can force a configuration
     mine._library = T
     try:
-        for cfg in (4, 6, 7, 2, 0, 3):
+        for cfg in (4, 6, 7, 8, 2, 0, 3):
             T.atlas_tune_set_gemm_cfg(cfg)
             assert torch.equal(mine(ids, mask), base), f"cfg {cfg} differs from the product library's default configuration"
     finally:

@@ -2,7 +2,7 @@
 import csv, sys, statistics as st
 path, modes = sys.argv[1], sys.argv[2:] or ["0", "1", "2"]
 rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
-g = [(r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows if "gemm_pp" in r["Kernel_Name"] or "gemm_co" in r["Kernel_Name"]]
+g = [(r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows if any(k in r["Kernel_Name"] for k in ("gemm_pp", "gemm_co", "gemm_wr"))]
 per_mode = len(g) // len(modes)
 other = {}
 for r in rows:
