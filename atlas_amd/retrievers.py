@@ -13,9 +13,13 @@ padding costs nothing) in the dtype of its parameters:
     fp16   the inference copy `copy.deepcopy(retriever).half().eval()` of `Atlas.build_index` /
            `retrieve_with_rerank` (atlas.py:54-59, 78, 168): every passage embedding of an index refresh
     fp32 / bf16 / fp16   query embedding in model precision (`--precision`, atlas.py:104)
-There is no eager-PyTorch fallback.
+Inference has no eager-PyTorch fallback: without autograd and outside train-mode dropout a forward either runs on the HIP encoder or
+raises AtlasHipError (CPU tensors, missing library).
 
-Not provided (raises AtlasHipError): forward with autograd (retriever training, atlas.py:457-465); CPU tensors.
+The training step of the reference (`Atlas.forward`, atlas.py:452-465: the retriever in train mode, under autograd, with the
+dropout `set_dropout` put on every nn.Dropout) is not part of the accelerated path; it is served by torch operators on the same
+parameters (atlas_amd/retriever_train.py) so that the module stays a drop-in under an unchanged training loop. `Contriever.last_path`
+("hip" / "autograd") records which way the last forward went.
 """
 import contextlib
 import copy
@@ -35,9 +39,12 @@ class BertConfigLite:
 
     def __init__(self, vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
                  intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12,
-                 initializer_range=0.02, pad_token_id=0, pooling="average"):
+                 initializer_range=0.02, pad_token_id=0, pooling=None, hidden_dropout_prob=0.1,
+                 attention_probs_dropout_prob=0.1):
         self.__dict__.update(locals())
         del self.__dict__["self"]
+        if pooling is None:              # like an HF BertConfig: no `pooling` attribute unless one was given, so that
+            del self.__dict__["pooling"]  # Contriever(config, pooling=...) decides (retrievers.py:19-20)
 
 
 class _LayerNormParams(nn.Module):        # parameters of modeling_bert.py:94-103 (the arithmetic lives in encoder.hip)
@@ -58,6 +65,7 @@ class _Embeddings(nn.Module):
         # persistent buffer of the reference's BertEmbeddings (modeling_bert.py:205): every Atlas checkpoint carries
         # `...embeddings.position_ids`, and src/model_io.py:122 loads with strict=True
         self.register_buffer("position_ids", torch.arange(c.max_position_embeddings).expand((1, -1)))
+        self.dropout = nn.Dropout(c.hidden_dropout_prob)       # modeling_bert.py:202 (train mode only: retriever_train.py)
 
 
 class _SelfAttention(nn.Module):
@@ -66,6 +74,7 @@ class _SelfAttention(nn.Module):
         self.query = nn.Linear(c.hidden_size, c.hidden_size)
         self.key = nn.Linear(c.hidden_size, c.hidden_size)
         self.value = nn.Linear(c.hidden_size, c.hidden_size)
+        self.dropout = nn.Dropout(c.attention_probs_dropout_prob)   # modeling_bert.py:267
 
 
 class _DenseLN(nn.Module):
@@ -73,6 +82,7 @@ class _DenseLN(nn.Module):
         super().__init__()
         self.dense = nn.Linear(in_features, c.hidden_size)
         self.LayerNorm = _LayerNormParams(c.hidden_size, c.layer_norm_eps)
+        self.dropout = nn.Dropout(c.hidden_dropout_prob)       # modeling_bert.py:380, 459
 
 
 class _Attention(nn.Module):
@@ -100,6 +110,7 @@ class _Encoder(nn.Module):
     def __init__(self, c):
         super().__init__()
         self.layer = nn.ModuleList([_Layer(c) for _ in range(c.num_hidden_layers)])
+        self.gradient_checkpointing = False                    # modeling_bert.py:559
 
 
 class Contriever(nn.Module):
@@ -113,6 +124,7 @@ class Contriever(nn.Module):
         self._packed = None          # (key, BertWeights struct, tensors kept alive)
         self._ws = None
         self._library = None         # tests / tools only: a handle of the tuning build (_lib.lib(tuning=True)) instead of the product library
+        self.last_path = None        # "hip" | "autograd": which implementation served the last forward
 
     @classmethod
     def from_pretrained(cls, path, pooling="average", **kwargs):
@@ -125,7 +137,8 @@ class Contriever(nn.Module):
         with open(os.path.join(path, "config.json")) as f:
             cj = json.load(f)
         known = ("vocab_size", "hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size", "max_position_embeddings",
-                 "type_vocab_size", "layer_norm_eps", "initializer_range", "pad_token_id")
+                 "type_vocab_size", "layer_norm_eps", "initializer_range", "pad_token_id", "hidden_dropout_prob",
+                 "attention_probs_dropout_prob")
         config = BertConfigLite(**{k: cj[k] for k in known if k in cj}, pooling=cj.get("pooling", pooling))
         if cj.get("hidden_act", "gelu") != "gelu":
             raise _lib.AtlasHipError(f"hidden_act={cj['hidden_act']!r}: only the exact-erf 'gelu' of BERT / Contriever is implemented")
@@ -195,14 +208,18 @@ class Contriever(nn.Module):
             raise _lib.AtlasHipError("atlas_amd.Contriever runs on an MI355X only; there is no CPU / eager fallback")
         if p.dtype not in (torch.float16, torch.bfloat16, torch.float32) or any(q.dtype != p.dtype for q in params):
             raise _lib.AtlasHipError(f"unsupported / mixed parameter dtype {p.dtype}")
-        if torch.is_grad_enabled() and any(q.requires_grad for q in params):
-            raise _lib.AtlasHipError(
-                "atlas_amd.Contriever is an inference encoder (index refresh, query embedding under torch.no_grad()); "
-                "a forward that needs autograd (retriever training) is not implemented and there is no eager fallback"
-            )
+        if self._needs_training_forward():
+            raise _lib.AtlasHipError("embed_into is the inference encoder: call it under torch.no_grad() on a module in eval mode "
+                                     "(a forward that needs autograd or train-mode dropout goes through Contriever.forward)")
         if self.config.pooling not in _POOLING:
             raise _lib.AtlasHipError(f"pooling={self.config.pooling!r}: the reference knows 'average', 'sqrt', 'cls' (retrievers.py:51-56)")
         return p.dtype
+
+    def _needs_training_forward(self) -> bool:
+        """autograd through the parameters, or train-mode dropout: the two things the eval-mode HIP encoder does not do"""
+        if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+            return True
+        return self.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in self.modules())
 
     def _out_dtype(self):
         # 'sqrt' divides a model-dtype tensor by an fp32 tensor: torch promotes, the reference returns fp32 (retrievers.py:53-54)
@@ -252,24 +269,30 @@ class Contriever(nn.Module):
                 output_hidden_states=None, normalize=False, trim_padding=False):
         """retrievers.py:22-60. Only the arguments atlas.py passes are supported (ids, mask, token_type_ids)."""
         assert position_ids is None and head_mask is None and inputs_embeds is None and encoder_hidden_states is None
+        if self._needs_training_forward():
+            from .retriever_train import training_forward
+
+            self.last_path = "autograd"
+            return training_forward(self, input_ids, attention_mask, token_type_ids, normalize=normalize)
+        self.last_path = "hip"
         out = torch.empty((input_ids.shape[0], EMBEDDINGS_DIM), dtype=self._out_dtype(), device=input_ids.device)
         self.embed_into(out, input_ids, attention_mask, token_type_ids, trim_padding=trim_padding)
         if normalize:
             out = torch.nn.functional.normalize(out, dim=-1).clone()
         return out
 
-    def gradient_checkpointing_enable(self):     # retrievers.py:81-87 calls these on children
-        pass
+    def gradient_checkpointing_enable(self):     # retrievers.py:81-87 calls these on children; the flag of modeling_bert.py:559, 586
+        self.encoder.gradient_checkpointing = True
 
     def gradient_checkpointing_disable(self):
-        pass
+        self.encoder.gradient_checkpointing = False
 
     def __deepcopy__(self, memo):                # atlas.py:59 deep-copies the retriever: drop the packed cache
         new = type(self).__new__(type(self))
         memo[id(self)] = new
         nn.Module.__init__(new)
         for k, v in self.__dict__.items():
-            if k in ("_packed", "_ws", "_library"):
+            if k in ("_packed", "_ws", "_library", "last_path"):
                 new.__dict__[k] = None
             else:
                 new.__dict__[k] = copy.deepcopy(v, memo)

@@ -79,8 +79,26 @@ def test_deepcopy_half_eval_like_atlas(gpu_index_cls):
         e = r16(input_ids=ids.cuda(), attention_mask=mask.cuda(), is_passages=True)   # atlas.py:78 passes **batch_enc
     want = ref.cuda()(ids.cuda(), mask.cuda())
     assert (e.float() - want.float()).abs().max() / want.float().abs().max() <= 2e-3
-    with pytest.raises(Exception, match="autograd"):
-        r(ids.cuda(), mask.cuda())                              # training forward (needs grad): not provided, and says so
+    assert r16.contriever.last_path == "hip"
+    # the training forward (train mode, autograd: atlas.py:457-465) is torch-operator plumbing on the same parameters
+    e_train = r(ids.cuda(), mask.cuda())
+    assert r.contriever.last_path == "autograd" and e_train.requires_grad
+    e_train.pow(2).sum().backward()
+    assert r.contriever.encoder.layer[0].attention.self.query.weight.grad is not None
+
+
+def test_hip_inference_and_autograd_forward_agree_in_fp32(gpu_index_cls):
+    """the two implementations behind `Contriever.forward` on the same fp32 parameters in eval mode: the HIP encoder (no grad) and the
+    torch-operator training forward (grad) differ by summation order only"""
+    ref, mine = _models(2)
+    mine = mine.float().eval().requires_grad_(True)
+    ids, mask = _batch(6, 48, 13)
+    with torch.no_grad():
+        hip = mine(ids.cuda(), mask.cuda())
+    assert mine.last_path == "hip" and not hip.requires_grad
+    auto = mine(ids.cuda(), mask.cuda())
+    assert mine.last_path == "autograd" and auto.requires_grad
+    assert float((hip - auto.detach()).abs().max() / auto.detach().abs().max()) <= 2e-5
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.2e-2)])
