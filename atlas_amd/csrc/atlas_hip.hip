@@ -99,6 +99,7 @@ struct MergeParams {
     const uint2* lists; const uint32_t* list_cnt; const uint32_t* wg_stat; int G, cap;   // the scan's per-(workgroup, query) candidate lists
     int total_cap;               // most candidates a query may bring to the merge (more: exact path)
     uint32_t* epoch;             // per-workspace call counter: block 0 bumps it (the next scan's granule tag)
+    uint32_t* ticket;            // the scan's pool-tile counter: block 0 puts it back to zero for the next scan
     uint32_t* qflag;             // read, then cleared for the next call by the block that owns the query
     int k, q0;                   // q0: first query of this chunk (output row offset)
     int key_cap;                 // approximate-score keys that fit in LDS
@@ -182,7 +183,7 @@ merge_rescore_kernel(const MergeParams p) {
     if (tid == 0) {                      // per-call state kept in the workspace is put back for the next call here: this block is the only
         flagged = p.qflag[q];            // reader of its query's flag, and every scan workgroup has finished
         p.qflag[q] = 0u;
-        if (q == 0) *p.epoch = *p.epoch + 1u;
+        if (q == 0) { *p.epoch = *p.epoch + 1u; *p.ticket = 0u; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
@@ -685,10 +686,21 @@ constexpr unsigned long long* g_scan_dbg = nullptr;
 constexpr int scan_variant_index() { return 0; }
 constexpr bool scan_coop_enabled() { return true; }
 #endif
+// run-time tile pool at the end of the slab: share of a workgroup's tiles that is NOT pre-assigned, and its cap
+#if ATLAS_TUNING
+int g_pool_permille = 60, g_pool_max = 16;   // atlas_tune_set_scan_pool
+int pool_permille() { return g_pool_permille; }
+int pool_max_per_wg() { return g_pool_max; }
+#else
+constexpr int pool_permille() { return 60; }
+constexpr int pool_max_per_wg() { return 16; }
+#endif
 
 struct ScanPlan {
     int G;               // workgroups
-    int64_t rows_per_wg;
+    int64_t rows_per_wg; // static range of every workgroup
+    int64_t pool_begin;  // rows [pool_begin, N) are handed out at run time, a tile at a time (scan_kernel.h: fill_next_tile)
+    int pool_rows, pool_tiles;
     int keep_max, cap, tile, buf_cap, flush_at;
     int S; int64_t sample_stride;     // sample pre-pass: S rows (0 = none), tile j starts at j*sample_stride
     int key_cap;
@@ -716,6 +728,28 @@ ScanPlan make_plan(int64_t N, int d, int k, int cus, const ScanVariant& v) {
     pl.G = (int)G;
     pl.rows_per_wg = ((frags + G - 1) / G) * 16;
     pl.tile = v.nw * v.pf * 16;
+    // The tail of the slab is not pre-assigned. Workgroups stream at rates that differ by a few per cent from call to call (which CUs
+    // are slow changes: a table measured on earlier calls did not help, profiles/r02/scan_tail.txt), so with equal static ranges the
+    // last workgroup ends 30-50 us after the median one at 4M rows. Each workgroup therefore gets pool_per_wg tiles LESS than its
+    // share, and the tiles of the pool [pool_begin, N) go to whoever is ready for the next one (one ticket per tile, drawn one tile
+    // ahead). Shards with fewer than 8 tiles per workgroup keep the static split.
+    pl.pool_begin = N; pl.pool_rows = 0; pl.pool_tiles = 0;
+    {
+        const int64_t tiles_per_wg = N / ((int64_t)G * pl.tile);
+        int64_t pool_per_wg = tiles_per_wg * pool_permille() / 1000;
+        if (pool_per_wg < 1) pool_per_wg = 1;
+        if (pool_per_wg > pool_max_per_wg()) pool_per_wg = pool_max_per_wg();
+        // one buffer descriptor spans the pool (< 4 GiB), and virtual candidate rows have 26 bits
+        const int64_t by_bytes = ((int64_t)0xe0000000ll / (D_FAST * 2)) / ((int64_t)G * pl.tile) - 1;
+        if (pool_per_wg > by_bytes) pool_per_wg = by_bytes;
+        if (tiles_per_wg >= 8 && pool_permille() > 0) {
+            pl.rows_per_wg = (tiles_per_wg - pool_per_wg) * pl.tile;
+            pl.pool_begin = (int64_t)G * pl.rows_per_wg;
+            pl.pool_rows = (int)(N - pl.pool_begin);          // < (pool_per_wg + 1) * G * tile + G * tile rows: far below 2^31
+            const int pool_tile = (v.nw - 1) * v.pf * 16;     // pool tiles leave the ticket wave without rows (scan_kernel.h)
+            pl.pool_tiles = (pl.pool_rows + pool_tile - 1) / pool_tile;
+        }
+    }
     pl.keep_max = (2 * k > k + 64) ? 2 * k : k + 64;
     // LDS candidate buffer: what fits next to the 96 KiB query image. A flush into the global lists (scattered stores, the ring of slab
     // loads drained and restarted: 15-20 us per workgroup, profiles/r02/scan_tail.txt) is requested at 3/4: a 4M-row shard collects ~2.3k
@@ -791,6 +825,7 @@ extern "C" int atlas_dbg_f64_to_f16(const double* in, uint16_t* out, int n, void
 // tuning build only (not in include/atlas_hip.h): scan variant, device buffers for cycle stamps
 void atlas_tune_set_scan_variant(int v) { g_scan_variant = v; }
 void atlas_tune_set_scan_coop(int c) { g_scan_coop = c; }
+void atlas_tune_set_scan_pool(int permille, int max_per_wg) { g_pool_permille = permille; g_pool_max = max_per_wg; }
 void atlas_tune_set_merge_stamps(unsigned long long* p) { g_merge_dbg = p; }
 void atlas_tune_set_scan_stamps(unsigned long long* p) { g_scan_dbg = p; }
 #endif
@@ -834,7 +869,8 @@ int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t
     const ScanPlan pl = make_plan(N, d, k, device_cus(), var);
     // per-lane byte offsets inside one workgroup's range are 32-bit (buffer voffset)
     if ((pl.rows_per_wg + 2 * pl.tile) * (int64_t)(D_FAST * 2) >= (int64_t)0xfff00000ll) return ATLAS_E_UNSUPPORTED;
-    if (pl.rows_per_wg + 2 * pl.tile >= (1 << 26)) return ATLAS_E_UNSUPPORTED;   // buffer entries carry 26-bit rows
+    if (pl.rows_per_wg + 2 * pl.tile + pl.pool_rows >= (1 << 26)) return ATLAS_E_UNSUPPORTED;   // buffer entries carry 26-bit (virtual) rows
+    if ((int64_t)pl.pool_rows * (D_FAST * 2) >= (int64_t)0xfff00000ll) return ATLAS_E_UNSUPPORTED;    // one descriptor spans the pool
     if (ws_bytes < pl.total) return ATLAS_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     unsigned char* w = (unsigned char*)ws;
@@ -877,6 +913,7 @@ int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t
         sp.lists = (uint2*)(w + pl.off_lists);
         sp.list_cnt = (uint32_t*)(w + pl.off_list_cnt); sp.wg_stat = (uint32_t*)(w + pl.off_wg_stat);
         sp.qflag = (uint32_t*)(w + pl.off_qflag);
+        sp.pool_begin = pl.pool_begin; sp.pool_rows = pl.pool_rows; sp.pool_tiles = pl.pool_tiles; sp.ticket = (uint32_t*)(w + pl.off_epoch + 128);
         sp.rows_per_wg = pl.rows_per_wg; sp.nq = nq; sp.k = k; sp.cap = pl.cap; sp.keep_max = pl.keep_max;
         sp.buf_cap = pl.buf_cap; sp.flush_at = pl.flush_at;
         sp.pmax2_hint = pmax_hint * pmax_hint;
@@ -888,7 +925,7 @@ int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t
         mp.slab = (const uint16_t*)slab_f16; mp.N = N; mp.d = d;
         mp.q = sp.q; mp.q_dtype = sp.q_dtype; mp.qbase = sp.q0; mp.pmax = pmax_hint;
         mp.lists = sp.lists; mp.list_cnt = sp.list_cnt; mp.wg_stat = sp.wg_stat; mp.G = pl.G; mp.cap = pl.cap;
-        mp.total_cap = pl.total_cap; mp.epoch = (uint32_t*)(w + pl.off_epoch);
+        mp.total_cap = pl.total_cap; mp.epoch = (uint32_t*)(w + pl.off_epoch); mp.ticket = sp.ticket;
         mp.qflag = sp.qflag; mp.k = k; mp.q0 = q0; mp.key_cap = pl.key_cap;
         mp.dbg = g_merge_dbg;
         mp.out_score = (uint16_t*)out_score_f16; mp.out_idx = out_idx; mp.out_status = out_status;

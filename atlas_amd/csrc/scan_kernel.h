@@ -189,7 +189,12 @@ struct ScanParams {
     uint32_t* list_cnt;       // [64][G] entries of lists[q][g] at the end of the scan (plain stores: every workgroup writes its 64)
     uint32_t* wg_stat;        // [G][2]  per workgroup: largest row sum of squares seen (float bits) | ATLAS_F_* flags
     uint32_t* qflag;          // [64] per-query fallback flag (band overflow; plain idempotent stores)
-    int64_t rows_per_wg;
+    int64_t rows_per_wg;      // rows of every workgroup's STATIC range [g * rows_per_wg, +rows_per_wg) (clipped to N)
+    // the tail of the slab, [pool_begin, N), is not pre-assigned: it is handed out in tiles at run time (pool_tiles == 0: no pool).
+    // Pool tile g is workgroup g's first one; further tiles come from the ticket counter (tile = G + ticket), see the main loop.
+    int64_t pool_begin;
+    int pool_rows, pool_tiles;
+    uint32_t* ticket;         // per-workspace counter, zero at launch (the merge kernel puts it back)
     int nq, k, cap, keep_max;
     int buf_cap;              // entries of the LDS candidate buffer
     int flush_at;             // buffer fill at which a flush into the global lists is requested
@@ -250,7 +255,7 @@ scan_kernel(const ScanParams p) {
     const int64_t wrow0 = r_begin + (int64_t)wave * PF * 16;
     int64_t span = (wrow0 < r_end) ? (r_end - wrow0) * (int64_t)ROWB : 0;
     if (span > 0xfffffff0ll) span = 0xfffffff0ll;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const unsigned char*)p.slab + (span > 0 ? wrow0 : 0) * (int64_t)ROWB), 0, (int)span, 0x00020000);
 
     // fill cursor: (rows of the tile being fetched -> vo[], k-step -> fill_step); it runs RING-1
@@ -260,13 +265,53 @@ scan_kernel(const ScanParams p) {
 #pragma unroll
     for (int pf = 0; pf < PF; ++pf) vo[pf] = (unsigned)((pf * 16 + lrow) * ROWB + lgrp * 16);
     int fill_step = 0;
-    auto fill_advance = [&]() {
-        ++fill_step;
-        if (fill_step == KSTEPS) {          // scalar condition: next tile of this wave
-            fill_step = 0;
+    // The tile sequence of a workgroup: its static tiles 0 .. ntiles-1, then pool tiles. The fill cursor enters tile f_seq + 1 seven
+    // k-steps before the consumer leaves tile f_seq, so it is the fill cursor that finds out where the next tile is:
+    //   static tile          the next TILE rows of the wave's descriptor;
+    //   first pool tile      pool tile blockIdx.x (pre-assigned);
+    //   every further one    G + the ticket that wave NW-1 drew at the START of the tile before (a plain returning atomic) and posted
+    //                        in LDS as {sequence number, ticket}; readers spin on the LDS word (lgkmcnt only -- the ring of slab
+    //                        loads is not disturbed), which in practice is there 10 us earlier.
+    // Pool tiles have POOL_TILE = (NW-1) * PF * 16 rows: wave NW-1 takes none. A returning atomic waits behind everything its CU has
+    // in flight (~5 us under a full ring) and the compiler drains the wave's own ring for it; with rows of its own the ticket wave
+    // reached every tile barrier last (measured: +4 us per pool tile). Its loads fall out of bounds instead (zeros, no traffic).
+    // A ticket past the last pool tile ends the sequence: the remaining fills fall out of bounds as well.
+    constexpr int POOL_TILE = (NW - 1) * PF * 16;
+    // (an LDS-address-space pointer: through a generic pointer the poll below would be a FLAT load, which counts in vmcnt and would
+    //  drain the ring of slab loads once per tile)
+    typedef __attribute__((address_space(3))) volatile unsigned long long lds_vu64;
+    lds_vu64* s_tk = (lds_vu64*)(smem + ScanSmem::flag_off + 32);   // [4] ring of posted {sequence number << 32 | ticket}
+    const uint32_t vpool = (uint32_t)p.rows_per_wg;        // virtual row index of pool row 0 in this workgroup's candidate entries
+    int f_seq = 0;                  // tile the fill cursor is in
+    uint32_t n_pt = 0;              // pool tile the fill cursor last entered
+    bool n_ok = false;              //   ... and whether it exists
+    auto fill_next_tile = [&]() {   // scalar code, once per tile
+        fill_step = 0;
+        ++f_seq;
+        if (f_seq < ntiles) {
 #pragma unroll
             for (int pf = 0; pf < PF; ++pf) vo[pf] += (unsigned)(TILE * ROWB);
+            return;
         }
+        uint32_t pt = blockIdx.x;
+        if (f_seq > ntiles) {
+            unsigned long long e = s_tk[f_seq & 3];
+            while ((uint32_t)(e >> 32) != (uint32_t)f_seq) { __builtin_amdgcn_s_sleep(1); e = s_tk[f_seq & 3]; }
+            pt = gridDim.x + (uint32_t)e;
+        }
+        pt = __builtin_amdgcn_readfirstlane(pt);
+        n_pt = pt;
+        n_ok = pt < (uint32_t)p.pool_tiles;
+        const int64_t pool_bytes = (int64_t)p.pool_rows * ROWB;                  // < 2^32 - 16 (host plan)
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)p.slab + p.pool_begin * (int64_t)ROWB), 0, (int)pool_bytes, 0x00020000);
+#pragma unroll
+        for (int pf = 0; pf < PF; ++pf)
+            vo[pf] = (n_ok && wave < NW - 1) ? (unsigned)(((pt * (uint32_t)POOL_TILE + (uint32_t)(wave * PF * 16 + pf * 16 + lrow)) * (uint32_t)ROWB) + (uint32_t)lgrp * 16u)
+                                             : 0xfffffff0u;
+    };
+    auto fill_advance = [&](const bool may_wrap) {   // the cursor wraps at ring slot 0 only: KSTEPS % RING == 0 and it runs RING-1 steps ahead
+        ++fill_step;
+        if (may_wrap && fill_step == KSTEPS) fill_next_tile();
     };
 
     u32x4 abuf[RING][PF];
@@ -275,7 +320,7 @@ scan_kernel(const ScanParams p) {
 #pragma unroll
         for (int pf = 0; pf < PF; ++pf)
             abuf[s][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)vo[pf], fill_step * 64, AUX);
-        fill_advance();
+        fill_advance(false);
         // keep issue order == ring order: hipcc's waitcnt for slot 0 is the minimum over the loop
         // entry and the back edge, so a shuffled prologue would cost ring depth on every revolution
         __builtin_amdgcn_sched_barrier(0);
@@ -324,6 +369,7 @@ scan_kernel(const ScanParams p) {
     });
     if (tid < 64) s_cnt[tid] = 0;
     if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; }
+    if (tid < 4) s_tk[tid] = 0ull;      // sequence number 0 is never asked for (LDS keeps the previous kernel's words)
     __syncthreads();
     float* s_eps = (float*)(smem + ScanSmem::aux_off + 256);
     if (wave == NW - 1) ATLAS_SCAN_STAMP_LANE0(1);   // [1] (re-stamped) image barrier passed
@@ -360,9 +406,14 @@ scan_kernel(const ScanParams p) {
     float pm = 0.0f;   // running max of row sum-of-squares seen by this lane's row group
 
     // rows relative to r_begin fit 32 bits (plan guarantees rows_per_wg * 1536 < 2^32)
-    const int nrows = (int)(r_end > r_begin ? r_end - r_begin : 0);
+    // Candidate entries carry a 26-bit VIRTUAL row: [0, rows_per_wg) = the static range, from vpool on = pool rows (host plan keeps
+    // vpool + pool_rows below 2^26); global_row() turns it into the shard-local row when entries leave for the global lists
+    int nrows = (int)(r_end > r_begin ? r_end - r_begin : 0);      // end of the valid virtual rows of the current tile's region
     const uint32_t gbase = (uint32_t)r_begin;          // shard-local row ids are < 2^32
-    int row0 = wave * PF * 16;   // first row (relative) of this wave's current tile
+    const uint32_t pbase = (uint32_t)p.pool_begin - vpool;
+    auto global_row = [&](const uint32_t v) -> uint32_t { return v + (v >= vpool ? pbase : gbase); };
+    int row0 = wave * PF * 16;   // first (virtual) row of this wave's current tile
+    int c_seq = 0;               // tile the consumer is in
     int par = 0;               // tile parity (double-buffers the compaction-request flag)
     int cstep = 0;             // consumer k-step inside the tile
 
@@ -376,7 +427,7 @@ scan_kernel(const ScanParams p) {
             const uint2 e = s_buf[i];
             const uint32_t qq = e.y >> 26;
             const uint32_t gs = atomicAdd(&s_cnt[qq], 1u);
-            if (gs < (uint32_t)p.cap) my_lists[qq * qstride + gs] = make_uint2(e.x, gbase + (e.y & 0x03ffffffu));
+            if (gs < (uint32_t)p.cap) my_lists[qq * qstride + gs] = make_uint2(e.x, global_row(e.y & 0x03ffffffu));
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);     // list stores complete before anyone reads them back
         wg_barrier_lds();
@@ -508,8 +559,9 @@ scan_kernel(const ScanParams p) {
     // One flat loop over ring revolutions of all tiles: the ring rotation is the same every
     // iteration (no register shuffling at tile boundaries), and the per-tile work (filter,
     // barrier) hangs off every RPT-th revolution.
+    if (ntiles > 0)
 #pragma unroll 1
-    for (int rev = 0; rev < ntiles * RPT; ++rev) {
+    for (;;) {
         // B operands of this revolution: query rows (16 qf + lrow), 16 bytes at k-step * 64 + 16 * lgrp (two bases: the offset of
         // query group 3 does not fit the 16-bit immediate of ds_read_b128)
         const uint4* bq0 = s_q + lrow * QROW_U4 + lgrp + cstep * 4;
@@ -523,7 +575,7 @@ scan_kernel(const ScanParams p) {
 #pragma unroll
             for (int pf = 0; pf < PF; ++pf)
                 abuf[fill][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)vo[pf], fill_step * 64, AUX);
-            fill_advance();
+            fill_advance(j == 0);
             __builtin_amdgcn_sched_barrier(0);
             uint4 b[4];
 #pragma unroll
@@ -576,7 +628,7 @@ scan_kernel(const ScanParams p) {
                         }
             }
         }
-        if (p.coop && row0 < TILE) {           // workgroup-uniform: the end of every wave's FIRST tile
+        if (p.coop && c_seq == 0) {            // workgroup-uniform: the end of every wave's FIRST tile
             float tm[4];
 #pragma unroll
             for (int qf = 0; qf < 4; ++qf) {
@@ -629,7 +681,7 @@ scan_kernel(const ScanParams p) {
                                     const uint32_t gs = atomicAdd(&s_cnt[qq], 1u);
                                     if (gs < (uint32_t)p.cap)
                                         my_lists[qq * qstride + gs] =
-                                            make_uint2(f32_bits(v), gbase + rrel + (uint32_t)(pf * 16 + r));
+                                            make_uint2(f32_bits(v), global_row(rrel + (uint32_t)(pf * 16 + r)));
                                     s_flag[par] = 1u;
                                     spilled = true;
                                 }
@@ -647,16 +699,28 @@ scan_kernel(const ScanParams p) {
         }
 
         wg_barrier_lds();
-        if (row0 == 0) ATLAS_SCAN_STAMP(3);   // [3] first tile done
+        if (c_seq == 0) ATLAS_SCAN_STAMP(3);   // [3] first tile done
 #if ATLAS_TUNING
         // per-tile end stamps of this workgroup, collected in LDS (no global store in the loop) and dumped after the hand-over
-        if (p.dbg && tid == 0 && row0 / TILE < 120) ((unsigned long long*)(smem + ScanSmem::buf_off + (size_t)p.buf_cap * 8))[row0 / TILE] = wall_clock64();
+        if (p.dbg && tid == 0 && c_seq < 120) ((unsigned long long*)(smem + ScanSmem::buf_off + (size_t)p.buf_cap * 8))[c_seq] = wall_clock64();
 #endif
         // the request word of this tile's parity cannot change until every wave has passed the next
         // barrier, so all waves take the same branch
         if (s_flag[par] != 0u) flush_and_compact(par, false);
-        row0 += TILE;
         par ^= 1;
+        // on to tile c_seq + 1 (the fill cursor entered it seven k-steps ago and knows where it is)
+        ++c_seq;
+        if (c_seq < ntiles) row0 += TILE;
+        else {
+            if (!n_ok) break;                                   // workgroup-uniform: every wave read the same ticket
+            nrows = (int)vpool + p.pool_rows;
+            row0 = (wave < NW - 1) ? (int)(vpool + n_pt * (uint32_t)POOL_TILE) + wave * PF * 16 : nrows;     // the ticket wave has no rows
+            // the ticket of the tile after this one, drawn now (see fill_next_tile)
+            if (wave == NW - 1 && lane == 0) {
+                const uint32_t t = atomicAdd(p.ticket, 1u);
+                s_tk[(c_seq + 1) & 3] = ((unsigned long long)(uint32_t)(c_seq + 1) << 32) | (unsigned long long)t;
+            }
+        }
     }
 
     ATLAS_SCAN_STAMP(4);        // [4] last tile done
@@ -673,7 +737,7 @@ scan_kernel(const ScanParams p) {
             const uint2 e = s_buf[i];
             const uint32_t qq = e.y >> 26;
             const uint32_t gs = atomicAdd(&s_cnt[qq], 1u);
-            if (gs < (uint32_t)p.cap) my_lists[qq * qstride + gs] = make_uint2(e.x, gbase + (e.y & 0x03ffffffu));
+            if (gs < (uint32_t)p.cap) my_lists[qq * qstride + gs] = make_uint2(e.x, global_row(e.y & 0x03ffffffu));
         }
         // largest row norm^2 of the workgroup (x1.001: v_dot2 accumulates in fp32): waves -> LDS -> one word
 #pragma unroll
@@ -696,7 +760,7 @@ scan_kernel(const ScanParams p) {
     }
     ATLAS_SCAN_STAMP(5);        // [5] hand-over done
 #if ATLAS_TUNING
-    if (p.dbg && tid < 120) p.dbg[2048 + blockIdx.x * 120 + tid] = (tid < ntiles) ? ((unsigned long long*)(smem + ScanSmem::buf_off + (size_t)p.buf_cap * 8))[tid] : 0ull;
+    if (p.dbg && tid < 120) p.dbg[2048 + blockIdx.x * 120 + tid] = (tid < c_seq) ? ((unsigned long long*)(smem + ScanSmem::buf_off + (size_t)p.buf_cap * 8))[tid] : 0ull;
 #endif
 }
 

@@ -103,6 +103,9 @@ const char* atlas_build_info(void);          /* "gfx950 <compile date> ..." */
  * from its own first tiles -- the workgroups exchange 8-byte granules inside the kernel; every wait is bounded, a value
  * that does not arrive in time only loosens a threshold -- and leaves per-workgroup candidate lists) and the merge
  * (exact rescoring of the candidate band, canonical order). Shards below 65 536 rows start without thresholds.
+ * The last ~6 % of a large shard's rows are handed out to the scan's workgroups at run time (one ticket per 240-row tile
+ * from a counter in the workspace state, put back by the merge): which workgroup scans which of those rows differs from
+ * call to call, the result -- canonical order, exact scores -- does not.
  */
 size_t atlas_scan_topk_workspace_bytes(int64_t N, int B, int d, int k);
 int atlas_scan_topk(const void* q, int q_dtype, const void* slab_f16, int64_t N, int B, int d,

@@ -268,6 +268,47 @@ def test_1m_scan_equals_exact_path(big):
     assert (s[:, :-1] >= s[:, 1:]).all()
 
 
+@pytest.mark.parametrize("rows", [700_001, 1_000_000])
+def test_tail_pool_hand_out_does_not_change_the_result(rows, big):
+    """The tail of the slab is handed out to the scan's workgroups at run time, a tile at a time (scan_kernel.h: fill_next_tile;
+    who scans which pool tile differs from call to call). Through the tuning build of the same sources, with the pool switched off,
+    at its product setting, and covering half / nearly all of the slab: every configuration returns the exact path's ids and score
+    bits for all 64 queries, three calls in a row on one workspace (the ticket counter is put back by the merge kernel)."""
+    import ctypes
+    from atlas_amd import _lib
+
+    idx, slab, q = big
+    T = _lib.lib(tuning=True)
+    T.atlas_tune_set_scan_pool.argtypes, T.atlas_tune_set_scan_pool.restype = [ctypes.c_int, ctypes.c_int], None
+    N, B, k = rows, 64, 40
+    sub = slab[:N]
+    es, ei = _index_of(idx.__class__, sub)._exact_topk(q, k)
+    out_s = torch.empty((B, k), dtype=torch.float16, device="cuda")
+    out_i = torch.empty((B, k), dtype=torch.int64, device="cuda")
+    out_st = torch.zeros(_lib.STATUS_HEADER + B, dtype=torch.int32, device="cuda")
+    try:
+        for permille, cap in ((0, 16), (60, 16), (500, 64), (950, 255)):
+            T.atlas_tune_set_scan_pool(permille, cap)
+            ws = torch.zeros(int(T.atlas_scan_topk_workspace_bytes(N, B, 768, k)), dtype=torch.uint8, device="cuda")
+            for rep in range(3):
+                out_s.zero_(); out_i.zero_()
+                rc = T.atlas_scan_topk(q.data_ptr(), _lib.DT_F32, sub.data_ptr(), N, B, 768, k, 1.001, out_s.data_ptr(), out_i.data_ptr(),
+                                       out_st.data_ptr(), ws.data_ptr(), ws.numel(), None)
+                assert rc == 0, rc
+                torch.cuda.synchronize()
+                st = out_st.cpu().numpy()
+                assert int(st[_lib.ST_FLAGS]) == 0 and int(st[_lib.ST_N_FALLBACK]) == 0, (permille, rep, st[:8])
+                assert torch.equal(out_s, es) and torch.equal(out_i, ei), (permille, cap, rep)
+    finally:
+        T.atlas_tune_set_scan_pool(60, 16)
+
+
+def _index_of(cls, slab):
+    sh = cls()
+    sh._set_slab(slab)
+    return sh
+
+
 def test_1m_sharding_invariance(big, gpu_index_cls):
     """top-k of 8 round-robin shards, packed + merged, is identical to the single-shard result"""
     from atlas_amd import index as im

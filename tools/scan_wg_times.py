@@ -60,7 +60,8 @@ for N in [int(a) for a in sys.argv[1:]] or [1_000_000, 4_000_000]:
     # per-tile picture of the last repetition: tile period (us) of the median workgroup vs the 8 slowest, tile by tile
     t = res[-1]
     order = np.argsort(t[:, 4])
-    nt = int(np.isfinite(last_tiles[0]).sum())
+    nt = int(np.isfinite(last_tiles).sum(axis=1).max())       # (workgroups draw different numbers of pool tiles)
+    print('  tiles per workgroup: min %d max %d' % (np.isfinite(last_tiles).sum(axis=1).min(), nt))
     per = np.diff(np.concatenate([t[:, 2:3], last_tiles[:, :nt]], axis=1), axis=1)      # [wg][tile] period
     med = np.nanmedian(per, axis=0)
     print(f"N={N}: tile periods (us), {nt} tiles; median over workgroups:", np.round(med, 1).tolist())
