@@ -268,7 +268,7 @@ def test_1m_scan_equals_exact_path(big):
     assert (s[:, :-1] >= s[:, 1:]).all()
 
 
-@pytest.mark.parametrize("rows", [700_001, 1_000_000])
+@pytest.mark.parametrize("rows", [524_288, 524_527, 700_001, 1_000_000])      # 8 tiles per workgroup exactly (the smallest pooled shard), + 239 rows, ragged, 1M
 def test_tail_pool_hand_out_does_not_change_the_result(rows, big):
     """The tail of the slab is handed out to the scan's workgroups at run time, a tile at a time (scan_kernel.h: fill_next_tile;
     who scans which pool tile differs from call to call). Through the tuning build of the same sources, with the pool switched off,
