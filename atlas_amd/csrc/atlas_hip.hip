@@ -742,6 +742,7 @@ ScanPlan make_plan(int64_t N, int d, int k, int cus, const ScanVariant& v) {
         // one buffer descriptor spans the pool (< 4 GiB), and virtual candidate rows have 26 bits
         const int64_t by_bytes = ((int64_t)0xe0000000ll / (D_FAST * 2)) / ((int64_t)G * pl.tile) - 1;
         if (pool_per_wg > by_bytes) pool_per_wg = by_bytes;
+        if (pool_per_wg > tiles_per_wg - 1) pool_per_wg = tiles_per_wg - 1;     // every workgroup keeps a static tile: its first tile is the sample
         if (tiles_per_wg >= 8 && pool_permille() > 0) {
             pl.rows_per_wg = (tiles_per_wg - pool_per_wg) * pl.tile;
             pl.pool_begin = (int64_t)G * pl.rows_per_wg;
