@@ -62,7 +62,8 @@ def main():
     ap.add_argument("--refresh-batches", type=int, default=30, help="timed 512-passage encoder batches for the index-refresh leg (0 = skip)")
     ap.add_argument("--refresh-len", type=int, default=128, help="tokens per passage in the refresh leg")
     ap.add_argument("--refresh-stream-seconds", type=float, default=2.0, help="sustained streamed-refresh leg from the token store (0 = skip)")
-    ap.add_argument("--shard-sweep", type=str, default="1000000,4000000", help="prefix sizes of the slab timed like the headline (N=1 only; '' = skip)")
+    ap.add_argument("--shard-sweep", type=str, default="1000000,4000000,8000000,16000000",
+                    help="prefix sizes of the slab timed like the headline: configs[1] and the per-GPU shards of an 8 / 4 / 2-GPU run (N=1 only; '' = skip)")
     ap.add_argument("--oracle-query", type=int, default=31, help="query of the batch held to the CPU oracle at full size in the cpu_baseline leg (-1 = skip)")
     args = ap.parse_args()
 
@@ -213,7 +214,7 @@ def main():
         assert torch.equal(out_s[sel], es) and torch.equal(out_i[sel], ei), "scan disagrees with the exact path at the benchmark size"
         parity_checked = {"rows": rows, "queries_exact": int(sel.numel()), "queries_oracle": 0}
 
-    # ---- the shard sizes an 8-GPU run actually scans (4M rows = 32M / 8) and BASELINE configs[1] (1M rows), on the first rows of the
+    # ---- BASELINE configs[1] (1M rows) and the shards a rank of an 8 / 4 / 2-GPU run of the default corpus scans (4M / 8M / 16M rows), on the first rows of the
     # same slab, timed exactly like the headline (same step, same fence, hipEvents around the scan kernel)
     shard_sweep = None
     if world == 1 and args.shard_sweep:
