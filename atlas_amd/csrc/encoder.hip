@@ -928,6 +928,7 @@ gemm_ms_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     gemm_epilogue<T, EPI, FA, FB>(acc, m0, n0, wi, wj, lr, lg, M, N, bias, R, C, VT, cu, tokinfo, Lp);
 }
 
+#if ATLAS_TUNING     // an experiment kept selectable in the tuning build only (slower than the ping-pong kernel: profiles/r02/gemm_wr_ab.txt)
 // ------------------------------------------------------------------------------------------
 // gemm_wr_kernel: the bulk GEMM with the WEIGHT operand loaded straight into registers and only the activations staged in LDS.
 // What holds the 256 x 256 kernels above at ~1 190 TFLOP/s in the k-loop is feeding LDS: 64 KiB of LDS-DMA per k-tile, whose pieces
@@ -1052,6 +1053,7 @@ gemm_wr_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     if (diag & 1) { if (acc[0][0][0] == 12345.678f) C[0] = 0; return; }
     gemm_epilogue<T, EPI, FA, FB>(acc, m0, n0, wave, 0, lr, lg, M, N, bias, R, C, VT, cu, tokinfo, Lp);
 }
+#endif
 
 // GEMM configurations. The encoder picks by worst-case token slots n * L: > 16384 -> 4, > 4096 -> 0, else 3;
 // the tuning build's atlas_tune_set_gemm_cfg(n) forces one (tuning and the bit-equality test: every configuration gives the same bits).
@@ -1099,6 +1101,7 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
                                VT, cu, n, tokinfo, N, K, Lp, g_gemm_diag);
         } else go(gemm_bt_kernel<T, EPI, 256, 256, 2, 4>, 256, 256, 512);
     }
+#if ATLAS_TUNING
     else if (cfg == 8) {                               // weights in registers, activations through four LDS stages
         if constexpr (sizeof(typename T::elem) == 2) {
             (void)hipFuncSetAttribute((const void*)gemm_wr_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1107,6 +1110,7 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
                                VT, cu, n, tokinfo, N, K, Lp, g_gemm_diag);
         } else go(gemm_bt_kernel<T, EPI, 256, 256, 2, 4>, 256, 256, 512);
     }
+#endif
     else if (cfg == 2) go(gemm_bt_kernel<T, EPI, 256, 256, 2, 4>, 256, 256, 512);
     else if (cfg == 3) {
         constexpr int ST = (sizeof(typename T::elem) == 2) ? 3 : 4;   // measured: 3 x 16 KiB (3 workgroups / CU) best for 16-bit
