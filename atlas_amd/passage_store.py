@@ -2,7 +2,8 @@
 
 Why: `DistributedIndex.search_knn` returns passage dicts, and the winners of a query live on other
 ranks. The reference moves W*k pickled passages per query through `varsize_gather` (src/index.py:134-150, ~160 ms of
-host time per call); `HipDistributedIndex` without a store moves the k winners per query with one `all_gather_object`.
+host time per call); `HipDistributedIndex` without a store sends every rank the k winners of ITS queries in one personalised
+exchange (`dist_utils.exchange_objects`).
 With a store attached there is NO text collective: after the packed (score, id) all-gather every rank resolves the
 winners' ids locally. One copy per node (page cache / /dev/shm), shared by its ranks through mmap.
 
