@@ -790,6 +790,15 @@ ScanPlan make_plan(int64_t N, int d, int k, int cus, const ScanVariant& v) {
     return pl;
 }
 
+// the ranges the scan kernel's 32-bit offsets and 26-bit candidate rows can express
+bool scan_plan_supported(const ScanPlan& pl) {
+    // per-lane byte offsets inside one workgroup's range are 32-bit (buffer voffset)
+    if ((pl.rows_per_wg + 2 * pl.tile) * (int64_t)(D_FAST * 2) >= (int64_t)0xfff00000ll) return false;
+    if (pl.rows_per_wg + 2 * pl.tile + pl.pool_rows >= (1 << 26)) return false;        // buffer entries carry 26-bit (virtual) rows
+    if ((int64_t)pl.pool_rows * (D_FAST * 2) >= (int64_t)0xfff00000ll) return false;     // one descriptor spans the pool
+    return true;
+}
+
 struct ExactPlan { size_t off_qrow, off_qeps, off_state, off_sel, off_keys, total; };
 ExactPlan make_exact_plan(int64_t N, int d, int k) {
     ExactPlan e{}; size_t o = 0;
@@ -827,6 +836,15 @@ extern "C" int atlas_dbg_f64_to_f16(const double* in, uint16_t* out, int n, void
 void atlas_tune_set_scan_variant(int v) { g_scan_variant = v; }
 void atlas_tune_set_scan_coop(int c) { g_scan_coop = c; }
 void atlas_tune_set_scan_pool(int permille, int max_per_wg) { g_pool_permille = permille; g_pool_max = max_per_wg; }
+// the launch plan of a scan over N rows on a device with `cus` CUs, for host-side checks of its invariants (no GPU needed):
+// out = {G, rows_per_wg, pool_begin, pool_rows, pool_tiles, tile, pool_tile, supported (the range checks of atlas_scan_topk)}
+void atlas_tune_scan_plan(int64_t N, int k, int cus, int64_t* out) {
+    const ScanVariant& var = kVariants[scan_variant_index()];
+    const ScanPlan pl = make_plan(N, D_FAST, k, cus, var);
+    out[0] = pl.G; out[1] = pl.rows_per_wg; out[2] = pl.pool_begin; out[3] = pl.pool_rows; out[4] = pl.pool_tiles; out[5] = pl.tile;
+    out[6] = (var.nw - 1) * var.pf * 16;
+    out[7] = scan_plan_supported(pl) ? 1 : 0;
+}
 void atlas_tune_set_merge_stamps(unsigned long long* p) { g_merge_dbg = p; }
 void atlas_tune_set_scan_stamps(unsigned long long* p) { g_scan_dbg = p; }
 #endif
@@ -868,10 +886,7 @@ int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t
     if (d != D_FAST || k > K_FAST_MAX || N >= (int64_t)0xffffffffll) return ATLAS_E_UNSUPPORTED;
     const ScanVariant& var = kVariants[scan_variant_index()];
     const ScanPlan pl = make_plan(N, d, k, device_cus(), var);
-    // per-lane byte offsets inside one workgroup's range are 32-bit (buffer voffset)
-    if ((pl.rows_per_wg + 2 * pl.tile) * (int64_t)(D_FAST * 2) >= (int64_t)0xfff00000ll) return ATLAS_E_UNSUPPORTED;
-    if (pl.rows_per_wg + 2 * pl.tile + pl.pool_rows >= (1 << 26)) return ATLAS_E_UNSUPPORTED;   // buffer entries carry 26-bit (virtual) rows
-    if ((int64_t)pl.pool_rows * (D_FAST * 2) >= (int64_t)0xfff00000ll) return ATLAS_E_UNSUPPORTED;    // one descriptor spans the pool
+    if (!scan_plan_supported(pl)) return ATLAS_E_UNSUPPORTED;
     if (ws_bytes < pl.total) return ATLAS_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     unsigned char* w = (unsigned char*)ws;

@@ -1,0 +1,64 @@
+"""Host-side invariants of the scan's launch plan (csrc/atlas_hip.hip make_plan), through a hook of the tuning build (no GPU needed:
+the plan is host arithmetic). The kernel trusts the plan for its 32-bit byte offsets, its 26-bit virtual candidate rows and the
+one-descriptor pool; sizes that cannot be tested on a GPU in this environment (up to what fits 288 GB of HBM, and beyond) are
+covered here."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from atlas_amd import _lib
+
+ROWB = 768 * 2
+
+
+@pytest.fixture(scope="module")
+def plan():
+    T = _lib.lib(tuning=True)
+    T.atlas_tune_scan_plan.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]
+    T.atlas_tune_scan_plan.restype = None
+    T.atlas_tune_set_scan_pool.argtypes, T.atlas_tune_set_scan_pool.restype = [ctypes.c_int, ctypes.c_int], None
+
+    def f(N, k=40, cus=256):
+        out = (ctypes.c_int64 * 8)()
+        T.atlas_tune_scan_plan(N, k, cus, out)
+        return dict(zip(("G", "rows_per_wg", "pool_begin", "pool_rows", "pool_tiles", "tile", "pool_tile", "supported"), [int(x) for x in out]))
+
+    yield f, T
+    T.atlas_tune_set_scan_pool(60, 16)
+
+
+def _check(N, p):
+    G, R, tile = p["G"], p["rows_per_wg"], p["tile"]
+    assert 1 <= G <= 1024 and R % 16 == 0 and tile == 256 and p["pool_tile"] == 240
+    if p["pool_tiles"] == 0:
+        # static split: the ranges cover [0, N) and nothing else
+        assert p["pool_rows"] == 0 and G * R >= N and G * R - N < G * 16 + 16    # (trailing workgroups may be left without rows: ntiles == 0)
+    else:
+        assert R % tile == 0 and R >= tile                          # whole static tiles, at least one (the sample)
+        assert p["pool_begin"] == G * R and p["pool_begin"] + p["pool_rows"] == N and p["pool_rows"] > 0
+        assert p["pool_tiles"] == -(-p["pool_rows"] // p["pool_tile"])
+        assert p["pool_tiles"] >= G                                   # every workgroup's pre-assigned first pool tile exists
+    if p["supported"]:
+        assert (R + 2 * tile) * ROWB < 0xfff00000                    # 32-bit byte offsets inside a static range
+        assert p["pool_rows"] * ROWB < 0xfff00000                    # one descriptor spans the pool
+        assert R + 2 * tile + p["pool_rows"] < (1 << 26)             # 26-bit virtual candidate rows
+
+
+def test_plan_invariants_over_sizes(plan):
+    f, T = plan
+    rng = np.random.default_rng(7)
+    sizes = [0, 1, 15, 16, 17, 255, 256, 4097, 65535, 65536, 524287, 524288, 524289, 1_000_000, 4_000_000, 32_000_000,
+             100_000_000, 187_000_000, 715_000_000, 2**31 - 1, 2**32 - 2]
+    sizes += [int(x) for x in rng.integers(1, 200_000_000, size=300)] + [int(x) for x in rng.integers(1, 3_000_000, size=300)]
+    for permille, cap in ((60, 16), (0, 16), (500, 64), (950, 255), (1000, 4096)):
+        T.atlas_tune_set_scan_pool(permille, cap)
+        for N in sizes:
+            for cus in (256, 304, 64):
+                _check(N, f(N, cus=cus))
+    T.atlas_tune_set_scan_pool(60, 16)
+    # what fits one MI355X (288 GB: 187M rows) is supported with the product setting, pooled, and the pool stays small
+    for N in (1_000_000, 32_000_000, 100_000_000, 187_000_000):
+        p = f(N)
+        assert p["supported"] == 1 and p["pool_tiles"] > 0 and p["pool_rows"] <= 17 * 256 * 256 + 65536
+    assert f(100_000)["pool_tiles"] == 0 and f(524_287)["pool_tiles"] == 0 and f(524_288)["pool_tiles"] > 0
