@@ -688,12 +688,12 @@ constexpr bool scan_coop_enabled() { return true; }
 #endif
 // run-time tile pool at the end of the slab: share of a workgroup's tiles that is NOT pre-assigned, and its cap
 #if ATLAS_TUNING
-int g_pool_permille = 60, g_pool_max = 16;   // atlas_tune_set_scan_pool
+int g_pool_permille = 60, g_pool_max = 32;   // atlas_tune_set_scan_pool
 int pool_permille() { return g_pool_permille; }
 int pool_max_per_wg() { return g_pool_max; }
 #else
 constexpr int pool_permille() { return 60; }
-constexpr int pool_max_per_wg() { return 16; }
+constexpr int pool_max_per_wg() { return 32; }
 #endif
 
 struct ScanPlan {

@@ -300,7 +300,7 @@ def test_tail_pool_hand_out_does_not_change_the_result(rows, big):
                 assert int(st[_lib.ST_FLAGS]) == 0 and int(st[_lib.ST_N_FALLBACK]) == 0, (permille, rep, st[:8])
                 assert torch.equal(out_s, es) and torch.equal(out_i, ei), (permille, cap, rep)
     finally:
-        T.atlas_tune_set_scan_pool(60, 16)
+        T.atlas_tune_set_scan_pool(60, 32)
 
 
 def _index_of(cls, slab):

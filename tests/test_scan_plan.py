@@ -25,7 +25,7 @@ def plan():
         return dict(zip(("G", "rows_per_wg", "pool_begin", "pool_rows", "pool_tiles", "tile", "pool_tile", "supported"), [int(x) for x in out]))
 
     yield f, T
-    T.atlas_tune_set_scan_pool(60, 16)
+    T.atlas_tune_set_scan_pool(60, 32)
 
 
 def _check(N, p):
@@ -56,9 +56,9 @@ def test_plan_invariants_over_sizes(plan):
         for N in sizes:
             for cus in (256, 304, 64):
                 _check(N, f(N, cus=cus))
-    T.atlas_tune_set_scan_pool(60, 16)
+    T.atlas_tune_set_scan_pool(60, 32)
     # what fits one MI355X (288 GB: 187M rows) is supported with the product setting, pooled, and the pool stays small
     for N in (1_000_000, 32_000_000, 100_000_000, 187_000_000):
         p = f(N)
-        assert p["supported"] == 1 and p["pool_tiles"] > 0 and p["pool_rows"] <= 17 * 256 * 256 + 65536
+        assert p["supported"] == 1 and p["pool_tiles"] > 0 and p["pool_rows"] <= 33 * 256 * 256 + 65536
     assert f(100_000)["pool_tiles"] == 0 and f(524_287)["pool_tiles"] == 0 and f(524_288)["pool_tiles"] > 0

@@ -46,5 +46,5 @@ for N in [int(a) for a in sys.argv[1:]] or [1_000_000, 4_000_000]:
             t = np.array([a.elapsed_time(b) for a, b in evs])
             print(f"N={N:9d} pool={permille:3d}/1000 cap {cap:3d}: scan mean {t.mean():.4f} min {t.min():.4f} ms ({N * 1536 / t.mean() / 1e9 / 8:.3f} of peak)   step {step:.4f} ms "
                   f"({N * 1536 / step / 1e9 / 8:.3f})  candidates {int(st[3])}  identical={ok}", flush=True)
-    L.atlas_tune_set_scan_pool(60, 16)
+    L.atlas_tune_set_scan_pool(60, 32)
     del slab, idx, ws; torch.cuda.empty_cache()
