@@ -11,7 +11,7 @@ import torch
 from atlas_amd import HipDistributedIndex, _lib
 
 B, k, D = 64, 40, 768
-SETTINGS = [(0, 16), (30, 16), (60, 16), (60, 32), (120, 32)]
+SETTINGS = [(0, 16), (60, 16), (60, 32), (30, 48)]
 for N in [int(a) for a in sys.argv[1:]] or [1_000_000, 4_000_000]:
     reps = 40 if N <= 4_000_000 else 12
     g = torch.Generator(device="cuda").manual_seed(1)
