@@ -166,6 +166,16 @@ merge_rescore_kernel(const MergeParams p) {
         }
     };
     if (p.dbg && q == 0 && tid == 0) p.dbg[0] = __builtin_readcyclecounter();
+    // (0) the segment table's inputs are requested FIRST, together with the query (one trip to memory instead of two: the barrier
+    // behind the query conversion used to stand between them): thread g takes workgroup g's list length for this query and its
+    // norm / flag word (the scan's certification state is reduced here, the scan kernel itself ends without a single global atomic)
+    static_assert(NT >= MERGE_GMAX, "one thread per scan workgroup");
+    uint32_t cg = 0, pmb = 0, flg = 0;
+    if (tid < p.G) {
+        cg = p.list_cnt[(size_t)q * p.G + tid];
+        pmb = p.wg_stat[(size_t)tid * 2 + 0];                         // non-negative floats order like their bits
+        flg = p.wg_stat[(size_t)tid * 2 + 1];
+    }
     // this block's query, converted here (no preparation kernel), and its certified error bound
     double ss = 0.0;
     for (int i = tid; i < p.d; i += NT) {
@@ -191,15 +201,7 @@ merge_rescore_kernel(const MergeParams p) {
     __syncthreads();
     if (lane == 0) s_ss[wave] = ss;
     if (tid == 0) misc[8] = flagged;
-    // (0) the segment table: thread g takes workgroup g's list length for this query (and its norm / flag word: the scan's
-    // certification state is reduced here, the scan kernel itself ends without a single global atomic), then a block-wide exclusive scan
-    static_assert(NT >= MERGE_GMAX, "one thread per scan workgroup");
-    uint32_t cg = 0, pmb = 0, flg = 0;
-    if (tid < p.G) {
-        cg = p.list_cnt[(size_t)q * p.G + tid];
-        pmb = p.wg_stat[(size_t)tid * 2 + 0];                         // non-negative floats order like their bits
-        flg = p.wg_stat[(size_t)tid * 2 + 1];
-    }
+    // the segment table: a block-wide exclusive scan of the list lengths
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const uint32_t a = __shfl_xor(pmb, o);
