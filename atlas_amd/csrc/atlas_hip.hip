@@ -37,6 +37,7 @@ using namespace atlas;
 #define K_EXACT_MAX 2048
 #define MERGE_SMAX 2048          // max candidates rescored per query in the merge
 #define MERGE_GMAX 1024          // most scan workgroups (= threads of a merge block)
+#define MERGE_HEAD 8             // entries of every list requested speculatively together with its length
 
 
 // ------------------------------------------------------------------------------------------
@@ -176,6 +177,18 @@ merge_rescore_kernel(const MergeParams p) {
         pmb = p.wg_stat[(size_t)tid * 2 + 0];                         // non-negative floats order like their bits
         flg = p.wg_stat[(size_t)tid * 2 + 1];
     }
+    // ... and, speculatively, the first MERGE_HEAD entries of that list (64 bytes; the length is not known yet): most lists of a small
+    // shard are shorter than that (1M rows: 2.7 entries on average), and for those the gather below needs no trip of its own
+    uint2 head[MERGE_HEAD];
+    if (tid < p.G) {
+        const uint4* hp = (const uint4*)(p.lists + ((size_t)q * p.G + tid) * p.cap);
+#pragma unroll
+        for (int u = 0; u < MERGE_HEAD / 2; ++u) {
+            const uint4 v = hp[u];
+            head[2 * u] = make_uint2(v.x, v.y);
+            head[2 * u + 1] = make_uint2(v.z, v.w);
+        }
+    }
     // this block's query, converted here (no preparation kernel), and its certified error bound
     double ss = 0.0;
     for (int i = tid; i < p.d; i += NT) {
@@ -239,16 +252,29 @@ merge_rescore_kernel(const MergeParams p) {
     auto key_at = [&](const uint32_t i) -> uint32_t { return i < ncache ? keys[i] : f32_order_key(bits_f32(entry_at(i).x)); };
     if (p.dbg && q == 0 && tid == 0) p.dbg[1] = __builtin_readcyclecounter();
     // (1) keys (+ rows) -> LDS with min / max: a wave takes 16 segments at a time and requests all of them before it uses the first
-    // (the segments were written by workgroups of every XCD: each is its own trip to memory). Requesting the segment heads
-    // speculatively together with the lengths (one trip instead of two) was measured: slower (128 KiB over-read per block)
+    // (the segments were written by workgroups of every XCD: each is its own trip to memory). The first MERGE_HEAD entries of every
+    // list came with the table (one 64-byte read per list by the list's own thread: 16 KiB per block; a wave-wide speculative read
+    // of 64 entries per list, 128 KiB per block, was measured slower); this loop fetches what lies beyond them
     uint32_t kmax = 0, kmin = 0xffffffffu;
     constexpr int NWV = NT / 64, SEG = 16;
+    if (tid < p.G) {                                  // the heads that came with the table
+        const uint32_t base = s_off[tid];
+        const uint32_t nh = cg < (uint32_t)MERGE_HEAD ? cg : (uint32_t)MERGE_HEAD;
+#pragma unroll
+        for (int j = 0; j < MERGE_HEAD; ++j)
+            if ((uint32_t)j < nh) {
+                const uint32_t key = f32_order_key(bits_f32(head[j].x));
+                if (base + j < ncache) { keys[base + j] = key; rows_l[base + j] = head[j].y; }
+                kmax = key > kmax ? key : kmax;
+                kmin = key < kmin ? key : kmin;
+            }
+    }
     for (int g0 = wave * SEG; g0 < p.G; g0 += NWV * SEG) {
         uint32_t longest = 0;
 #pragma unroll
         for (int u = 0; u < SEG; ++u)
             if (g0 + u < p.G) { const uint32_t n = s_off[g0 + u + 1] - s_off[g0 + u]; longest = n > longest ? n : longest; }
-        for (uint32_t r0 = 0; r0 < longest; r0 += 64) {
+        for (uint32_t r0 = MERGE_HEAD; r0 < longest; r0 += 64) {       // entries beyond the heads
             uint2 sc[SEG];
 #pragma unroll
             for (int u = 0; u < SEG; ++u) {
