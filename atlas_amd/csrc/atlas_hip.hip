@@ -698,6 +698,8 @@ const ScanVariant kVariants[] = {
 #endif
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+// the production variant without the row-norm measurement, for callers that pass a certified pmax (ATLAS_SCAN_TRUST_PMAX)
+const ScanVariant kTrusted = {16, 1, 8, scan_kernel<16, 1, 8, 64>, "scan_kernel<16,1,8> (trusted pmax)"};
 
 constexpr int MERGE_NT = 1024;
 constexpr int SAMPLE_MAX = 16384;
@@ -909,10 +911,20 @@ int atlas_scan_topk(const void* q, int q_dtype, const void* slab_f16, int64_t N,
 int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t N, int B, int d, int k,
                        float pmax_hint, void* out_score_f16, int64_t* out_idx, int32_t* out_status, void* ws,
                        size_t ws_bytes, void* stream_, void* ev_scan_begin, void* ev_scan_end) {
+    return atlas_scan_topk_flags(q, q_dtype, slab_f16, N, B, d, k, pmax_hint, out_score_f16, out_idx, out_status, ws,
+                                 ws_bytes, stream_, ev_scan_begin, ev_scan_end, 0);
+}
+
+int atlas_scan_topk_flags(const void* q, int q_dtype, const void* slab_f16, int64_t N, int B, int d, int k,
+                          float pmax_hint, void* out_score_f16, int64_t* out_idx, int32_t* out_status, void* ws,
+                          size_t ws_bytes, void* stream_, void* ev_scan_begin, void* ev_scan_end, int flags) {
+    if (flags & ~ATLAS_SCAN_TRUST_PMAX) return ATLAS_E_BADARG;
     if (!q || (!slab_f16 && N > 0) || !out_score_f16 || !out_idx || !out_status || !ws) return ATLAS_E_BADARG;
     if (B <= 0 || k <= 0 || N < 0 || q_dtype < 0 || q_dtype > 2 || !(pmax_hint >= 0.f)) return ATLAS_E_BADARG;
     if (d != D_FAST || k > K_FAST_MAX || N >= (int64_t)0xffffffffll) return ATLAS_E_UNSUPPORTED;
-    const ScanVariant& var = kVariants[scan_variant_index()];
+    // same shape, same plan; the trusted twin exists for the production variant only
+    const bool trusted = (flags & ATLAS_SCAN_TRUST_PMAX) && scan_variant_index() == 0;
+    const ScanVariant& var = trusted ? kTrusted : kVariants[scan_variant_index()];
     const ScanPlan pl = make_plan(N, d, k, device_cus(), var);
     if (!scan_plan_supported(pl)) return ATLAS_E_UNSUPPORTED;
     if (ws_bytes < pl.total) return ATLAS_E_WORKSPACE;

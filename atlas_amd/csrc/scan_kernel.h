@@ -211,7 +211,9 @@ struct ScanSmem {   // byte offsets into dynamic LDS
     static constexpr int buf_off = aux_off + 768;         // buf_cap x {u32 score bits, u32 (query<<26)|row}
 };
 
-// AUX = cache-policy bits of the slab loads (0 = default, 2 = nt: rows are read once by one CU)
+// AUX & 31 = cache-policy bits of the slab loads (0 = default, 2 = nt: rows are read once by one CU)
+// AUX & 64 = the caller's pmax is certified (ATLAS_SCAN_TRUST_PMAX): the row norms are not measured (4 v_dot2 per MFMA less; the
+//            kernel runs at the board's power limit and that VALU work was 4.6 % of its time, profiles/r02/scan_power.txt)
 template <int NW, int PF, int RING, int AUX = 0>
 __global__ void __launch_bounds__(NW * 64)
 scan_kernel(const ScanParams p) {
@@ -319,7 +321,7 @@ scan_kernel(const ScanParams p) {
     for (int s = 0; s < RING - 1; ++s) {
 #pragma unroll
         for (int pf = 0; pf < PF; ++pf)
-            abuf[s][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)vo[pf], fill_step * 64, AUX);
+            abuf[s][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)vo[pf], fill_step * 64, AUX & 31);
         fill_advance(false);
         // keep issue order == ring order: hipcc's waitcnt for slot 0 is the minimum over the loop
         // entry and the back edge, so a shuffled prologue would cost ring depth on every revolution
@@ -574,7 +576,7 @@ scan_kernel(const ScanParams p) {
             const int fill = (j + RING - 1) % RING;
 #pragma unroll
             for (int pf = 0; pf < PF; ++pf)
-                abuf[fill][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)vo[pf], fill_step * 64, AUX);
+                abuf[fill][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)vo[pf], fill_step * 64, AUX & 31);
             fill_advance(j == 0);
             __builtin_amdgcn_sched_barrier(0);
             uint4 b[4];
@@ -594,10 +596,12 @@ scan_kernel(const ScanParams p) {
                 const unsigned ax = a.x, ay = a.y, az = a.z, aw = a.w;
                 const f16x2 h0 = __builtin_bit_cast(f16x2, ax), h1 = __builtin_bit_cast(f16x2, ay);
                 const f16x2 h2 = __builtin_bit_cast(f16x2, az), h3 = __builtin_bit_cast(f16x2, aw);
+                if constexpr (!(AUX & 64)) {
                 nrm[pf] = __builtin_amdgcn_fdot2(h0, h0, nrm[pf], false);
                 nrm[pf] = __builtin_amdgcn_fdot2(h1, h1, nrm[pf], false);
                 nrm[pf] = __builtin_amdgcn_fdot2(h2, h2, nrm[pf], false);
                 nrm[pf] = __builtin_amdgcn_fdot2(h3, h3, nrm[pf], false);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -262,6 +262,9 @@ class Contriever(nn.Module):
                                                  n, seq, out.data_ptr(), out_rows.data_ptr() if out_rows is not None else None,
                                                  self._ws.data_ptr(), self._ws.numel(), stream),
                    "atlas_contriever_embed")
+        # the kernel wrote through a raw pointer: tell torch (an empty in-place op bumps the version counter that `out` shares with the
+        # tensor it is a view of -- HipDistributedIndex trusts its measured row-norm bound only while that counter stands still)
+        out[:0].zero_()
         return out
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,

@@ -125,8 +125,10 @@ def main():
     def step(ev=None):
         eb = ev[0].cuda_event if ev else None
         ee = ev[1].cuda_event if ev else None
-        rc = L.atlas_scan_topk_ex(q.data_ptr(), _lib.DT_F32, slab.data_ptr(), rows, B, D, k, pmax, out_s.data_ptr(),
-                                  out_i.data_ptr(), out_st.data_ptr(), ws.data_ptr(), ws.numel(), stream, eb, ee)
+        # the call of HipDistributedIndex._local_topk: pmax was measured by the product call above (atlas_slab_pmax) and nothing has
+        # written to the slab since, so the scan takes it as certified (ATLAS_SCAN_TRUST_PMAX) instead of re-measuring every row's norm
+        rc = L.atlas_scan_topk_flags(q.data_ptr(), _lib.DT_F32, slab.data_ptr(), rows, B, D, k, pmax, out_s.data_ptr(),
+                                     out_i.data_ptr(), out_st.data_ptr(), ws.data_ptr(), ws.numel(), stream, eb, ee, _lib.SCAN_TRUST_PMAX)
         assert rc == 0, rc
         if world > 1:
             rc = L.atlas_pack_candidates(out_s.data_ptr(), out_i.data_ptr(), B * k, world, rank, packed.data_ptr(), stream)
@@ -232,9 +234,9 @@ def main():
                 a.record(); b_.record()
 
             def sub_step(ev=None):
-                rc = L.atlas_scan_topk_ex(q.data_ptr(), _lib.DT_F32, slab.data_ptr(), n_sub, B, D, k, pm_s, out_s.data_ptr(),
-                                          out_i.data_ptr(), out_st.data_ptr(), ws_s.data_ptr(), ws_s.numel(), stream,
-                                          ev[0].cuda_event if ev else None, ev[1].cuda_event if ev else None)
+                rc = L.atlas_scan_topk_flags(q.data_ptr(), _lib.DT_F32, slab.data_ptr(), n_sub, B, D, k, pm_s, out_s.data_ptr(),
+                                             out_i.data_ptr(), out_st.data_ptr(), ws_s.data_ptr(), ws_s.numel(), stream,
+                                             ev[0].cuda_event if ev else None, ev[1].cuda_event if ev else None, _lib.SCAN_TRUST_PMAX)
                 assert rc == 0, rc
 
             for _ in range(max(args.warmup, 5)):
@@ -420,6 +422,8 @@ def main():
                 "search_knn_queries_per_s": (B / (knn_ms * 1e-3)) if knn_ms else None, "candidates_per_search": stats0.get("candidates"),
                 "rescored_per_search": stats0.get("rescored"), "max_err_over_eps": stats0.get("max_err_over_eps"),
                 "build": L.atlas_build_info().decode(),
+                "pmax": {"value": pmax, "how": "atlas_slab_pmax once per state of the slab (torch version counter); the timed scans take it as certified "
+                                               "(ATLAS_SCAN_TRUST_PMAX), as HipDistributedIndex does", "trusted_by_product_call": bool(stats0.get("pmax_trusted"))},
             },
         }
         print(json.dumps(line), flush=True)

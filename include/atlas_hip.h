@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ATLAS_ABI_VERSION 5
+#define ATLAS_ABI_VERSION 6
 
 #define ATLAS_WS_STATE_BYTES (1u << 20)   /* head of a scan workspace that must be zero before the workspace's first use */
 
@@ -85,7 +85,10 @@ const char* atlas_build_info(void);          /* "gfx950 <compile date> ..." */
  *   k          neighbours per query; rows beyond min(k,N) are filled with (-inf, -1)
  *   pmax_hint  upper bound on the L2 norm of any slab row (the certified error margin
  *              scales with it); if a larger row is met, ATLAS_F_PMAX_VIOLATION is raised
- *              and the measured maximum is reported so the caller can re-run once
+ *              and the measured maximum is reported so the caller can re-run once. Measuring every row's norm inside
+ *              the scan is not free (4 v_dot2 per MFMA: 4.6 % of the scan time on a power-limited MI355X): a caller that KNOWS
+ *              its bound -- atlas_slab_pmax() taken after the last write to the slab -- passes ATLAS_SCAN_TRUST_PMAX to
+ *              atlas_scan_topk_flags() and the scan takes pmax_hint as certified (ATLAS_ST_PMAX_BITS then reads 0)
  *   out_score  [B x k] fp16, canonical scores, descending
  *   out_idx    [B x k] int64 shard-local passage rows (same meaning as torch.topk indices)
  *   out_status int32[ATLAS_STATUS_HEADER + B]
@@ -118,6 +121,13 @@ int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t
                        int k, float pmax_hint, void* out_score_f16, int64_t* out_idx,
                        int32_t* out_status, void* ws, size_t ws_bytes, void* stream,
                        void* ev_scan_begin, void* ev_scan_end);
+/* The same call with `flags` (0 = atlas_scan_topk_ex):
+ *   ATLAS_SCAN_TRUST_PMAX   pmax_hint is a certified upper bound of the row norms: no re-measurement, no ATLAS_F_PMAX_VIOLATION */
+#define ATLAS_SCAN_TRUST_PMAX 1
+int atlas_scan_topk_flags(const void* q, int q_dtype, const void* slab_f16, int64_t N, int B, int d,
+                       int k, float pmax_hint, void* out_score_f16, int64_t* out_idx,
+                       int32_t* out_status, void* ws, size_t ws_bytes, void* stream,
+                       void* ev_scan_begin, void* ev_scan_end, int flags);
 
 /* ---- search: exact reference-order path (any d, any k <= 2048) --------------------
  * Same contract and same canonical result as atlas_scan_topk, computed without MFMA:

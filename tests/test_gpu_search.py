@@ -126,7 +126,52 @@ def test_large_norm_row_triggers_recertification(gpu_index_cls, oracle_mod):
     s, i = _search(idx, Q, 10)
     es, ei = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, 10)
     parity.assert_identical(s, i, es, ei, "after big row")
-    assert idx.last_search_stats["reruns"] == 1 and idx._pmax > 10 * p_before
+    # the write went through torch (atlas.py:79's slice assignment): the version counter moved, the bound was measured again before
+    # the scan (no violation / re-run protocol needed), and the scan trusted it
+    st = idx.last_search_stats
+    assert st["reruns"] == 0 and st["pmax_trusted"] and idx._pmax > 10 * p_before
+    # a writer torch does not see (raw pointer): the stale bound is trusted until invalidate_pmax() -- the documented contract
+    v = idx._slab_version()
+    idx.invalidate_pmax()
+    _search(idx, Q, 10)
+    assert idx._pmax_version == v and idx.last_search_stats["pmax_trusted"]
+
+
+def test_certifying_and_trusting_scans_agree_and_the_certifying_one_notices_a_large_row(gpu_index_cls):
+    """the two modes of the C-ABI (atlas_scan_topk = certifying: measures every row's norm, reports a violation of pmax_hint;
+    atlas_scan_topk_flags + ATLAS_SCAN_TRUST_PMAX: takes the bound as certified): same ids and score bits; a too-small hint raises
+    ATLAS_F_PMAX_VIOLATION with the measured maximum in the certifying call only"""
+    from atlas_amd import _lib
+
+    L = _lib.lib()
+    N, B, k = 300_000, 64, 40
+    g = torch.Generator(device="cuda").manual_seed(5)
+    slab = torch.randn((N, 768), generator=g, device="cuda")
+    slab = (slab / slab.norm(dim=1, keepdim=True)).half()
+    q = torch.randn((B, 768), generator=g, device="cuda")
+    outs = {}
+    for name, fn, extra in (("certify", L.atlas_scan_topk, ()), ("trust", L.atlas_scan_topk_flags, (None, None, _lib.SCAN_TRUST_PMAX))):
+        ws = torch.zeros(int(L.atlas_scan_topk_workspace_bytes(N, B, 768, k)), dtype=torch.uint8, device="cuda")
+        o_s = torch.empty((B, k), dtype=torch.float16, device="cuda"); o_i = torch.empty((B, k), dtype=torch.int64, device="cuda")
+        o_st = torch.zeros(_lib.STATUS_HEADER + B, dtype=torch.int32, device="cuda")
+        assert fn(q.data_ptr(), _lib.DT_F32, slab.data_ptr(), N, B, 768, k, 1.002, o_s.data_ptr(), o_i.data_ptr(), o_st.data_ptr(),
+                  ws.data_ptr(), ws.numel(), None, *extra) == 0
+        torch.cuda.synchronize()
+        outs[name] = (o_s.clone(), o_i.clone(), o_st.cpu().numpy().copy())
+    assert torch.equal(outs["certify"][0], outs["trust"][0]) and torch.equal(outs["certify"][1], outs["trust"][1])
+    assert int(outs["certify"][2][_lib.ST_FLAGS]) == 0 and int(outs["trust"][2][_lib.ST_FLAGS]) == 0
+    measured = float(outs["certify"][2][_lib.ST_PMAX_BITS:_lib.ST_PMAX_BITS + 1].view(np.float32)[0])
+    assert 0.99 < measured < 1.01 and int(outs["trust"][2][_lib.ST_PMAX_BITS]) == 0
+    # a hint below the true maximum: only the certifying scan can tell
+    ws = torch.zeros(int(L.atlas_scan_topk_workspace_bytes(N, B, 768, k)), dtype=torch.uint8, device="cuda")
+    o_s = torch.empty((B, k), dtype=torch.float16, device="cuda"); o_i = torch.empty((B, k), dtype=torch.int64, device="cuda")
+    o_st = torch.zeros(_lib.STATUS_HEADER + B, dtype=torch.int32, device="cuda")
+    assert L.atlas_scan_topk(q.data_ptr(), _lib.DT_F32, slab.data_ptr(), N, B, 768, k, 0.5, o_s.data_ptr(), o_i.data_ptr(), o_st.data_ptr(),
+                             ws.data_ptr(), ws.numel(), None) == 0
+    st = o_st.cpu().numpy()
+    assert int(st[_lib.ST_FLAGS]) & _lib.F_PMAX_VIOLATION and 0.99 < float(st[_lib.ST_PMAX_BITS:_lib.ST_PMAX_BITS + 1].view(np.float32)[0]) < 1.01
+    assert L.atlas_scan_topk_flags(q.data_ptr(), _lib.DT_F32, slab.data_ptr(), N, B, 768, k, 1.0, o_s.data_ptr(), o_i.data_ptr(), o_st.data_ptr(),
+                                   ws.data_ptr(), ws.numel(), None, None, None, 2) == _lib.E_BADARG
 
 
 @pytest.mark.parametrize("d,k", [(96, 300), (768, 1000), (1000, 10)])
