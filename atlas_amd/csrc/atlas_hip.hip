@@ -675,6 +675,48 @@ slab_pmax_kernel(const uint16_t* __restrict__ slab, int64_t N, int d, uint32_t* 
     if (lane == 0 && best > 0.f) atomicMax(out_bits, f32_bits(sqrtf(best * 1.002f)));   // >= what the scan will measure
 }
 
+// d == 768: a wave takes TWO rows per step with three 16-byte loads per lane (3072 contiguous bytes: row A | row B; the middle load
+// is split between them at lane 32), up to four steps in flight. Streams at the scan's rate instead of the 2-byte loads' 1.7 TB/s:
+// HipDistributedIndex runs this pass once per state of the slab before it lets the scan trust the bound.
+__global__ void __launch_bounds__(256)
+slab_pmax768_kernel(const uint16_t* __restrict__ slab, int64_t N, uint32_t* __restrict__ out_bits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    const int64_t npairs = (N + 1) / 2;
+    auto sumsq = [](const uint4 v) {
+        float s = 0.f;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const f16x2 h = __builtin_bit_cast(f16x2, w[i]); s = __builtin_amdgcn_fdot2(h, h, s, false); }
+        return s;
+    };
+    float best = 0.f;
+    constexpr int U = 4;
+    for (int64_t p0 = wave * U; p0 < npairs; p0 += nwaves * U) {
+        uint4 v[U][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t pr = p0 + u < npairs ? p0 + u : npairs - 1;             // clamped: loads stay unconditional
+            const uint4* base = (const uint4*)(slab + (size_t)pr * 2 * D_FAST);
+            const bool has_b = 2 * pr + 1 < N;                                     // an odd N: the last pair has no second row
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int c = j * 64 + lane;                                       // 16-byte chunk of the pair; chunks >= 96 are row B
+                v[u][j] = (c < 96 || has_b) ? base[c] : make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float s0 = sumsq(v[u][0]), s1 = sumsq(v[u][1]), s2 = sumsq(v[u][2]);
+            float a = s0 + (lane < 32 ? s1 : 0.f), b = (lane < 32 ? 0.f : s1) + s2;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+            best = fmaxf(best, fmaxf(a, b));
+        }
+    }
+    if (lane == 0 && best > 0.f) atomicMax(out_bits, f32_bits(sqrtf(best * 1.002f)));   // >= what the scan will measure
+}
+
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
@@ -1080,8 +1122,11 @@ int atlas_slab_pmax(const void* slab_f16, int64_t N, int d, float* out_pmax, voi
     if (N == 0) return 0;
     int grid = (int)((N + 3) / 4 > 65536 ? 65536 : (N + 3) / 4);
     if (grid > device_cus() * 16) grid = device_cus() * 16;
-    hipLaunchKernelGGL(slab_pmax_kernel, dim3(grid), dim3(256), 0, stream, (const uint16_t*)slab_f16, N, d,
-                       (uint32_t*)out_pmax);
+    if (d == D_FAST && ((uintptr_t)slab_f16 & 15) == 0)
+        hipLaunchKernelGGL(slab_pmax768_kernel, dim3(device_cus() * 8), dim3(256), 0, stream, (const uint16_t*)slab_f16, N, (uint32_t*)out_pmax);
+    else
+        hipLaunchKernelGGL(slab_pmax_kernel, dim3(grid), dim3(256), 0, stream, (const uint16_t*)slab_f16, N, d,
+                           (uint32_t*)out_pmax);
     return (int)hipGetLastError();
 }
 

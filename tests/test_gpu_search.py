@@ -137,6 +137,31 @@ def test_large_norm_row_triggers_recertification(gpu_index_cls, oracle_mod):
     assert idx._pmax_version == v and idx.last_search_stats["pmax_trusted"]
 
 
+@pytest.mark.parametrize("N", [1, 2, 3, 7, 64, 1001, 4096, 65537])
+def test_slab_pmax_is_a_tight_upper_bound_wherever_the_largest_row_is(N, gpu_index_cls):
+    """the scan TRUSTS this number (ATLAS_SCAN_TRUST_PMAX): it must be >= every row's norm -- first / last row, first / second row of
+    the pairs the d = 768 kernel walks, odd N, a row whose weight sits in the half of the middle load that belongs to it -- and tight
+    (rounded up by 0.1 %), also for a slab that starts at an odd row of a larger tensor and for another d"""
+    g = torch.Generator(device="cuda").manual_seed(N)
+    base = torch.randn((N + 1, 768), generator=g, device="cuda") * 0.03
+    for where in sorted({0, N - 1, N // 2, max(N // 2 - 1, 0), min(1, N - 1)}):
+        for cols in (slice(0, 768), slice(500, 520), slice(760, 768), slice(0, 8)):      # where in the row the weight sits
+            x = base.clone()
+            x[1 + where, cols] = 3.0
+            whole = x.half()
+            slab = whole[1:]                                     # starts 1536 B into the allocation
+            idx = gpu_index_cls()
+            idx._set_slab(slab)
+            true = float(slab.float().norm(dim=1).max())
+            got = idx.slab_pmax()
+            assert true * 0.99999 <= got <= true * 1.0015, (N, where, cols, true, got)
+    other = (torch.randn((N, 96), generator=g, device="cuda")).half()
+    idx = gpu_index_cls()
+    idx._set_slab(other)
+    true = float(other.float().norm(dim=1).max())
+    assert true * 0.99999 <= idx.slab_pmax() <= true * 1.0015
+
+
 def test_certifying_and_trusting_scans_agree_and_the_certifying_one_notices_a_large_row(gpu_index_cls):
     """the two modes of the C-ABI (atlas_scan_topk = certifying: measures every row's norm, reports a violation of pmax_hint;
     atlas_scan_topk_flags + ATLAS_SCAN_TRUST_PMAX: takes the bound as certified): same ids and score bits; a too-small hint raises
