@@ -9,7 +9,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = ["r01/bench_default_32m.json", "r01/bench_4m.json", "r01/bench_1m.json", "r02/bench_default_32m_sessionK.json"]
+LINES = ["r01/bench_default_32m.json", "r01/bench_4m.json", "r01/bench_1m.json", "r02/bench_default_32m_sessionM.json"]
 
 
 @pytest.mark.parametrize("name", LINES)
