@@ -17,7 +17,7 @@
 // launched for the worst case n*L tokens and blocks beyond the packed count T = cu[n] exit immediately.
 //
 // Kernels (T = F16 | BF16 | F32 traits)
-//   count_kernel / pack_kernel   per-passage real-token counts, exclusive scan cu[n+1], tokinfo[t] = (passage, position)
+//   count_kernel / pack_kernel   per-passage real-token counts, exclusive scan cu[n+1], tokinfo[t] = (passage, position | rank << 16)
 //   embed_ln_kernel<T>   word + type (+= position) embeddings, LayerNorm                     (one wave per token)
 //   gemm_pp_kernel<T,EPI>   C[M,N] = A[M,K] . W[N,K]^T + bias on the matrix cores, 256 x 256 tiles, LDS-DMA staging, the
 //                        two waves of a SIMD in opposite read / multiply phases; epilogues: QKV split + V^T | erf GELU |
@@ -179,7 +179,8 @@ count_kernel(const int64_t* __restrict__ mask, int n, int L, int* __restrict__ c
 }
 
 // cu[b] = sum counts[0..b) (every wave sums its own prefix: n is a few thousand at most and counts is L2-resident),
-// tokinfo[cu[b] + rank] = (b, l) for the real tokens of passage b in position order
+// tokinfo[cu[b] + rank] = (b, l | rank << 16) for the real tokens of passage b in position order (l, rank < 512: the rank inside the
+// passage = the token's V^T column rides along, so that an epilogue that needs it does not have to chase cu[passage])
 __global__ void __launch_bounds__(256)
 pack_kernel(const int64_t* __restrict__ mask, int n, int L, const int* __restrict__ counts, int* __restrict__ cu,
             int2* __restrict__ tokinfo) {
@@ -199,7 +200,8 @@ pack_kernel(const int64_t* __restrict__ mask, int n, int L, const int* __restric
         const int l = l0 + lane;
         const bool real = (l < L) && (mask[(size_t)b * L + l] != 0);
         const unsigned long long bal = __ballot(real);
-        if (real) tokinfo[run + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(b, l);
+        const int at = run + __popcll(bal & ((1ull << lane) - 1ull));
+        if (real) tokinfo[at] = make_int2(b, l | ((at - base) << 16));
         run += __popcll(bal);
     }
 }
@@ -215,11 +217,11 @@ embed_ln_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ typ
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= cu[n]) return;
     const int2 ti = tokinfo[t];
-    const size_t src = (size_t)ti.x * L + ti.y;
+    const size_t src = (size_t)ti.x * L + (ti.y & 0xffff);
     int64_t id = ids[src], ty = type_ids ? type_ids[src] : 0;
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);            // never read outside the tables (atlas_hip.h)
     ty = ty < 0 ? 0 : (ty >= type_vocab ? type_vocab - 1 : ty);
-    const int p = ti.y;
+    const int p = ti.y & 0xffff;
     float x[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
@@ -819,6 +821,345 @@ gemm_co_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 }
 
 // ------------------------------------------------------------------------------------------
+// gemm_pt_kernel: the bulk GEMM as a PERSISTENT kernel -- one 8-wave workgroup per CU walks over its share of the 256 x 256 tiles with
+// the ping-pong k-loop of gemm_pp_kernel running straight THROUGH the tile boundaries, and an epilogue that needs no LDS and no barrier.
+// Why (profiles/r01/gemm_fixed_cost.txt): with one launch-scheduled workgroup per tile, everything between two tiles' k-loops was
+// exposed -- workgroup dispatch, the dependent load of the token count, the first LDS-DMA pieces' round trip to L2 / HBM, and a 6 us
+// epilogue that parked the C tile in LDS (it occupies all four stage buffers) behind two barriers: ~10 us per tile whatever its kind,
+// 365 us of a 1 045 us layer with the k-loops switched off. Here
+//   * the LDS-DMA of the next tile's first two k-tiles is issued from inside the current tile's last two iterations (the k index simply
+//     runs on: k-tile g+1 is staged by group A in iteration g, k-tile g+2 by group B), so a tile's first MFMAs find their operands in LDS;
+//   * the C tile leaves STRAIGHT FROM THE ACCUMULATOR REGISTERS as 16-byte stores. A lane of v_mfma_f32_16x16x32 holds 4 consecutive
+//     MFMA rows of one MFMA column per fragment; which weight row an MFMA row IS, is decided by the LDS-DMA source address alone. The
+//     weight rows are therefore staged permuted -- LDS row 16 a + i of a wave's 128 holds weight row 32 (a >> 1) + 8 (i >> 2) + 4 (a & 1)
+//     + (i & 3) -- which makes the lane's registers of a fragment pair (2 j, 2 j + 1) 8 CONSECUTIVE output columns 32 j + 8 lg .. + 7 of
+//     token lr: one dwordx4 store, a wave instruction = 16 tokens x 64 contiguous bytes. LDS addresses, swizzle and the k order of every
+//     element are those of gemm_pp_kernel (bit-identical results); only the row the DMA fetches differs;
+//   * V tiles of the QKV projection swap the MFMA operands (activations as the A operand: the same products summed in the same order)
+//     and permute the staged TOKEN rows instead, so a lane holds 8 consecutive keys of one V^T row: again one 16-byte store;
+//   * group A runs its epilogue while group B multiplies the tile's last k-tile, group B while group A multiplies the next tile's first;
+//     epilogue stores are issued behind the wave's last wait of the iteration, so the next k-tiles never wait for them;
+//   * operands go through buffer descriptors (one per tile, in SGPRs): rows past the token count read as nothing and are dropped on
+//     store by the hardware bounds check, and a lane's address state is 4 VGPRs for the whole kernel.
+// Tile order as in the launch-per-tile kernels: token tile t belongs to XCD t % 8 (workgroup b runs on XCD b % 8: speed only), whose
+// 32 workgroups walk its (token tile, column tile) pairs in order, so one token tile's column tiles run side by side on one L2.
+// ------------------------------------------------------------------------------------------
+typedef unsigned int pt_u4 __attribute__((ext_vector_type(4)));
+// the lane id, recomputed where it is called (volatile: neither hoisted nor merged): what a tile's epilogue derives from the lane is then
+// not carried through the k-loop, which has no register to spare (every value kept alive across it ended up in scratch)
+static __device__ __forceinline__ int pt_fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+template <class T> static __device__ __forceinline__ uint32_t pack2(const float a, const float b) {       // two values -> one word of the model dtype (RNE)
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    if constexpr (T::DT == ATLAS_DT_F16) {
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector((f2v){a, b}, h2v));                     // v_cvt_pk_f16_f32
+    } else {
+        typedef __bf16 b2v __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector((f2v){a, b}, b2v));                     // v_cvt_pk_bf16_f32
+    }
+}
+
+// acc -> global memory for one wave. EPI 1 | 2 | 3 (plain, the q | k columns of the QKV projection): acc[a][b][r] = C[token 16 b + lr]
+// [column 32 (a >> 1) + 8 lg + 4 (a & 1) + r] of the wave's 128 x 64; EPI 4 (the V columns, stored transposed): acc[a][b][r] =
+// C[token 32 (b >> 1) + 8 lg + 4 (b & 1) + r][column 16 a + lr]. Rounding points are those of gemm_epilogue: dt(acc + bias), then [gelu] /
+// [+ residual] on that, rounded by the store.
+//   cbuf: descriptor of C's rows [m0, M) (stores past M fall out of bounds);  rv: the residual pieces of EPI 2, same addressing;
+//   bq: the lane's bias values -- EPI 1-3: 8 consecutive columns per fragment pair j (packed); EPI 4: word a = bias of column 16 a + lr
+//   tki (EPI 4): tokinfo of the first and the last token of the lane's two runs of 8 (run jj: tki[2 jj], tki[2 jj + 1]; clamped to M - 1)
+template <class T, int EPI>
+static __device__ __forceinline__ void pt_epilogue(const f4 (&acc)[8][4], const pt_u4 (&bq)[4], const pt_u4 (&rv)[16], const int2 (&tki)[4],
+                                                   const __amdgpu_buffer_rsrc_t cbuf,
+                                                   const int64_t m0, const int n0, const int wi, const int wj,
+                                                   const int64_t M, const int N, uint16_t* __restrict__ VT, const int2* __restrict__ tokinfo, const int Lp) {
+    const int lane = pt_fresh_lane(), lr = lane & 15, lg = lane >> 4;
+    if constexpr (EPI != 4) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t vo = (uint32_t)(((wj * 64 + b * 16 + lr) * N + n0 + wi * 128 + 8 * lg) * 2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pt_u4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {                           // columns 2 e, 2 e + 1 of the lane's eight
+                    const f4 s = acc[2 * j + (e >> 1)][b];
+                    const uint32_t bw = bq[j][e], rw = rv[b * 4 + j][e];
+                    float v0 = ((e & 1) ? s[2] : s[0]) + T::ld((uint16_t)(bw & 0xffff));
+                    float v1 = ((e & 1) ? s[3] : s[1]) + T::ld((uint16_t)(bw >> 16));
+                    if (EPI == 1) {                                     // erf GELU in fp32 on the Linear output in the model dtype (common.h)
+                        const gelu_f2 g = gelu_erf_poly2((gelu_f2){T::rnd(v0), T::rnd(v1)});
+                        v0 = g.x; v1 = g.y;
+                    }
+                    if (EPI == 2) {                                     // + input_tensor
+                        v0 = T::rnd(v0) + T::ld((uint16_t)(rw & 0xffff));
+                        v1 = T::rnd(v1) + T::ld((uint16_t)(rw >> 16));
+                    }
+                    o[e] = pack2<T>(v0, v1);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(o, cbuf, (int)vo, 64 * j, 0);
+            }
+        }
+    } else {
+        // V^T[passage][h*64+d][rank in passage]: the lane's 8 consecutive tokens of a fragment pair are one 16-byte run of keys when they
+        // lie in ONE passage at a key offset that is a multiple of 8 (fixed-length batches: always); ragged batches fall back to
+        // narrower stores, and the few groups that straddle two passages (or the end of the batch) go out token by token
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int64_t tok0 = m0 + wj * 64 + 32 * jj + 8 * lg;
+            int64_t off0 = 0;
+            int mode = 3;            // 0: one 16-byte store | 1: four 4-byte stores (key offset even) | 2: 2 + 3 x 4 + 2 bytes (odd) | 3: per token
+            if (tok0 + 7 < M) {
+                const int2 t0 = tki[2 * jj], t7 = tki[2 * jj + 1];
+                const int pos0 = t0.y >> 16;
+                off0 = (int64_t)t0.x * HID * Lp + pos0;
+                if (t0.x == t7.x) mode = ((pos0 & 7) == 0) ? 0 : ((pos0 & 1) == 0) ? 1 : 2;
+            }
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const float bv = T::ld((uint16_t)(bq[a >> 1][(a & 1) * 2] & 0xffff));     // (words 0 and 2 of bq[a >> 1]: see the loads)
+                const f4 s0 = acc[a][2 * jj], s1 = acc[a][2 * jj + 1];
+                const uint4 v = make_uint4(pack2<T>(s0[0] + bv, s0[1] + bv), pack2<T>(s0[2] + bv, s0[3] + bv),
+                                           pack2<T>(s1[0] + bv, s1[1] + bv), pack2<T>(s1[2] + bv, s1[3] + bv));
+                const int64_t crow = (int64_t)(n0 + wi * 128 + a * 16 + lr) * Lp;
+                uint16_t* dst = VT + off0 + crow;
+                if (mode == 0) {
+                    *(uint4*)dst = v;
+                } else if (mode == 1) {
+                    ((uint32_t*)dst)[0] = v.x; ((uint32_t*)dst)[1] = v.y; ((uint32_t*)dst)[2] = v.z; ((uint32_t*)dst)[3] = v.w;
+                } else if (mode == 2) {
+                    dst[0] = (uint16_t)v.x;
+                    ((uint32_t*)(dst + 1))[0] = (v.x >> 16) | (v.y << 16);
+                    ((uint32_t*)(dst + 1))[1] = (v.y >> 16) | (v.z << 16);
+                    ((uint32_t*)(dst + 1))[2] = (v.z >> 16) | (v.w << 16);
+                    dst[7] = (uint16_t)(v.w >> 16);
+                } else {
+                    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll 1
+                    for (int e = 0; e < 8; ++e)
+                        if (tok0 + e < M) {
+                            const int2 t = tokinfo[tok0 + e];
+                            VT[(int64_t)t.x * HID * Lp + (t.y >> 16) + crow] = (uint16_t)(w4[e >> 1] >> ((e & 1) * 16));
+                        }
+                }
+            }
+        }
+    }
+}
+
+// EPI 1: C = dt(gelu(dt(acc + bias)))   2: C = dt(dt(acc + bias) + R)   3: C = dt(acc + bias)   4: V^T = dt(acc + bias), transposed per passage
+// (the QKV projection is two launches: its q | k columns with EPI 3 into [M, 1536], its v columns with EPI 4 into V^T)
+template <class T, int EPI>
+__global__ void __launch_bounds__(512)
+gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* __restrict__ W, const typename T::elem* __restrict__ bias,
+               const typename T::elem* __restrict__ R, typename T::elem* __restrict__ C, typename T::elem* __restrict__ VT,
+               const int* __restrict__ cu, int n, const int2* __restrict__ tokinfo, int N, int K, int Lp,
+               int diag /* tuning only (ATLAS_GEMM_DIAG): 1 = no epilogue; 0 in production */) {
+    typedef typename T::elem E;
+    static_assert(sizeof(E) == 2, "16-bit dtypes only");
+    constexpr int FA = 8, FB = 4;
+    constexpr bool VTR = (EPI == 4);                                 // V tile: token rows staged permuted, MFMA operands swapped
+    constexpr uint32_t STG = 256 * 128;                              // bytes per operand stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // W0 | W1 | A0 | A1, 32 KiB each
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 2, wj = wave & 3;
+    const bool grpB = wave >= 4;
+    const int64_t M = cu[n];
+    const int ncol = N >> 8;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int ntt = (int)((M + 255) >> 8);
+    const int njobs = (ntt > xcd ? (ntt - xcd + 7) >> 3 : 0) * ncol;        // (token tile, column tile) pairs of this XCD
+    if (slot >= njobs) return;
+    const int nk = K >> 6;                                                    // k-tiles of 128 bytes per tile (>= 2)
+    const uint32_t K2 = (uint32_t)K * 2u;
+
+    // tile j of this XCD: column tile j % ncol of token tile (j / ncol) * 8 + xcd. Operands go through buffer descriptors: W rows
+    // [n0, n0 + 256) and rows [m0, M) of the activations / the output / the residual (all SGPR arithmetic, redone where it is needed
+    // rather than carried: the kernel has no scalar registers to spare)
+    auto tile_n0 = [&](const int j) { return (j % ncol) << 8; };
+    auto tile_m0 = [&](const int j) { return (int64_t)((j / ncol) * 8 + xcd) << 8; };
+    auto rows_rsrc = [&](const E* base, const int64_t m0, const int ld) {      // rows [m0, M) of a [M, ld] tensor
+        int64_t rem = (M - m0) * (int64_t)ld * 2;
+        if (rem > 0xfffffff0ll) rem = 0xfffffff0ll;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)m0 * ld), 0, (int)rem, 0x00020000);
+    };
+
+    // LDS-DMA: a wave instruction writes 8 LDS rows x 128 B, lane-linear; wave w stages LDS rows 32 w + 8 i + (lane >> 3), i = 0..3, of
+    // both operands. The bank swizzle goes on the SOURCE chunk (as in gemm_bt_kernel), and so does the row permutation (header):
+    //   identity      source row = LDS row                                                                           (piece i: + 8 i)
+    //   permuted W    128-row groups: 32 (w & 3) + 16 (i & 1) + 8 (lane >> 5) + 4 (i >> 1) + ((lane >> 3) & 3)      [EPI 1, 2, 3]
+    //   permuted A     64-row groups: 32 (w & 1) + 16 (i & 1) + 8 (lane >> 5) + 4 (i >> 1) + ((lane >> 3) & 3)      [EPI 4]
+    // The activation offsets are complete in the bounds-checked voffset (rows past M are not fetched); weight rows are always there,
+    // so their piece offset rides in the scalar offset.
+    const uint32_t chb = (uint32_t)(((lane & 7) ^ (lane >> 3)) * 16);
+    const uint32_t perm_lane = (uint32_t)(8 * (lane >> 5) + ((lane >> 3) & 3));
+    const uint32_t vw = VTR ? (uint32_t)(wave * 32 + (lane >> 3)) * K2 + chb
+                            : ((uint32_t)(128 * (wave >> 2) + 32 * (wave & 3)) + perm_lane) * K2 + chb;
+    const uint32_t va = VTR ? ((uint32_t)(64 * (wave >> 1) + 32 * (wave & 1)) + perm_lane) * K2 + chb
+                            : (uint32_t)(wave * 32 + (lane >> 3)) * K2 + chb;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto stage = [&](const int buf, const int j, const int kt) {       // k-tile kt of tile j -> stage buffer buf
+        const uint32_t kb = (uint32_t)kt * 128u;
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)tile_n0(j) * K), 0, (int)(256u * K2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ra = rows_rsrc(A, tile_m0(j), K);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t rw_ = (uint32_t)(VTR ? 8 * i : 16 * (i & 1) + 4 * (i >> 1)) * K2;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem_raw + buf * STG + (wave * 32 + i * 8) * 128), 16, (int)vw, (int)(rw_ + kb), 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t ra_ = (uint32_t)(VTR ? 16 * (i & 1) + 4 * (i >> 1) : 8 * i) * K2;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(smem_raw + 2 * STG + buf * STG + (wave * 32 + i * 8) * 128), 16, (int)(va + ra_), (int)kb, 0, 0);
+        }
+    };
+
+    // LDS byte addresses of this lane's fragment chunks (fragment a / b adds a * 2048: rows 16 apart keep row & 7)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+    const int lr0 = lane & 15, lg0 = lane >> 4;
+    const uint32_t aw0 = lds0 + (wi * 128 + lr0) * 128 + ((0 + lg0) ^ (lr0 & 7)) * 16;
+    const uint32_t aw1 = lds0 + (wi * 128 + lr0) * 128 + ((4 + lg0) ^ (lr0 & 7)) * 16;
+    const uint32_t aa0 = lds0 + 2 * STG + (wj * 64 + lr0) * 128 + ((0 + lg0) ^ (lr0 & 7)) * 16;
+    const uint32_t aa1 = lds0 + 2 * STG + (wj * 64 + lr0) * 128 + ((4 + lg0) ^ (lr0 & 7)) * 16;
+
+    f4 acc[FA][FB];
+#pragma unroll
+    for (int a = 0; a < FA; ++a)
+#pragma unroll
+        for (int b = 0; b < FB; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    int jc = slot;                                     // the tile being multiplied; the next one is jc + nslots
+    stage(0, jc, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's pieces of k-tile 0 have landed
+    __builtin_amdgcn_s_barrier();
+    if (grpB) {                                        // B's phase 0: nothing to multiply yet
+        stage(1, jc, 1);
+        __builtin_amdgcn_s_barrier();
+    }
+    int buf = 0;
+    bool skip_wait = false;                            // B: its wait of a tile's first iteration was taken before the epilogue
+    pt_u4 rv[16], bq[4];
+    int2 tki[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rv[i] = (pt_u4){0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tki[i] = make_int2(0, 0);
+
+    // One iteration = one k-tile; phases as in gemm_pp_kernel. The k-tiles staged here (one and two steps on) may be the next tile's.
+    auto iteration = [&](const int kt, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const bool has_next = jc + nslots < njobs;
+        u4v fw0[FA], fa0[FB], fw1[FA], fa1[FB];
+        {
+            const uint32_t w0 = aw0 + buf * STG, w1 = aw1 + buf * STG, a0 = aa0 + buf * STG, a1 = aa1 + buf * STG;
+            asm volatile(
+                "ds_read_b128 %0, %24\n ds_read_b128 %1, %24 offset:2048\n ds_read_b128 %2, %24 offset:4096\n ds_read_b128 %3, %24 offset:6144\n"
+                "ds_read_b128 %4, %24 offset:8192\n ds_read_b128 %5, %24 offset:10240\n ds_read_b128 %6, %24 offset:12288\n ds_read_b128 %7, %24 offset:14336\n"
+                "ds_read_b128 %8, %25\n ds_read_b128 %9, %25 offset:2048\n ds_read_b128 %10, %25 offset:4096\n ds_read_b128 %11, %25 offset:6144\n"
+                "ds_read_b128 %12, %26\n ds_read_b128 %13, %26 offset:2048\n ds_read_b128 %14, %26 offset:4096\n ds_read_b128 %15, %26 offset:6144\n"
+                "ds_read_b128 %16, %26 offset:8192\n ds_read_b128 %17, %26 offset:10240\n ds_read_b128 %18, %26 offset:12288\n ds_read_b128 %19, %26 offset:14336\n"
+                "ds_read_b128 %20, %27\n ds_read_b128 %21, %27 offset:2048\n ds_read_b128 %22, %27 offset:4096\n ds_read_b128 %23, %27 offset:6144\n"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(fw0[0]), "=&v"(fw0[1]), "=&v"(fw0[2]), "=&v"(fw0[3]), "=&v"(fw0[4]), "=&v"(fw0[5]), "=&v"(fw0[6]), "=&v"(fw0[7]),
+                  "=&v"(fa0[0]), "=&v"(fa0[1]), "=&v"(fa0[2]), "=&v"(fa0[3]),
+                  "=&v"(fw1[0]), "=&v"(fw1[1]), "=&v"(fw1[2]), "=&v"(fw1[3]), "=&v"(fw1[4]), "=&v"(fw1[5]), "=&v"(fw1[6]), "=&v"(fw1[7]),
+                  "=&v"(fa1[0]), "=&v"(fa1[1]), "=&v"(fa1[2]), "=&v"(fa1[3])
+                : "v"(w0), "v"(a0), "v"(w1), "v"(a1)
+                : "memory");
+        }
+        if (!grpB) {                                   // A stages the k-tile after this one (after its reads: see gemm_pp_kernel)
+            if (!LAST) stage(buf ^ 1, jc, kt + 1);
+            else if (has_next) stage(buf ^ 1, jc + nslots, 0);
+        } else if (!skip_wait) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);        // B: its pieces of the next k-tile (issued a phase ago) have landed
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (grpB) {                                    // B stages two k-tiles on, into the buffer both groups have finished reading
+            if (!LAST) { if (kt + 2 < nk) stage(buf, jc, kt + 2); else if (has_next) stage(buf, jc + nslots, 0); }
+            else if (has_next) stage(buf, jc + nslots, 1);
+        }
+        if constexpr (VTR) {                           // activations as the MFMA A operand: C^T fragments, the same products in the same order
+#pragma unroll
+            for (int a = 0; a < FA; ++a)
+#pragma unroll
+                for (int b = 0; b < FB; ++b) acc[a][b] = T::mma(fa0[b], fw0[a], acc[a][b]);
+#pragma unroll
+            for (int a = 0; a < FA; ++a)
+#pragma unroll
+                for (int b = 0; b < FB; ++b) acc[a][b] = T::mma(fa1[b], fw1[a], acc[a][b]);
+        } else {
+            mma_tile<T, FA, FB>(fw0, fa0, acc);
+            mma_tile<T, FA, FB>(fw1, fa1, acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (LAST) {
+            // what the epilogue adds is requested behind the tile's last MFMAs (the fragment registers are free now) and lands under the
+            // wait / barrier that follows: the lane's bias values and, for EPI 2, its 16 residual pieces
+            const int n0 = tile_n0(jc);
+            const int fl = pt_fresh_lane(), lr = fl & 15, lg = fl >> 4;
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(bias + n0), 0, 512, 0x00020000);
+            if constexpr (EPI != 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bq[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (wi * 128 + 8 * lg) * 2, 64 * j, 0);
+            } else {                                   // column 16 a + lr of the wave's 128: word (a & 1) * 2 of bq[a >> 1], low half
+#pragma unroll
+                for (int a = 0; a < 8; ++a) bq[a >> 1][(a & 1) * 2] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rb, (wi * 128 + a * 16 + lr) * 2, 0, 0);
+                const int64_t mlast = M - 1;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {       // where the lane's two runs of 8 tokens live in V^T (pt_epilogue)
+                    const int64_t tok0 = tile_m0(jc) + wj * 64 + 32 * jj + 8 * lg;
+                    tki[2 * jj] = tokinfo[tok0 < mlast ? tok0 : mlast];
+                    tki[2 * jj + 1] = tokinfo[tok0 + 7 < mlast ? tok0 + 7 : mlast];
+                }
+            }
+            if constexpr (EPI == 2) {
+                const __amdgpu_buffer_rsrc_t rr = rows_rsrc(R, tile_m0(jc), N);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t vo = (uint32_t)(((wj * 64 + b * 16 + lr) * N + n0 + wi * 128 + 8 * lg) * 2);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rv[b * 4 + j] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)vo, 64 * j, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!grpB) __builtin_amdgcn_s_waitcnt(0x0F70); // A: its pieces of the next k-tile have landed (and its epilogue stores, if any, are out)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        buf ^= 1;
+        skip_wait = false;
+    };
+
+    for (;;) {
+#pragma unroll 1
+        for (int kt = 0; kt < nk - 1; ++kt) iteration(kt, std::false_type{});
+        iteration(nk - 1, std::true_type{});
+        // epilogue of this tile: group A right behind its last MFMAs (group B is multiplying the same k-tile), group B behind its own
+        // (group A is multiplying the next tile's first). The stores stay in flight behind the wave's next wait.
+        // group B waits here for its pieces of the next tile's k-tile 1, the bias and the residual (group A did so in front of the barrier:
+        // for it this is a no-op that tells hipcc's wait insertion that nothing is in flight, so the epilogue carries no waits of its own)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (grpB) skip_wait = true;
+        if (!(ATLAS_TUNING && (diag & 1)))
+            pt_epilogue<T, EPI>(acc, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp);
+        else { __builtin_amdgcn_s_waitcnt(0x0F70); if (acc[0][0][0] == 12345.678f) C[0] = 0; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+#pragma unroll
+            for (int b = 0; b < FB; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+        jc += nslots;
+        if (jc >= njobs) break;
+    }
+    if (!grpB) __builtin_amdgcn_s_barrier();           // A matches B's extra barrier
+}
+
+// ------------------------------------------------------------------------------------------
 // The GEMM for SMALL batches (query embedding: tens of tokens per query after packing, <= 4096 token slots): 64 x 64
 // tiles so that a 768-wide GEMM of 1 300 tokens still makes ~250 workgroups, and a DEEP LDS-DMA pipeline. With tiles
 // this small the MFMAs of a k-tile take 130 (16-bit) to 1 000 (fp32) cycles while an LDS-DMA piece needs ~2 000 cycles
@@ -1057,7 +1398,8 @@ gemm_wr_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 
 // GEMM configurations. The encoder picks by worst-case token slots n * L: > 16384 -> 4, > 4096 -> 0, else 3;
 // the tuning build's atlas_tune_set_gemm_cfg(n) forces one (tuning and the bit-equality test: every configuration gives the same bits).
-//   4  gemm_pp_kernel  256 x 256, ping-pong schedule, LDS epilogue          (index refresh; FFN-1 of the 16-bit dtypes goes to 6)
+//   9  gemm_pt_kernel  256 x 256, PERSISTENT ping-pong, register epilogue    (index refresh, 16-bit dtypes: every GEMM)
+//   4  gemm_pp_kernel  256 x 256, ping-pong schedule, LDS epilogue          (fp32 bulk; A/B reference for 9; FFN-1 of the 16-bit dtypes goes to 6)
 //   6  gemm_co_kernel  256 x 128, two co-resident workgroups per CU         (16-bit dtypes; every GEMM when forced)
 //   7  gemm_pp_kernel  for every GEMM                                        (A/B reference for the 4 / 6 split)
 //   2  gemm_bt_kernel  256 x 256, single phase                              (A/B reference for 4)
@@ -1074,6 +1416,12 @@ constexpr int g_gemm_diag = 0;
 constexpr int g_gemm_cfg = -1;
 #endif
 
+static int encoder_device_cus() {     // CU count of the current device, asked every time (an attribute read; no cached state)
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) return 256;
+    return cus;
+}
+
 template <class T, int EPI>
 static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, const typename T::elem* W, const typename T::elem* bias,
                         const typename T::elem* R, typename T::elem* C, typename T::elem* VT, int64_t Mmax, const int* cu, int n,
@@ -1085,6 +1433,24 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
         hipLaunchKernelGGL(kern, dim3((mtiles + 7) / 8 * 8 * (N / bcol)), dim3(nthreads), lds, stream, A, W, bias, R, C, VT,
                            cu, n, tokinfo, N, K, Lp);
     };
+    if (cfg == 9 && sizeof(typename T::elem) != 2) cfg = 4;                 // the persistent kernel serves the 16-bit dtypes
+    if (cfg == 9) {
+        if constexpr (sizeof(typename T::elem) == 2) {
+            // one workgroup per CU, a multiple of 8 so that workgroup b's tiles are those of XCD b % 8; workgroups without a tile exit
+            const unsigned grid = (unsigned)(encoder_device_cus() / 8 * 8);
+            auto go_pt = [&](auto kern, const typename T::elem* Wp, const typename T::elem* bp, int Np) {
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 128 * 1024, stream, A, Wp, bp, R, C, VT, cu, n, tokinfo, Np, K, Lp, g_gemm_diag);
+            };
+            if constexpr (EPI == 3) {        // QKV projection: q | k columns -> [M, 1536], then the v columns -> V^T
+                go_pt(gemm_pt_kernel<T, 3>, W, bias, 2 * HID);
+                go_pt(gemm_pt_kernel<T, 4>, W + (size_t)2 * HID * K, bias + 2 * HID, HID);
+            } else {
+                go_pt(gemm_pt_kernel<T, EPI>, W, bias, N);
+            }
+        }
+        return;
+    }
     if (cfg == 4 && EPI == 1 && sizeof(typename T::elem) == 2) cfg = 6;     // FFN-1: the two-workgroup kernel is 4 % faster there
     if (cfg == 7) cfg = 4;                                                  // 7 = gemm_pp_kernel for every GEMM (A/B)
     if (cfg == 4) {
@@ -1487,7 +1853,7 @@ pool_packed_kernel(const typename T::elem* __restrict__ x, const int* __restrict
     if (mode == ATLAS_POOL_CLS) {
         // last_hidden[:, 0] after masked_fill (retrievers.py:50, 55-56): position 0 is the first packed token if unmasked
         float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (L > 0 && tokinfo[tb].y == 0) load4<T>(base, v);
+        if (L > 0 && (tokinfo[tb].y & 0xffff) == 0) load4<T>(base, v);
         store4<T>((typename T::elem*)out_ + (size_t)ob * HID + threadIdx.x * 4, v);
         return;
     }
@@ -1542,7 +1908,7 @@ int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int
     const unsigned tok_blocks = (unsigned)((M + 3) / 4), pas_blocks = (unsigned)((n + 3) / 4);
     // configuration table: see launch_gemm. Small batches (queries) need more, smaller tiles to cover the 256 CUs: 64 queries
     // x ~20 tokens are 21 x 12 tiles of 64x64 for a 768-wide GEMM
-    const int cfg = g_gemm_cfg >= 0 ? g_gemm_cfg : (M > 16384 ? 4 : (M > 4096 ? 0 : 3));
+    const int cfg = g_gemm_cfg >= 0 ? g_gemm_cfg : (M > 16384 ? 9 : (M > 4096 ? 0 : 3));
     hipLaunchKernelGGL(count_kernel, dim3(pas_blocks), dim3(256), 0, stream, attention_mask, n, L, counts);
     hipLaunchKernelGGL(pack_kernel, dim3(pas_blocks), dim3(256), 0, stream, attention_mask, n, L, counts, cu, tokinfo);
     hipLaunchKernelGGL(embed_ln_kernel<T>, dim3(tok_blocks), dim3(256), 0, stream, input_ids, token_type_ids, L, cu, n, tokinfo,

@@ -183,11 +183,12 @@ def test_fully_masked_passage_gives_nan_like_torch(gpu_index_cls):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
 def test_bulk_gemm_kernels_agree_bit_for_bit(dtype, gpu_index_cls, monkeypatch):
-    """Batches above 16k tokens (the index refresh) run the 256x256 ping-pong GEMM (cfg 4); the other tile shapes serve
-    smaller batches. Every configuration adds the k-products of an output element in the same order, so all of them
-    must give the same bits — which also screens the ping-pong schedule's barriers / DMA waits for races (run twice).
-    One configuration is compared with the torch restatement; ragged lengths make the packed token count end inside a
-    tile."""
+    """Batches above 16k tokens (the index refresh) run the persistent 256x256 ping-pong GEMM (cfg 9; fp32: cfg 4); the
+    other kernels / tile shapes serve smaller batches or are A/B references. Every configuration adds the k-products of an
+    output element in the same order, so all of them must give the same bits — which also screens the ping-pong
+    schedules' barriers / DMA waits, the persistent kernel's row permutations and its register epilogues for races and
+    mix-ups (run twice). One configuration is compared with the torch restatement; ragged lengths make the packed token
+    count end inside a tile and send V^T through its narrow-store paths, the full-length batch through the 16-byte one."""
     from atlas_amd import retrievers
     from oracle.contriever_ref import BertConfigLite, ContrieverRef
 
@@ -203,10 +204,17 @@ def test_bulk_gemm_kernels_agree_bit_for_bit(dtype, gpu_index_cls, monkeypatch):
     from atlas_amd import _lib
     T = _lib.lib(tuning=True)                                 # the tuning build of the same sources can force a configuration
     mine._library = T
+    ids_f, mask_f = _batch(136, 128, seed=32)                # 17 408 slots, every token real: V^T leaves as 16-byte runs of 8 keys
+    mask_f = torch.ones_like(mask_f)
+    ids_f, mask_f = ids_f.cuda(), mask_f.cuda()
+    base_f = mine(ids_f, mask_f)
     try:
-        for cfg in (4, 6, 7, 8, 2, 0, 3):
+        for cfg in (9, 4, 6, 7, 8, 2, 0, 3):
             T.atlas_tune_set_gemm_cfg(cfg)
             assert torch.equal(mine(ids, mask), base), f"cfg {cfg} differs from the product library's default configuration"
+            assert torch.equal(mine(ids, mask), base), f"cfg {cfg}: second run differs"
+            if cfg in (9, 4, 0):
+                assert torch.equal(mine(ids_f, mask_f), base_f), f"cfg {cfg} differs on the full-length batch"
     finally:
         T.atlas_tune_set_gemm_cfg(-1)
         mine._library = None
