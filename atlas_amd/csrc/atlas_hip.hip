@@ -97,6 +97,8 @@ struct MergeParams {
     const uint16_t* slab; int64_t N; int d;
     const void* q; int q_dtype, qbase;  // the queries [.][d] (the caller's, or the fp16 rows of the sample pass): block b converts row qbase + b itself (RNE to fp16 = `.half()`)
     float pmax;                  // eps = GAMMA |q| pmax, as in the scan
+    int pmax_trusted;            // the scan took pmax as certified and measured no norms (ATLAS_SCAN_TRUST_PMAX): every row rescored here is held
+                                 // to it -- a larger one raises ATLAS_F_PMAX_VIOLATION (the caller's certificate was stale)
     const uint2* lists; const uint32_t* list_cnt; const uint32_t* wg_stat; int G, cap;   // the scan's per-(workgroup, query) candidate lists
     int total_cap;               // most candidates a query may bring to the merge (more: exact path)
     uint32_t* epoch;             // per-workspace call counter: block 0 bumps it (the next scan's granule tag)
@@ -145,7 +147,7 @@ merge_rescore_kernel(const MergeParams p) {
     // layout: qs[d] u16 (padded to 16 B) | misc[64] | s_row[SMAX] | s_app[SMAX] | s_key[SMAX] u64 | s_off[MERGE_GMAX + 8] | keys[key_cap]
     uint16_t* qs = (uint16_t*)smem;
     const int qbytes = ((p.d * 2 + 15) / 16) * 16;
-    uint32_t* misc = (uint32_t*)(smem + qbytes);   // [1] kmax [2] kmin [4] maxerr bits [5] nsurv [6] scan flags [7] pmax^2 bits [16..31] wave totals of the offset scan
+    uint32_t* misc = (uint32_t*)(smem + qbytes);   // [1] kmax [2] kmin [4] maxerr bits [5] nsurv [6] scan flags [7] pmax^2 bits [9] largest offending row norm^2 (trusted pmax) [16..31] wave totals of the offset scan
     uint32_t* s_row = misc + 64;
     float* s_app = (float*)(s_row + MERGE_SMAX);
     uint64_t* s_key = (uint64_t*)(s_app + MERGE_SMAX);
@@ -379,12 +381,20 @@ merge_rescore_kernel(const MergeParams p) {
             for (int r = 0; r < R; ++r) {
                 const uint32_t i = i0 + r * NWV;
                 double c = 0.0;
+                float n2 = 0.f;                                            // the row's squared norm (trusted-pmax check)
 #pragma unroll
-                for (int t = 0; t < D_FAST / 64; ++t)
-                    c += (double)(float)__builtin_bit_cast(_Float16, qs[t * 64 + lane]) *
-                         (double)(float)__builtin_bit_cast(_Float16, pv[r][t]);
+                for (int t = 0; t < D_FAST / 64; ++t) {
+                    const float pf = (float)__builtin_bit_cast(_Float16, pv[r][t]);
+                    c += (double)(float)__builtin_bit_cast(_Float16, qs[t * 64 + lane]) * (double)pf;
+                    n2 = __builtin_fmaf(pf, pf, n2);
+                }
 #pragma unroll
                 for (int m = 1; m < 64; m <<= 1) c += __shfl_xor(c, m);   // canonical tree (common.h)
+                if (p.pmax_trusted) {
+#pragma unroll
+                    for (int m = 1; m < 64; m <<= 1) n2 += __shfl_xor(n2, m);
+                    if (lane == 0 && i < nsurv && n2 > p.pmax * p.pmax) atomicMax(&misc[9], f32_bits(n2));   // non-negative floats order like their bits
+                }
                 if (lane == 0 && i < nsurv) {
                     s_key[i] = local_key(f64_to_f16_bits_rto(c), row[r]);
                     const float err = fabsf((float)((double)s_app[i] - c));   // a-posteriori check of the error model
@@ -429,6 +439,10 @@ merge_rescore_kernel(const MergeParams p) {
         // scan-level flags / pmax (idempotent across blocks)
         if (misc[6]) atomicOr((uint32_t*)&p.out_status[ATLAS_ST_FLAGS], misc[6]);
         atomicMax((uint32_t*)&p.out_status[ATLAS_ST_PMAX_BITS], f32_bits(sqrtf(bits_f32(misc[7])) * 1.000001f));
+        if (misc[9]) {           // a rescored row is longer than the bound the caller certified: the pruning margin of this call was too small
+            atomicOr((uint32_t*)&p.out_status[ATLAS_ST_FLAGS], (uint32_t)ATLAS_F_PMAX_VIOLATION);
+            atomicMax((uint32_t*)&p.out_status[ATLAS_ST_PMAX_BITS], f32_bits(sqrtf(bits_f32(misc[9]) * 1.001f)));
+        }
     }
 }
 
@@ -872,13 +886,14 @@ bool scan_plan_supported(const ScanPlan& pl) {
 }
 
 struct ExactPlan { size_t off_qrow, off_qeps, off_state, off_sel, off_keys, total; };
-ExactPlan make_exact_plan(int64_t N, int d, int k) {
+ExactPlan make_exact_plan(int64_t N, int d, int k, int B) {
     ExactPlan e{}; size_t o = 0;
+    const int qb = B < EXACT_QB ? (B > 0 ? B : 1) : EXACT_QB;          // queries of one slab pass: a single fallback query needs one key row, not eight
     e.off_qrow = o;  o += align_up((size_t)QCHUNK * d * 2, 256);
     e.off_qeps = o;  o += 256;
     e.off_state = o; o += align_up((size_t)EXACT_QB * EXACT_STATE_WORDS * 4, 256);
     e.off_sel = o;   o += align_up((size_t)EXACT_QB * k * 8, 256);
-    e.off_keys = o;  o += align_up((size_t)EXACT_QB * (size_t)(N > 0 ? N : 1) * 8, 256);
+    e.off_keys = o;  o += align_up((size_t)qb * (size_t)(N > 0 ? N : 1) * 8, 256);
     e.total = o;
     return e;
 }
@@ -1021,7 +1036,7 @@ int atlas_scan_topk_flags(const void* q, int q_dtype, const void* slab_f16, int6
         if (q0 == 0 && ev_scan_end) (void)hipEventRecord((hipEvent_t)ev_scan_end, stream);
         MergeParams mp{};
         mp.slab = (const uint16_t*)slab_f16; mp.N = N; mp.d = d;
-        mp.q = sp.q; mp.q_dtype = sp.q_dtype; mp.qbase = sp.q0; mp.pmax = pmax_hint;
+        mp.q = sp.q; mp.q_dtype = sp.q_dtype; mp.qbase = sp.q0; mp.pmax = pmax_hint; mp.pmax_trusted = trusted ? 1 : 0;
         mp.lists = sp.lists; mp.list_cnt = sp.list_cnt; mp.wg_stat = sp.wg_stat; mp.G = pl.G; mp.cap = pl.cap;
         mp.total_cap = pl.total_cap; mp.epoch = (uint32_t*)(w + pl.off_epoch); mp.ticket = sp.ticket;
         mp.qflag = sp.qflag; mp.k = k; mp.q0 = q0; mp.key_cap = pl.key_cap;
@@ -1033,9 +1048,8 @@ int atlas_scan_topk_flags(const void* q, int q_dtype, const void* slab_f16, int6
 }
 
 size_t atlas_exact_topk_workspace_bytes(int64_t N, int B, int d, int k) {
-    (void)B;
-    if (N < 0 || d <= 0 || k <= 0) return 0;
-    return make_exact_plan(N, d, k).total;
+    if (N < 0 || d <= 0 || k <= 0 || B <= 0) return 0;
+    return make_exact_plan(N, d, k, B).total;
 }
 
 int atlas_exact_topk(const void* q, int q_dtype, const void* slab_f16, int64_t N, int B, int d, int k,
@@ -1043,7 +1057,7 @@ int atlas_exact_topk(const void* q, int q_dtype, const void* slab_f16, int64_t N
     if (!q || (!slab_f16 && N > 0) || !out_score_f16 || !out_idx || !ws) return ATLAS_E_BADARG;
     if (B <= 0 || k <= 0 || N < 0 || d <= 0 || q_dtype < 0 || q_dtype > 2) return ATLAS_E_BADARG;
     if (k > K_EXACT_MAX || d > 8192 || N >= (int64_t)0xffffffffll) return ATLAS_E_UNSUPPORTED;
-    const ExactPlan pl = make_exact_plan(N, d, k);
+    const ExactPlan pl = make_exact_plan(N, d, k, B);
     if (ws_bytes < pl.total) return ATLAS_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     unsigned char* w = (unsigned char*)ws;

@@ -81,10 +81,17 @@ def _collective_device() -> torch.device:
 
 def exchange_objects(per_dst: list) -> list:
     """Personalised all-to-all of python objects: rank r receives [per_dst[r] of rank 0, ..., of rank W-1]. Two collectives
-    (sizes, then the pickled bytes with uneven splits): every rank gets exactly what was addressed to it, nothing else."""
+    (sizes, then the pickled bytes with uneven splits): every rank gets exactly what was addressed to it, nothing else.
+    ATLAS_EXCHANGE=allgather swaps it for one `all_gather_object` of the whole outbox (W x the bytes, the plainest collective
+    there is): the switch to throw if a backend mishandles uneven or empty all-to-all splits."""
     if not is_initialized():
         return [per_dst[0]]
+    import os
     import pickle
+
+    if os.environ.get("ATLAS_EXCHANGE", "") == "allgather":
+        rank = dist.get_rank()
+        return [outbox[rank] for outbox in all_gather_object(per_dst)]
 
     W, dev = dist.get_world_size(), _collective_device()
     assert len(per_dst) == W

@@ -75,7 +75,12 @@ def merge_packed_host(gathered: np.ndarray, k: int) -> np.ndarray:
 
 
 class HipDistributedIndex(object):
-    def __init__(self):
+    def __init__(self, certify_every: int = 64):
+        """certify_every: every that-many-th search runs the scan that measures every row's norm itself (the C-ABI's default mode,
+        ~5 % slower) instead of trusting the bound taken when the slab last changed -- the net under writers torch's version counter
+        cannot see (`.data`, a numpy / DLPack alias, a raw pointer). 1 = every search certifies, 0 = never (trust the counter alone)."""
+        self.certify_every = int(certify_every)
+        self._since_certified = 0
         self.embeddings = None          # (d, N) fp16 view of the slab, like the reference
         self.doc_map = dict()
         self.is_in_gpu = True
@@ -223,8 +228,10 @@ class HipDistributedIndex(object):
         attr = "_ws_exact" if exact else "_ws"
         ws = getattr(self, attr)
         if ws is None or ws.numel() < nbytes or ws.device != self._slab.device:
-            # zero-filled once: the head of a scan workspace holds state that lives across calls (include/atlas_hip.h)
-            ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=self._slab.device)
+            # a scan workspace is zero-filled once: its head holds state that lives across calls (include/atlas_hip.h); the exact
+            # path's holds nothing between calls (a multi-GiB memset on the first tie-heavy query would be pure cost)
+            alloc = torch.empty if exact else torch.zeros
+            ws = alloc(int(nbytes), dtype=torch.uint8, device=self._slab.device)
             setattr(self, attr, ws)
         return ws
 
@@ -324,6 +331,11 @@ class HipDistributedIndex(object):
             if self._pmax is None or self._pmax_version != version:
                 self._pmax = self.slab_pmax()
                 self._pmax_version = version
+                self._since_certified = 0
+            # ... and every certify_every-th search certifies anyway: a write that went around the counter is found by the scan itself
+            self._since_certified += 1
+            if self.certify_every > 0 and self._since_certified >= self.certify_every:
+                call_flags = 0
         ws = self._workspace(L.atlas_scan_topk_workspace_bytes(N, B, d, k))
         # one output buffer -> one D2H copy: [status int32 | scores fp16 | rows int64]
         n_st = _lib.STATUS_HEADER + B
@@ -335,18 +347,32 @@ class HipDistributedIndex(object):
         base = out.data_ptr()
         reruns = 0
         while True:
-            _lib.check(L.atlas_scan_topk_flags(q.data_ptr(), code, self._slab.data_ptr(), N, B, d, k, float(self._pmax),
-                                               base + off_s, base + off_i, base, ws.data_ptr(), ws.numel(), stream, None, None, call_flags),
-                       "atlas_scan_topk")
+            rc = L.atlas_scan_topk_flags(q.data_ptr(), code, self._slab.data_ptr(), N, B, d, k, float(self._pmax),
+                                         base + off_s, base + off_i, base, ws.data_ptr(), ws.numel(), stream, None, None, call_flags)
+            if rc != 0:
+                # a launch that failed half-way may have left the workspace's per-call state (tile-pool ticket, flags) behind: the
+                # next search starts from a fresh zero-filled one
+                self._ws = None
+            _lib.check(rc, "atlas_scan_topk")
             host = out.cpu().numpy()      # synchronises
             st = host[: n_st * 4].view(np.int32)
             flags = int(st[_lib.ST_FLAGS])
             pmax_seen = float(st[_lib.ST_PMAX_BITS : _lib.ST_PMAX_BITS + 1].view(np.float32)[0])
             if flags & _lib.F_PMAX_VIOLATION and reruns < 2:
-                self._pmax = pmax_seen    # the scan measured the true maximum: certified on the re-run
+                if call_flags & _lib.SCAN_TRUST_PMAX:
+                    # the merge met a rescored row longer than the trusted bound: something wrote to the slab behind torch's back.
+                    # Its norm is only a lower bound of the maximum -- the repeat certifies for itself, from a fresh measurement
+                    logger.warning("a slab row is longer than the certified bound (%.4g > %.4g): the slab was written without a version "
+                                   "bump; re-certifying (see invalidate_pmax)", pmax_seen, self._pmax)
+                    self._pmax = self.slab_pmax()
+                    call_flags = 0
+                else:
+                    self._pmax = pmax_seen    # the scan measured the true maximum: certified on the re-run
                 reruns += 1
                 continue
             break
+        if not (call_flags & _lib.SCAN_TRUST_PMAX):
+            self._since_certified = 0
         if flags & (_lib.F_PMAX_VIOLATION | _lib.F_EPS_VIOLATION):
             raise _lib.AtlasHipError(f"scan could not certify its result (flags={flags}); this is a bug")
         self._pmax = pmax_seen if pmax_seen > 0 else self._pmax

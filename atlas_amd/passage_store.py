@@ -102,6 +102,11 @@ class PassageStore:
                 except (OSError, ValueError):
                     fresh = False
             if not fresh:
+                # the old signature goes FIRST: a crash between here and the new meta file must not leave it next to new content
+                try:
+                    os.remove(meta_path)
+                except OSError:
+                    pass
                 cls.build_from_items(path, make_items())
                 tmp = meta_path + ".tmp%d" % os.getpid()
                 with open(tmp, "w") as f:

@@ -119,6 +119,15 @@ class IndexRefresher:
         return len(store) * repeat
 
 
+def _passages_fingerprint(passages) -> int:
+    """a cheap content fingerprint of a passage list: ids, titles and texts of a few spread entries (first, last, and up to 62 between)"""
+    n = len(passages)
+    if n == 0:
+        return 0
+    picks = sorted({0, n - 1, *range(0, n, max(1, n // 62))})
+    return hash(tuple((passages[i].get("id"), passages[i].get("title"), passages[i].get("text")) for i in picks))
+
+
 @torch.no_grad()
 def build_index_streamed(self, index, passages, gpu_embedder_batch_size, logger=None):
     """`Atlas.build_index` (src/atlas.py:61-88) with the streamed refresh underneath; `self` is the Atlas module
@@ -127,11 +136,14 @@ def build_index_streamed(self, index, passages, gpu_embedder_batch_size, logger=
     First call: tokenises `passages` once into a TokenStore and builds the persistent fp16 mirror of the retriever; every later
     call re-casts the weights in place and streams the stored tokens. Same slab as the reference's loop run on the same encoder."""
     state = index.__dict__.setdefault("_refresh_state", {})
-    if state.get("n") != len(passages) or state.get("passages_id") != id(passages):
+    # the token store is reused while `passages` is the same list with the same content at its ends and in its middle (a list edited
+    # in place keeps its id and, often, its length: the fingerprint is what notices)
+    key = (id(passages), len(passages), _passages_fingerprint(passages))
+    if state.get("passages_key") != key:
         state.clear()
         state["store"] = TokenStore.from_passages(passages, self.retriever_tokenizer, self.opt.retriever_format, self.opt.text_maxlength,
                                                   gpu_embedder_batch_size)
-        state["n"], state["passages_id"] = len(passages), id(passages)
+        state["passages_key"] = key
     if "mirror" not in state:
         state["mirror"] = HalfMirror(self.retriever)
     half = state["mirror"].sync(self.retriever)

@@ -27,13 +27,15 @@ import torch.utils.checkpoint
 
 
 def _layer_norm(ln, x):
-    """the reference's BertLayerNorm (modeling_bert.py:104-114): second moment around ZERO, fp32 statistics, affine in the weight dtype"""
-    mean = x.to(torch.float32).mean(-1, keepdim=True)
-    second = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
-    x = (x - mean) * torch.rsqrt(second + ln.variance_epsilon)
-    if ln.weight.dtype in (torch.float16, torch.bfloat16):
-        x = x.to(ln.weight.dtype)
-    return ln.weight * x + ln.bias
+    """BertLayerNorm as the reference computes it (modeling_bert.py:104-114) -- NOT torch's LayerNorm: the scale is the root of the
+    UNCENTRED second moment, statistics in fp32, the normalised value cast to a 16-bit weight's dtype before the affine step"""
+    x32 = x.float()
+    centred = x - torch.mean(x32, dim=-1, keepdim=True)
+    y = centred * torch.rsqrt(torch.mean(x32.pow(2), dim=-1, keepdim=True) + ln.variance_epsilon)
+    w = ln.weight
+    if w.dtype.itemsize == 2:                      # fp16 / bf16 weights
+        y = y.to(w.dtype)
+    return w * y + ln.bias
 
 
 def _embed(emb, input_ids, token_type_ids):
@@ -88,15 +90,16 @@ def training_forward(model, input_ids, attention_mask, token_type_ids=None, norm
             x = torch.utils.checkpoint.checkpoint(_layer, layer, c.num_attention_heads, x, ext_mask, use_reentrant=False)
         else:
             x = _layer(layer, c.num_attention_heads, x, ext_mask)
-    last_hidden = x.masked_fill(~attention_mask[..., None].bool(), 0.0).clone()
-    if c.pooling == "average":
-        emb = last_hidden.sum(dim=1).clone() / attention_mask.sum(dim=1)[..., None].clone()
-    elif c.pooling == "sqrt":
-        emb = last_hidden.sum(dim=1) / torch.sqrt(attention_mask.sum(dim=1)[..., None].float())
-    elif c.pooling == "cls":
-        emb = last_hidden[:, 0]
-    else:
+    # retrievers.py:49-59: padded positions zeroed, then one of three poolings over the sequence axis
+    if c.pooling not in _POOLINGS:
         raise ValueError(f"pooling={c.pooling!r}: the reference knows 'average', 'sqrt', 'cls' (retrievers.py:51-56)")
-    if normalize:
-        emb = F.normalize(emb, dim=-1).clone()
-    return emb
+    hidden = x.masked_fill(attention_mask.unsqueeze(-1) == 0, 0.0)
+    emb = _POOLINGS[c.pooling](hidden, attention_mask.sum(dim=1, keepdim=True))
+    return F.normalize(emb, dim=-1) if normalize else emb
+
+
+_POOLINGS = {
+    "average": lambda hidden, count: hidden.sum(dim=1) / count,                       # integer count: true division in the sum's dtype
+    "sqrt": lambda hidden, count: hidden.sum(dim=1) / count.float().sqrt(),           # fp32 divisor: promotes
+    "cls": lambda hidden, count: hidden[:, 0],
+}

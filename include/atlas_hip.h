@@ -122,7 +122,10 @@ int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t
                        int32_t* out_status, void* ws, size_t ws_bytes, void* stream,
                        void* ev_scan_begin, void* ev_scan_end);
 /* The same call with `flags` (0 = atlas_scan_topk_ex):
- *   ATLAS_SCAN_TRUST_PMAX   pmax_hint is a certified upper bound of the row norms: no re-measurement, no ATLAS_F_PMAX_VIOLATION */
+ *   ATLAS_SCAN_TRUST_PMAX   pmax_hint is a certified upper bound of the row norms: the scan does not re-measure them. What the call
+ *                           still checks is every row its merge rescans (the candidates that reach the exact rescoring): one longer than
+ *                           pmax_hint raises ATLAS_F_PMAX_VIOLATION with ATLAS_ST_PMAX_BITS = that row's norm -- a LOWER bound of the true
+ *                           maximum; the caller's certificate was stale: take atlas_slab_pmax() again and repeat the call */
 #define ATLAS_SCAN_TRUST_PMAX 1
 int atlas_scan_topk_flags(const void* q, int q_dtype, const void* slab_f16, int64_t N, int B, int d,
                        int k, float pmax_hint, void* out_score_f16, int64_t* out_idx,

@@ -137,6 +137,50 @@ def test_large_norm_row_triggers_recertification(gpu_index_cls, oracle_mod):
     assert idx._pmax_version == v and idx.last_search_stats["pmax_trusted"]
 
 
+def test_writes_behind_the_version_counter_are_caught(gpu_index_cls, oracle_mod):
+    """`index.embeddings.data[...] = x` (or any alias torch does not track) does not move the slab's version counter, so the bound the
+    scan trusts goes stale. Two nets: the merge holds every row it rescans to the trusted bound -- a long row
+    that reaches the top-k candidates raises ATLAS_F_PMAX_VIOLATION and the search re-certifies from a fresh measurement -- and every
+    certify_every-th search runs the certifying scan, which measures every row. A search never returns a result that differs from
+    the oracle's without one of them having fired."""
+    P = synth.passages_f16(30000, 768, 188)
+    Q = synth.queries_f32(8, 768, 189)
+    q16 = oracle_mod.f32_to_f16(Q)
+
+    # (1) a 50x row ALIGNED with query 0, written through .data: it is query 0's best passage, the merge rescans it and notices
+    idx = _index(gpu_index_cls, P)
+    _search(idx, Q, 10)
+    v0, p0 = idx._slab_version(), idx._pmax
+    big = (q16[0].astype(np.float32) / np.linalg.norm(q16[0].astype(np.float32)) * 50).astype(np.float16)
+    idx.embeddings.data[:, 777:778] = torch.from_numpy(big).cuda()[:, None]
+    assert idx._slab_version() == v0                           # torch did not see the write
+    P1 = P.copy(); P1[777] = big
+    s, i = _search(idx, Q, 10)
+    es, ei = oracle_mod.search(q16, P1, 10)
+    parity.assert_identical(s, i, es, ei, "after an untracked aligned write")
+    st = idx.last_search_stats
+    assert i[0, 0] == 777 and st["reruns"] == 1 and not st["pmax_trusted"] and idx._pmax > 10 * p0, st
+
+    # (2) a 50x row ANTI-aligned with every query (never a candidate): only a certifying scan can see it
+    anti = (-(q16.astype(np.float32).sum(axis=0)) / np.linalg.norm(q16.astype(np.float32).sum(axis=0)) * 50).astype(np.float16)
+    for every, expect_rerun_at in ((1, 1), (3, 3)):
+        idx = gpu_index_cls(certify_every=every)
+        idx.init_embeddings([{"id": str(j)} for j in range(P.shape[0])], 768)
+        idx.embeddings[:, :] = torch.from_numpy(P).cuda().T
+        _search(idx, Q, 10)                                    # measures the bound; counts as search 1 of the period
+        idx.embeddings.data[:, 4242:4243] = torch.from_numpy(anti).cuda()[:, None]
+        P2 = P.copy(); P2[4242] = anti
+        es, ei = oracle_mod.search(q16, P2, 10)
+        fired = None
+        for n in range(1, 5):
+            s, i = _search(idx, Q, 10)
+            parity.assert_identical(s, i, es, ei, f"certify_every={every}, search {n} after the write")
+            if idx.last_search_stats["reruns"] and fired is None:
+                fired = n
+        assert fired is not None and fired <= expect_rerun_at, (every, fired)
+        assert idx._pmax > 10 * p0
+
+
 @pytest.mark.parametrize("N", [1, 2, 3, 7, 64, 1001, 4096, 65537])
 def test_slab_pmax_is_a_tight_upper_bound_wherever_the_largest_row_is(N, gpu_index_cls):
     """the scan TRUSTS this number (ATLAS_SCAN_TRUST_PMAX): it must be >= every row's norm -- first / last row, first / second row of
