@@ -25,6 +25,9 @@
 //   gemm_co_kernel<T,EPI>   the same GEMM as two co-resident 4-wave workgroups per CU on 256 x 128 tiles (serves FFN-1)
 //   gemm_bt_kernel<T,EPI,..>  the single-phase version; 128 x 128 and 64 x 64 tiles serve small (query) batches
 //   attention_kernel<T,MAXKF>  per (passage, head): S^T = K.Q^T -> dtype -> /8 -> fp32 softmax -> dtype P -> P.V, P in registers
+// V^T layout: [passage][768][Lp + 8], the key of packed token t of passage b at column (t - cu[b]) + (cu[b] & 7) = t - (cu[b] & ~7): the
+// passage's keys start cu[b] & 7 columns in, so that 8 consecutive PACKED tokens starting at a multiple of 8 (what a GEMM lane holds)
+// are always one 16-byte-aligned run of a row, for ragged batches too; the attention kernel reads its rows from that offset on
 //   attention_f32_kernel the same on v_mfma_f32_16x16x4_f32 for the fp32 model
 //   ln_kernel<T>         the reference's LayerNorm on a [T,768] tensor                     (one wave per token)
 //   pool_packed_kernel<T>  mean over a passage's tokens with the reference's two roundings, row written into the slab
@@ -47,6 +50,8 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));   // 16-byte MFMA operand chunk (see the note on LDS reads in gemm_bt_kernel)
+typedef uint4 __attribute__((aligned(2))) uint4_a2;          // 16-byte global loads at the alignment of their elements (V^T rows of ragged batches)
+typedef uint4 __attribute__((aligned(4))) uint4_a4;
 
 #define HID 768
 #define NHEAD 12
@@ -259,7 +264,7 @@ static __device__ __forceinline__ void gemm_epilogue(f4 (&acc)[FA][FB], int64_t 
         if (tok >= M) continue;
         int64_t pb = 0;
         int pos = 0;                                             // rank of the token inside its passage = V^T column
-        if (EPI == 3 && v_part) { pb = tokinfo[tok].x; pos = (int)(tok - cu[pb]); }
+        if (EPI == 3 && v_part) { pb = tokinfo[tok].x; pos = (int)(tok - (cu[pb] & ~7)); }      // V^T column: rank + (cu[pb] & 7)
 #pragma unroll
         for (int a = 0; a < FA; ++a) {
             const int col = n0 + wi * (FA * 16) + a * 16 + lg * 4;
@@ -434,23 +439,22 @@ static __device__ __forceinline__ void gemm_epilogue_lds(f4 (&acc)[8][4], unsign
     }
     // V tile: where this lane's 8 consecutive tokens (8j .. 8j+7 of the tile, j = lane & 31) live in V^T; requested before the
     // conversion as well. One 16-byte store per column needs them in ONE passage at a key offset that is a multiple of 8.
-    int64_t vt_off = 0;            // element offset of token 8j inside a V^T row block: passage * 768 * Lp + key
-    int vt_mode = 3;               // 0: one 16-byte store | 1: four 4-byte stores (key offset even) | 2: 2 + 3 x 4 + 2 bytes (odd) | 3: per element
+    int64_t vt_off = 0;            // element offset of token 8j inside a V^T row block: passage * 768 * pitch + column
+    int vt_mode = 3;               // 0: one 16-byte store (the 8 tokens are one passage's: always aligned, see the layout note) | 3: per element
     int64_t vt_off8[8];            // mode 3 only (groups that straddle passages / the end of the batch): per-token offsets, -1 = no token
     if (EPI == 3 && v_tile) {
         const int64_t tok0 = m0 + 8 * (lane % OCT);
         if (tok0 + 7 < M) {
             const int pb0 = tokinfo[tok0].x, pb7 = tokinfo[tok0 + 7].x;
-            const int pos0 = (int)(tok0 - cu[pb0]);
-            vt_off = (int64_t)pb0 * HID * Lp + pos0;
-            if (pb0 == pb7) vt_mode = ((pos0 & 7) == 0) ? 0 : ((pos0 & 1) == 0) ? 1 : 2;
+            vt_off = (int64_t)pb0 * HID * Lp + (tok0 - (cu[pb0] & ~7));
+            if (pb0 == pb7) vt_mode = 0;
         }
         if (vt_mode == 3) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int64_t tok = tok0 + e;
                 vt_off8[e] = -1;
-                if (tok < M) { const int64_t pb = tokinfo[tok].x; vt_off8[e] = pb * HID * Lp + (tok - cu[pb]); }
+                if (tok < M) { const int64_t pb = tokinfo[tok].x; vt_off8[e] = pb * HID * Lp + (tok - (cu[pb] & ~7)); }
             }
         }
     }
@@ -533,9 +537,8 @@ static __device__ __forceinline__ void gemm_epilogue_lds(f4 (&acc)[8][4], unsign
             *(uint4*)(C + (size_t)tok * ldc + n0 + 8 * j) = v;
         }
     } else {
-        // V^T[passage][h*64+d][rank in passage]: a lane stores 8 consecutive keys of one column (16 B) where the passage layout
-        // allows it; token groups that straddle passages or start at a key offset that is not a multiple of 8 (ragged batches) go
-        // out as single elements
+        // V^T[passage][h*64+d][column]: a lane stores 8 consecutive keys of one column (16 B, always aligned: layout note at the top);
+        // the token groups that straddle two passages or the end of the batch go out as single elements
 #pragma unroll 4
         for (int it = 0; it < 16; ++it) {
             const int colT = wave * CW + it * CPI + lane / OCT;
@@ -545,14 +548,6 @@ static __device__ __forceinline__ void gemm_epilogue_lds(f4 (&acc)[8][4], unsign
             uint16_t* dst = VT + vt_off + crow;
             if (vt_mode == 0) {
                 *(uint4*)dst = v;
-            } else if (vt_mode == 1) {                       // ragged batch, even key offset: 4-byte aligned
-                ((uint32_t*)dst)[0] = v.x; ((uint32_t*)dst)[1] = v.y; ((uint32_t*)dst)[2] = v.z; ((uint32_t*)dst)[3] = v.w;
-            } else if (vt_mode == 2) {                       // odd key offset: the inner six keys as three aligned words
-                dst[0] = (uint16_t)v.x;
-                ((uint32_t*)(dst + 1))[0] = (v.x >> 16) | (v.y << 16);
-                ((uint32_t*)(dst + 1))[1] = (v.y >> 16) | (v.z << 16);
-                ((uint32_t*)(dst + 1))[2] = (v.z >> 16) | (v.w << 16);
-                dst[7] = (uint16_t)(v.w >> 16);
             } else {
                 const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -870,7 +865,7 @@ template <class T> static __device__ __forceinline__ uint32_t pack2(const float 
 //   cbuf: descriptor of C's rows [m0, M) (stores past M fall out of bounds);  rv: the residual pieces of EPI 2, same addressing;
 //   bq: the lane's bias values -- EPI 1-3: 8 consecutive columns per fragment pair j (packed); EPI 4: word a = bias of column 16 a + lr
 //   tki (EPI 4): tokinfo of the first and the last token of the lane's two runs of 8 (run jj: tki[2 jj], tki[2 jj + 1]; clamped to M - 1)
-template <class T, int EPI>
+template <class T, int EPI, int AUX = 0>      // AUX: cache-policy bits of the C stores (0 = default; tuning builds A/B 2 = nt and 16 = sc1)
 static __device__ __forceinline__ void pt_epilogue(const f4 (&acc)[8][4], const pt_u4 (&bq)[4], const pt_u4 (&rv)[16], const int2 (&tki)[4],
                                                    const __amdgpu_buffer_rsrc_t cbuf,
                                                    const int64_t m0, const int n0, const int wi, const int wj,
@@ -899,24 +894,20 @@ static __device__ __forceinline__ void pt_epilogue(const f4 (&acc)[8][4], const 
                     }
                     o[e] = pack2<T>(v0, v1);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(o, cbuf, (int)vo, 64 * j, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o, cbuf, (int)vo, 64 * j, AUX);
             }
         }
     } else {
-        // V^T[passage][h*64+d][rank in passage]: the lane's 8 consecutive tokens of a fragment pair are one 16-byte run of keys when they
-        // lie in ONE passage at a key offset that is a multiple of 8 (fixed-length batches: always); ragged batches fall back to
-        // narrower stores, and the few groups that straddle two passages (or the end of the batch) go out token by token
+        // V^T[passage][h*64+d][column]: the lane's 8 consecutive tokens of a fragment pair are one aligned 16-byte run of a row whenever
+        // they belong to one passage (layout note at the top of the file), ragged batches included; the few groups that straddle two
+        // passages or the end of the batch go out token by token
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int64_t tok0 = m0 + wj * 64 + 32 * jj + 8 * lg;
-            int64_t off0 = 0;
-            int mode = 3;            // 0: one 16-byte store | 1: four 4-byte stores (key offset even) | 2: 2 + 3 x 4 + 2 bytes (odd) | 3: per token
-            if (tok0 + 7 < M) {
-                const int2 t0 = tki[2 * jj], t7 = tki[2 * jj + 1];
-                const int pos0 = t0.y >> 16;
-                off0 = (int64_t)t0.x * HID * Lp + pos0;
-                if (t0.x == t7.x) mode = ((pos0 & 7) == 0) ? 0 : ((pos0 & 1) == 0) ? 1 : 2;
-            }
+            const int2 t0 = tki[2 * jj], t7 = tki[2 * jj + 1];
+            const bool whole = (tok0 + 7 < M) && (t0.x == t7.x);
+            // column of token tok0 in its passage's rows: tok0 - (cu[passage] & ~7), with cu[passage] = tok0 - rank
+            const int64_t off0 = (int64_t)t0.x * HID * Lp + (tok0 - ((tok0 - (t0.y >> 16)) & ~(int64_t)7));
 #pragma unroll
             for (int a = 0; a < 8; ++a) {
                 const float bv = T::ld((uint16_t)(bq[a >> 1][(a & 1) * 2] & 0xffff));     // (words 0 and 2 of bq[a >> 1]: see the loads)
@@ -924,24 +915,16 @@ static __device__ __forceinline__ void pt_epilogue(const f4 (&acc)[8][4], const 
                 const uint4 v = make_uint4(pack2<T>(s0[0] + bv, s0[1] + bv), pack2<T>(s0[2] + bv, s0[3] + bv),
                                            pack2<T>(s1[0] + bv, s1[1] + bv), pack2<T>(s1[2] + bv, s1[3] + bv));
                 const int64_t crow = (int64_t)(n0 + wi * 128 + a * 16 + lr) * Lp;
-                uint16_t* dst = VT + off0 + crow;
-                if (mode == 0) {
-                    *(uint4*)dst = v;
-                } else if (mode == 1) {
-                    ((uint32_t*)dst)[0] = v.x; ((uint32_t*)dst)[1] = v.y; ((uint32_t*)dst)[2] = v.z; ((uint32_t*)dst)[3] = v.w;
-                } else if (mode == 2) {
-                    dst[0] = (uint16_t)v.x;
-                    ((uint32_t*)(dst + 1))[0] = (v.x >> 16) | (v.y << 16);
-                    ((uint32_t*)(dst + 1))[1] = (v.y >> 16) | (v.z << 16);
-                    ((uint32_t*)(dst + 1))[2] = (v.z >> 16) | (v.w << 16);
-                    dst[7] = (uint16_t)(v.w >> 16);
+                if (whole) {
+                    *(uint4*)(VT + off0 + crow) = v;
                 } else {
                     const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll 1
                     for (int e = 0; e < 8; ++e)
                         if (tok0 + e < M) {
                             const int2 t = tokinfo[tok0 + e];
-                            VT[(int64_t)t.x * HID * Lp + (t.y >> 16) + crow] = (uint16_t)(w4[e >> 1] >> ((e & 1) * 16));
+                            const int64_t tok = tok0 + e;
+                            VT[(int64_t)t.x * HID * Lp + (tok - ((tok - (t.y >> 16)) & ~(int64_t)7)) + crow] = (uint16_t)(w4[e >> 1] >> ((e & 1) * 16));
                         }
                 }
             }
@@ -956,7 +939,7 @@ __global__ void __launch_bounds__(512)
 gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* __restrict__ W, const typename T::elem* __restrict__ bias,
                const typename T::elem* __restrict__ R, typename T::elem* __restrict__ C, typename T::elem* __restrict__ VT,
                const int* __restrict__ cu, int n, const int2* __restrict__ tokinfo, int N, int K, int Lp,
-               int diag /* tuning only (ATLAS_GEMM_DIAG): 1 = no epilogue; 0 in production */) {
+               int diag /* tuning build only: bit 0 = no epilogue, bits 2-3 = store policy (1 nt, 2 sc1), bits 8.. = start stagger; 0 in production */) {
     typedef typename T::elem E;
     static_assert(sizeof(E) == 2, "16-bit dtypes only");
     constexpr int FA = 8, FB = 4;
@@ -1032,6 +1015,12 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         for (int b = 0; b < FB; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
 
     int jc = slot;                                     // the tile being multiplied; the next one is jc + nslots
+#if ATLAS_TUNING
+    if (diag >> 8) {                                   // experiment: workgroups start in four classes, (diag >> 8) x 0.25 us apart (are the CUs' store bursts the epilogue's cost?)
+        const unsigned long long until = wall_clock64() + (unsigned long long)((blockIdx.x >> 3) & 3) * (unsigned long long)(diag >> 8) * 25ull;
+        while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     stage(0, jc, 0);
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's pieces of k-tile 0 have landed
     __builtin_amdgcn_s_barrier();
@@ -1145,9 +1134,13 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         // for it this is a no-op that tells hipcc's wait insertion that nothing is in flight, so the epilogue carries no waits of its own)
         __builtin_amdgcn_s_waitcnt(0x0F70);
         if (grpB) skip_wait = true;
-        if (!(ATLAS_TUNING && (diag & 1)))
-            pt_epilogue<T, EPI>(acc, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp);
-        else { __builtin_amdgcn_s_waitcnt(0x0F70); if (acc[0][0][0] == 12345.678f) C[0] = 0; }
+#if ATLAS_TUNING
+        if (diag & 1) { if (acc[0][0][0] == 12345.678f) C[0] = 0; }
+        else if ((diag & 12) == 4) pt_epilogue<T, EPI, 2>(acc, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp);
+        else if ((diag & 12) == 8) pt_epilogue<T, EPI, 16>(acc, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp);
+        else
+#endif
+        pt_epilogue<T, EPI>(acc, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 0; a < FA; ++a)
@@ -1523,7 +1516,7 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
     float* sMask = (float*)(sVt + 64 * vstride);               // [Lp] 0 for keys < L, -inf beyond
     const uint16_t* Qb = qk + (size_t)tb * (2 * HID) + h * DHEAD;
     const uint16_t* Kb = Qb + HID;
-    const uint16_t* Vt = vt + ((size_t)b * HID + h * DHEAD) * LpMax;
+    const uint16_t* Vt = vt + ((size_t)b * HID + h * DHEAD) * LpMax + (tb & 7);     // the passage's keys start tb & 7 columns into its rows (layout note)
     // the first query fragment of this wave is requested before K / V^T are staged (its latency runs under the staging), the
     // next one before the current one is computed
     auto load_q = [&](const int qf, uint4& qa, uint4& qb) {
@@ -1552,7 +1545,7 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
             const int idx = base + i * 256 + tid;              // V^T has 64 * cpr = Lp * 8 chunks as well
             const int idc = idx < Lp * 8 ? idx : Lp * 8 - 1;
             const int dim = idc / cpr, c = idc - dim * cpr;
-            vv[i] = *(const uint4*)(Vt + (size_t)dim * LpMax + c * 8);
+            vv[i] = *(const uint4_a2*)(Vt + (size_t)dim * LpMax + c * 8);     // 2-byte aligned for ragged batches: one global_load_dwordx4 all the same
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1767,7 +1760,7 @@ attention_f32_kernel(const float* __restrict__ qk, const float* __restrict__ vt,
     const int nkf = (L + 15) >> 4;
     const float* Qb = qk + (size_t)tb * (2 * HID) + h * DHEAD;
     const float* Kb = Qb + HID;
-    const float* Vt = vt + ((size_t)b * HID + h * DHEAD) * LpMax;
+    const float* Vt = vt + ((size_t)b * HID + h * DHEAD) * LpMax + (tb & 7);
     for (int qf = wave; qf * 16 < L; qf += 4) {
         int qrow = qf * 16 + lr; if (qrow >= L) qrow = L - 1;
         uint4 q[4];
@@ -1820,7 +1813,7 @@ attention_f32_kernel(const float* __restrict__ qk, const float* __restrict__ vt,
                                             __builtin_bit_cast(uint32_t, s[kf][2] / sum), __builtin_bit_cast(uint32_t, s[kf][3] / sum));
 #pragma unroll
                 for (int df = 0; df < 4; ++df) {
-                    uint4 vv = *(const uint4*)(Vt + (size_t)(df * 16 + lr) * LpMax + key0);
+                    uint4 vv = *(const uint4_a4*)(Vt + (size_t)(df * 16 + lr) * LpMax + key0);
                     if (key0 + 0 >= L) vv.x = 0u;                          // columns >= L were never written
                     if (key0 + 1 >= L) vv.y = 0u;
                     if (key0 + 2 >= L) vv.z = 0u;
@@ -1899,7 +1892,8 @@ int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int
     E* ctx = (E*)p;  p += up256((size_t)M * HID * es);
     E* u = (E*)p;    p += up256((size_t)M * HID * es);
     E* qk = (E*)p;   p += up256((size_t)M * 2 * HID * es);
-    E* vt = (E*)p;   p += up256((size_t)n * HID * Lp * es);
+    const int LpS = Lp + 8;                            // V^T row pitch: a passage's keys start up to 7 columns in (layout note)
+    E* vt = (E*)p;   p += up256((size_t)n * HID * LpS * es);
     E* hbuf = (E*)p; p += up256((size_t)M * 4 * HID * es);
     int* counts = (int*)p;        p += up256((size_t)n * 4);
     int* cu = (int*)p;            p += up256((size_t)(n + 1) * 4);
@@ -1918,17 +1912,17 @@ int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int
     for (int l = 0; l < w->n_layers; ++l) {
         const atlas_bert_layer& ly = w->layers[l];
         launch_gemm<T, 3>(cfg, stream, x, (const E*)ly.qkv_w, (const E*)ly.qkv_b, (const E*)nullptr, qk, vt, M, cu, n, tokinfo,
-                          3 * HID, HID, Lp);
+                          3 * HID, HID, LpS);
         if constexpr (T::DT == ATLAS_DT_F32) {
             if (Lp <= 128)
-                hipLaunchKernelGGL(attention_f32_kernel<8>, dim3((unsigned)n * NHEAD), dim3(256), 0, stream, qk, vt, cu, Lp, ctx);
+                hipLaunchKernelGGL(attention_f32_kernel<8>, dim3((unsigned)n * NHEAD), dim3(256), 0, stream, qk, vt, cu, LpS, ctx);
             else
-                hipLaunchKernelGGL(attention_f32_kernel<32>, dim3((unsigned)n * NHEAD), dim3(256), 0, stream, qk, vt, cu, Lp, ctx);
+                hipLaunchKernelGGL(attention_f32_kernel<32>, dim3((unsigned)n * NHEAD), dim3(256), 0, stream, qk, vt, cu, LpS, ctx);
         } else {
             const size_t att_lds = (size_t)Lp * 128 + (size_t)64 * (Lp + 8) * 2 + (size_t)Lp * 4;
             auto att = [&](auto kern) {
                 (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                hipLaunchKernelGGL(kern, dim3((unsigned)n * NHEAD), dim3(256), att_lds, stream, qk, vt, cu, Lp, ctx);
+                hipLaunchKernelGGL(kern, dim3((unsigned)n * NHEAD), dim3(256), att_lds, stream, qk, vt, cu, LpS, ctx);
             };
             if (Lp <= 128) att(attention_kernel<T, 8>);
             else if (Lp <= 256) att(attention_kernel<T, 16>);
@@ -1963,7 +1957,7 @@ size_t atlas_contriever_workspace_bytes(int n, int L, int dtype) {
     if (n <= 0 || L <= 0) return 0;
     const size_t M = (size_t)n * L, Lp = (size_t)((L + 31) & ~31), es = esize(dtype);
     // x, ctx, u : [M,768]; qk : [M,1536]; vt : [n,768,Lp]; h : [M,3072]; counts[n], cu[n+1], tokinfo[M]
-    return up256(M * HID * es) * 3 + up256(M * 2 * HID * es) + up256((size_t)n * HID * Lp * es) + up256(M * 4 * HID * es) +
+    return up256(M * HID * es) * 3 + up256(M * 2 * HID * es) + up256((size_t)n * HID * (Lp + 8) * es) + up256(M * 4 * HID * es) +
            up256((size_t)n * 4) + up256((size_t)(n + 1) * 4) + up256(M * 8) + 256;
 }
 
