@@ -894,7 +894,10 @@ static __device__ __forceinline__ void pt_epilogue(const f4 (&acc)[8][4], const 
                     }
                     o[e] = pack2<T>(v0, v1);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(o, cbuf, (int)vo, 64 * j, AUX);
+                // (the whole offset in the VGPR, soffset 0: for a 16-byte buffer store with an SGPR soffset hipcc does not pad the wait state the
+                //  store's data registers need before the next VALU write -- measured on gfx950: tools/hazard_probe.hip -- and this loop
+                //  recycles them at once)
+                __builtin_amdgcn_raw_buffer_store_b128(o, cbuf, (int)(vo + 64 * j), 0, AUX);
             }
         }
     } else {
@@ -939,9 +942,16 @@ __global__ void __launch_bounds__(512)
 gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* __restrict__ W, const typename T::elem* __restrict__ bias,
                const typename T::elem* __restrict__ R, typename T::elem* __restrict__ C, typename T::elem* __restrict__ VT,
                const int* __restrict__ cu, int n, const int2* __restrict__ tokinfo, int N, int K, int Lp,
-               int diag /* tuning build only: bit 0 = no epilogue, bits 2-3 = store policy (1 nt, 2 sc1), bits 8.. = start stagger; 0 in production */) {
+               int diag /* tuning build only: bit 0 = no epilogue, bits 2-3 = store policy (1 nt, 2 sc1), bits 8.. = start stagger; 0 in production */,
+               unsigned long long* __restrict__ dbg /* tuning build only: 100 MHz stamps of workgroup 0 around its tile boundaries; null in production */) {
     typedef typename T::elem E;
     static_assert(sizeof(E) == 2, "16-bit dtypes only");
+#if ATLAS_TUNING
+    int tstamp = 0;                                                  // tile counter of the stamps
+#define PT_STAMP(i) do { if (dbg != nullptr && blockIdx.x == 0 && tstamp < 8 && pt_fresh_lane() == 0) dbg[((int)wave * 8 + tstamp) * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define PT_STAMP(i) do { } while (0)
+#endif
     constexpr int FA = 8, FB = 4;
     constexpr bool VTR = (EPI == 4);                                 // V tile: token rows staged permuted, MFMA operands swapped
     constexpr uint32_t STG = 256 * 128;                              // bytes per operand stage
@@ -1059,6 +1069,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
                 : "v"(w0), "v"(a0), "v"(w1), "v"(a1)
                 : "memory");
         }
+        if (LAST) PT_STAMP(1);
         if (!grpB) {                                   // A stages the k-tile after this one (after its reads: see gemm_pp_kernel)
             if (!LAST) stage(buf ^ 1, jc, kt + 1);
             else if (has_next) stage(buf ^ 1, jc + nslots, 0);
@@ -1068,6 +1079,8 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if (kt == 0) PT_STAMP(9);
+        if (LAST) PT_STAMP(2);
         if (grpB) {                                    // B stages two k-tiles on, into the buffer both groups have finished reading
             if (!LAST) { if (kt + 2 < nk) stage(buf, jc, kt + 2); else if (has_next) stage(buf, jc + nslots, 0); }
             else if (has_next) stage(buf, jc + nslots, 1);
@@ -1086,6 +1099,8 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
             mma_tile<T, FA, FB>(fw1, fa1, acc);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (kt == 0) PT_STAMP(10);
+        if (LAST) PT_STAMP(3);
         if (LAST) {
             // what the epilogue adds is requested behind the tile's last MFMAs (the fragment registers are free now) and lands under the
             // wait / barrier that follows: the lane's bias values and, for EPI 2, its 16 residual pieces
@@ -1118,13 +1133,17 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
             __builtin_amdgcn_sched_barrier(0);
         }
         if (!grpB) __builtin_amdgcn_s_waitcnt(0x0F70); // A: its pieces of the next k-tile have landed (and its epilogue stores, if any, are out)
+        if (LAST) PT_STAMP(4);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if (kt == 0) PT_STAMP(11);
+        if (LAST) PT_STAMP(5);
         buf ^= 1;
         skip_wait = false;
     };
 
     for (;;) {
+        PT_STAMP(0);
 #pragma unroll 1
         for (int kt = 0; kt < nk - 1; ++kt) iteration(kt, std::false_type{});
         iteration(nk - 1, std::true_type{});
@@ -1133,6 +1152,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         // group B waits here for its pieces of the next tile's k-tile 1, the bias and the residual (group A did so in front of the barrier:
         // for it this is a no-op that tells hipcc's wait insertion that nothing is in flight, so the epilogue carries no waits of its own)
         __builtin_amdgcn_s_waitcnt(0x0F70);
+        PT_STAMP(6);
         if (grpB) skip_wait = true;
 #if ATLAS_TUNING
         if (diag & 1) { if (acc[0][0][0] == 12345.678f) C[0] = 0; }
@@ -1142,14 +1162,21 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 #endif
         pt_epilogue<T, EPI>(acc, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp);
         __builtin_amdgcn_sched_barrier(0);
+        PT_STAMP(7);
 #pragma unroll
         for (int a = 0; a < FA; ++a)
 #pragma unroll
             for (int b = 0; b < FB; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);
+        PT_STAMP(8);
+#if ATLAS_TUNING
+        ++tstamp;
+#endif
         jc += nslots;
         if (jc >= njobs) break;
     }
     if (!grpB) __builtin_amdgcn_s_barrier();           // A matches B's extra barrier
+#undef PT_STAMP
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1401,6 +1428,7 @@ gemm_wr_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 //   5  gemm_bt_kernel  64 x 64, single stage                                (A/B reference for 3)
 #if ATLAS_TUNING
 unsigned long long* g_gemm_dbg = nullptr;    // atlas_tune_set_gemm_stamps
+int g_pt_stamp_nth = 0, g_pt_launches = 0;   // atlas_tune_set_gemm_stamps_nth: only the nth gemm_pt launch from now on gets the stamp buffer
 int g_gemm_diag = 0;                         // atlas_tune_set_gemm_diag
 int g_gemm_cfg = -1;                         // atlas_tune_set_gemm_cfg: -1 = by size (what the product library always does)
 #else
@@ -1433,7 +1461,11 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
             const unsigned grid = (unsigned)(encoder_device_cus() / 8 * 8);
             auto go_pt = [&](auto kern, const typename T::elem* Wp, const typename T::elem* bp, int Np) {
                 (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 128 * 1024, stream, A, Wp, bp, R, C, VT, cu, n, tokinfo, Np, K, Lp, g_gemm_diag);
+                unsigned long long* dbg = g_gemm_dbg;
+#if ATLAS_TUNING
+                if (g_pt_stamp_nth > 0 && ++g_pt_launches != g_pt_stamp_nth) dbg = nullptr;
+#endif
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 128 * 1024, stream, A, Wp, bp, R, C, VT, cu, n, tokinfo, Np, K, Lp, g_gemm_diag, dbg);
             };
             if constexpr (EPI == 3) {        // QKV projection: q | k columns -> [M, 1536], then the v columns -> V^T
                 go_pt(gemm_pt_kernel<T, 3>, W, bias, 2 * HID);
@@ -1948,7 +1980,8 @@ extern "C" {
 
 #if ATLAS_TUNING
 // tuning build only (libatlas_hip_tune.so; not part of include/atlas_hip.h)
-void atlas_tune_set_gemm_stamps(unsigned long long* p) { g_gemm_dbg = p; }
+void atlas_tune_set_gemm_stamps(unsigned long long* p) { g_gemm_dbg = p; g_pt_stamp_nth = 0; }
+void atlas_tune_set_gemm_stamps_nth(unsigned long long* p, int nth) { g_gemm_dbg = p; g_pt_stamp_nth = nth; g_pt_launches = 0; }
 void atlas_tune_set_gemm_diag(int d) { g_gemm_diag = d; }
 void atlas_tune_set_gemm_cfg(int c) { g_gemm_cfg = c; }
 #endif

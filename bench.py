@@ -49,6 +49,44 @@ def make_shard(rows: int, seed: int, device) -> torch.Tensor:
     return slab
 
 
+class _SmiSampler:
+    """socket power and shader clock from rocm-smi beside a timed leg (a thread of this process; rocm-smi missing or silent -> None)"""
+
+    def __init__(self):
+        import threading
+
+        self._stop, self.power, self.sclk = False, [], []
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def start(self):
+        self._t.start()
+
+    def _run(self):
+        import re
+        import subprocess
+
+        while not self._stop:
+            try:
+                o = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+            except Exception:
+                return
+            m = re.search(r"Power \(W\): ([\d.]+)", o)
+            c = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", o)
+            if m:
+                self.power.append(float(m.group(1)))
+            if c:
+                self.sclk.append(float(c.group(1)))
+
+    def finish(self):
+        self._stop = True
+        self._t.join(timeout=8)
+        pw, sc = self.power[1:], self.sclk[1:]              # the first sample may predate the leg
+        if not pw:
+            return None
+        return {"source": "rocm-smi --showpower --showclocks, sampled beside the leg", "samples": len(pw), "watts_mean": float(np.mean(pw)),
+                "watts_max": float(np.max(pw)), "sclk_mhz_mean": float(np.mean(sc)) if sc else None, "sclk_mhz_min": float(np.min(sc)) if sc else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,11 +95,12 @@ def main():
     ap.add_argument("--passages", type=int, default=32_000_000, help="total corpus rows (sharded over --gpus)")
     ap.add_argument("--queries", type=int, default=64)
     ap.add_argument("--topk", type=int, default=40)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="rows of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="most rows of the CPU baseline sample (at least 500k are timed)")
     ap.add_argument("--refresh-batches", type=int, default=30, help="timed 512-passage encoder batches for the index-refresh leg (0 = skip)")
     ap.add_argument("--refresh-len", type=int, default=128, help="tokens per passage in the refresh leg")
-    ap.add_argument("--refresh-stream-seconds", type=float, default=2.0, help="sustained streamed-refresh leg from the token store (0 = skip)")
+    ap.add_argument("--refresh-stream-seconds", type=float, default=15.0, help="sustained streamed-refresh leg from the token store, with rocm-smi power / clock samples (0 = skip)")
+    ap.add_argument("--batch-sweep", type=str, default="64,128,256,512", help="query-batch sizes timed on the 4M-row prefix (a rank of an N-GPU search scores ALL gathered queries; N=1 only; '' = skip)")
     ap.add_argument("--shard-sweep", type=str, default="1000000,4000000,8000000,16000000",
                     help="prefix sizes of the slab timed like the headline: configs[1] and the per-GPU shards of an 8 / 4 / 2-GPU run (N=1 only; '' = skip)")
     ap.add_argument("--oracle-query", type=int, default=31, help="query of the batch held to the CPU oracle at full size in the cpu_baseline leg (-1 = skip)")
@@ -180,6 +219,20 @@ def main():
     if world > 1:   # slowest rank's kernel
         scan_ms = reduce_max(scan_ms)
 
+    # the OTHER twin, same events: the C-ABI's default mode measures every row's norm inside the scan (atlas_scan_topk; what
+    # HipDistributedIndex runs every certify_every-th search). Outside the timed region; same results.
+    certifying = None
+    if world == 1:
+        for it in range(args.steps):
+            rc = L.atlas_scan_topk_ex(q.data_ptr(), _lib.DT_F32, slab.data_ptr(), rows, B, D, k, pmax, out_s.data_ptr(), out_i.data_ptr(),
+                                      out_st.data_ptr(), ws.data_ptr(), ws.numel(), stream, evs[it][0].cuda_event, evs[it][1].cuda_event)
+            assert rc == 0, rc
+        fence()
+        assert int(out_st.cpu()[_lib.ST_FLAGS]) == 0 and torch.equal(out_s, s0) and torch.equal(out_i, i0), "certifying scan disagrees with the trusting one"
+        c_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        certifying = {"kernel": "scan_kernel<16,1,8,0> (measures every row norm: atlas_scan_topk)", "kernel_ms_mean": c_ms,
+                      "frac": rows * D * 2 / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "steps": args.steps}
+
     # synchronous latency of the full product call (host sync + D2H of results + status check), for DESIGN.md
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -256,10 +309,55 @@ def main():
             fence()
             k_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in evs_s]))
             nbytes = n_sub * D * 2
+            # the timed launches' results, held to the MFMA-free exact path on this prefix for 8 queries (outside the timed loops)
+            sel_s = torch.tensor(sorted({min(B - 1, j * 9) for j in range(8)}), device=dev)
+            es_s, ei_s = sub._exact_topk(q[sel_s], k)
+            assert torch.equal(out_s[sel_s], es_s) and torch.equal(out_i[sel_s], ei_s), f"scan disagrees with the exact path on the {n_sub}-row prefix"
             shard_sweep[str(n_sub)] = {"ms_per_step": dts * 1e3, "queries_per_s": B / dts, "kernel_ms_mean": k_ms,
                                        "step_frac": nbytes / dts / 1e9 / HBM_PEAK_GBS, "kernel_frac": nbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                       "steps": steps_s, "timing": "step: K launches without events; kernel: hipEvents in a second pass of K"}
+                                       "steps": steps_s, "timing": "step: K launches without events; kernel: hipEvents in a second pass of K",
+                                       "parity_checked": {"rows": n_sub, "queries_exact": int(sel_s.numel())}}
             del sub
+
+    # ---- larger query batches on the 4M-row prefix (the shard of an 8-GPU run): a rank of a distributed search scores ALL gathered
+    # queries (src/index.py:127-131), B_total = W x b_r; the scan takes them 64 at a time, one slab pass each
+    batch_sweep = None
+    if world == 1 and args.batch_sweep and rows >= 4_000_000:
+        batch_sweep = {}
+        n_b = 4_000_000
+        subb = HipDistributedIndex()
+        subb._set_slab(slab[:n_b])
+        for Bb in (int(x) for x in args.batch_sweep.split(",")):
+            qb = torch.randn((Bb, D), generator=torch.Generator(device=dev).manual_seed(1000 + Bb), device=dev)
+            sb, ib = subb._compute_scores_and_indices(qb, k)            # product call: certifies pmax, sizes the workspace, checks the status
+            assert subb.last_search_stats["fallback_queries"] == 0
+            ws_b, pm_b = subb._ws, float(subb._pmax)
+            o_s = torch.empty((Bb, k), dtype=torch.float16, device=dev); o_i = torch.empty((Bb, k), dtype=torch.int64, device=dev)
+            o_st = torch.empty(_lib.STATUS_HEADER + Bb, dtype=torch.int32, device=dev)
+
+            def b_step():
+                rc = L.atlas_scan_topk_flags(qb.data_ptr(), _lib.DT_F32, slab.data_ptr(), n_b, Bb, D, k, pm_b, o_s.data_ptr(), o_i.data_ptr(),
+                                             o_st.data_ptr(), ws_b.data_ptr(), ws_b.numel(), stream, None, None, _lib.SCAN_TRUST_PMAX)
+                assert rc == 0, rc
+
+            for _ in range(3):
+                b_step()
+            fence()
+            tb = time.perf_counter()
+            nsteps_b = 20
+            for _ in range(nsteps_b):
+                b_step()
+            fence()
+            dtb = (time.perf_counter() - tb) / nsteps_b
+            assert int(o_st.cpu()[_lib.ST_FLAGS]) == 0 and torch.equal(o_s, sb) and torch.equal(o_i, ib)
+            sel_b = torch.tensor(sorted({min(Bb - 1, j * (Bb // 8) + 3) for j in range(8)}), device=dev)
+            es_b, ei_b = subb._exact_topk(qb[sel_b], k)
+            assert torch.equal(o_s[sel_b], es_b) and torch.equal(o_i[sel_b], ei_b), f"B={Bb}: scan disagrees with the exact path"
+            passes = (Bb + 63) // 64
+            batch_sweep[str(Bb)] = {"ms_per_step": dtb * 1e3, "queries_per_s": Bb / dtb, "slab_passes": passes,
+                                    "bytes_read_per_query": passes * n_b * D * 2 / Bb, "step_frac_of_hbm_peak": passes * n_b * D * 2 / dtb / 1e9 / HBM_PEAK_GBS,
+                                    "parity_checked": {"rows": n_b, "queries_exact": int(sel_b.numel())}}
+        del subb
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
@@ -356,10 +454,14 @@ def main():
             fence()
             t_one = time.perf_counter() - t_one
             reps = max(1, int(np.ceil(args.refresh_stream_seconds / t_one)))
+            smi = _SmiSampler() if rank == 0 else None
+            if smi:
+                smi.start()
             t4 = time.perf_counter()
             rf.run_store(store, nb, repeat=reps)
             fence()
             dts = time.perf_counter() - t4
+            power = smi.finish() if smi else None
             if world > 1:
                 dts = reduce_max(dts)
             lfs = lens_s.astype(np.float64)
@@ -368,7 +470,8 @@ def main():
                                    "refreshes": reps, "lengths": "uniform 64..200, length-bucketed batches of %d" % nb,
                                    "includes": "host batch assembly from the pinned token store + H2D + encoder + slab-row writes",
                                    "real_token_tflops": flops_s / dts / 1e12, "mean_len": float(lfs.mean()),
-                                   "vs_device_resident_ragged": (world * n_s * reps / dts) / refresh["ragged"]["value"]}
+                                   "vs_device_resident_ragged": (world * n_s * reps / dts) / refresh["ragged"]["value"],
+                                   "power": power}
             del rf, sub, store
 
     if rank == 0:
@@ -381,9 +484,10 @@ def main():
             import hashlib
 
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            src = hashlib.sha256(open(os.path.join(ROOT, "atlas_amd", "csrc", "scan_kernel.h"), "rb").read()).hexdigest()
-            # only a PMC pass of THIS scan kernel source counts: a pass of an older kernel says nothing about this one's re-reads
-            if pmc.get("kernel") == L.atlas_build_info().decode().split()[2] and pmc.get("scan_kernel_h_sha256") == src:
+            src = hashlib.sha256(b"".join(open(os.path.join(ROOT, "atlas_amd", "csrc", f), "rb").read() for f in ("scan_kernel.h", "atlas_hip.hip"))).hexdigest()
+            # only a PMC pass of THESE sources counts (the kernel and the launch plan that decides its grid and tile pool): a pass of an
+            # older build says nothing about this one's re-reads
+            if pmc.get("sources_sha256") == src:
                 traffic = pmc["per_rows"].get(str(rows), {}).get("traffic_bytes")
         except Exception:
             traffic = None
@@ -408,14 +512,17 @@ def main():
                 "parallelism": f"shard{world}" + ("+rccl-allgather" if world > 1 else ""),
             },
             "roofline": {
-                "kernel": L.atlas_build_info().decode().split()[2], "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch (PMC FETCH_SIZE, calibrated)",
+                "kernel": "scan_kernel<16,1,8,64> (the twin that takes pmax as certified: ATLAS_SCAN_TRUST_PMAX, what HipDistributedIndex runs "
+                          "between certifying searches)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch (PMC FETCH_SIZE, calibrated; from the committed pass of these sources, profiles/pmc_traffic.json)",
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_mean": scan_ms, "kernel_ms_min": scan_ms_min,
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+                "certifying": certifying,
             },
             "cpu_baseline": cpu,
             "refresh": refresh,
             "shard_sweep": shard_sweep,
+            "batch_sweep": batch_sweep,
             "detail": {
                 "parity_checked": parity_checked,
                 "sync_call_latency_ms": lat_ms, "search_knn_ms_per_batch": knn_ms,
