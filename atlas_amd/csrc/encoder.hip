@@ -862,42 +862,61 @@ template <class T> static __device__ __forceinline__ uint32_t pack2(const float 
 // [column 32 (a >> 1) + 8 lg + 4 (a & 1) + r] of the wave's 128 x 64; EPI 4 (the V columns, stored transposed): acc[a][b][r] =
 // C[token 32 (b >> 1) + 8 lg + 4 (b & 1) + r][column 16 a + lr]. Rounding points are those of gemm_epilogue: dt(acc + bias), then [gelu] /
 // [+ residual] on that, rounded by the store.
-//   cbuf: descriptor of C's rows [m0, M) (stores past M fall out of bounds);  rv: the residual pieces of EPI 2, same addressing;
-//   bq: the lane's bias values -- EPI 1-3: 8 consecutive columns per fragment pair j (packed); EPI 4: word a = bias of column 16 a + lr
-//   tki (EPI 4): tokinfo of the first and the last token of the lane's two runs of 8 (run jj: tki[2 jj], tki[2 jj + 1]; clamped to M - 1)
+// EPI 1-3: what a store costs the wave is set by how many ROWS its 64 lanes touch, not by its bytes (tools/store_bench.hip, one 128 KiB
+// tile per CU: 16 rows x 64 B per instruction = 3.2 us, 2 rows x 512 B = 0.85 us), and the fragment layout gives 16 rows x 64 B. So each
+// 16-token slice of the wave's tile takes a turn through a WAVE-PRIVATE 4 KiB of LDS (no barrier: a wave's LDS operations execute in
+// order) and leaves as 4 rows x 256 B per instruction; the residual of EPI 2 is fetched and added in that layout too.
+//   s_tr: this wave's 4 KiB: [16 tokens][16 chunks of 8 columns], chunk c of token t at 16-byte slot c ^ t (conflict-free both ways)
+//   s_bias: the tile's 256 bias values in LDS;  cbuf: descriptor of C's rows [m0, M) (stores past M fall out of bounds)
+//   rv: EPI 2: the residual piece of (slice b, store s) = rv[4 b + s];  EPI 4: bq word a = bias of column 16 a + lr, tki: see below
 template <class T, int EPI, int AUX = 0>      // AUX: cache-policy bits of the C stores (0 = default; tuning builds A/B 2 = nt and 16 = sc1)
-static __device__ __forceinline__ void pt_epilogue(const f4 (&acc)[8][4], const pt_u4 (&bq)[4], const pt_u4 (&rv)[16], const int2 (&tki)[4],
+static __device__ __forceinline__ void pt_epilogue(const f4 (&acc)[8][4], const uint16_t* __restrict__ s_bias, unsigned char* __restrict__ s_tr,
+                                                   const pt_u4 (&bq4)[4], const pt_u4 (&rv)[16], const int2 (&tki)[4],
                                                    const __amdgpu_buffer_rsrc_t cbuf,
                                                    const int64_t m0, const int n0, const int wi, const int wj,
                                                    const int64_t M, const int N, uint16_t* __restrict__ VT, const int2* __restrict__ tokinfo, const int Lp) {
     const int lane = pt_fresh_lane(), lr = lane & 15, lg = lane >> 4;
     if constexpr (EPI != 4) {
+        uint4 bq[4];                                                    // the lane's 8 bias values of every fragment pair, packed
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bq[j] = *(const uint4*)(s_bias + wi * 128 + 32 * j + 8 * lg);
+        const int tq = lane >> 4, cc = lane & 15;                       // transposed side: token 4 s + tq of the slice, column chunk cc
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const uint32_t vo = (uint32_t)(((wj * 64 + b * 16 + lr) * N + n0 + wi * 128 + 8 * lg) * 2);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                pt_u4 o;
+                const uint32_t bw[4] = {bq[j].x, bq[j].y, bq[j].z, bq[j].w};
+                uint4 o;
+                uint32_t* ow = (uint32_t*)&o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {                           // columns 2 e, 2 e + 1 of the lane's eight
                     const f4 s = acc[2 * j + (e >> 1)][b];
-                    const uint32_t bw = bq[j][e], rw = rv[b * 4 + j][e];
-                    float v0 = ((e & 1) ? s[2] : s[0]) + T::ld((uint16_t)(bw & 0xffff));
-                    float v1 = ((e & 1) ? s[3] : s[1]) + T::ld((uint16_t)(bw >> 16));
+                    float v0 = ((e & 1) ? s[2] : s[0]) + T::ld((uint16_t)(bw[e] & 0xffff));
+                    float v1 = ((e & 1) ? s[3] : s[1]) + T::ld((uint16_t)(bw[e] >> 16));
                     if (EPI == 1) {                                     // erf GELU in fp32 on the Linear output in the model dtype (common.h)
                         const gelu_f2 g = gelu_erf_poly2((gelu_f2){T::rnd(v0), T::rnd(v1)});
                         v0 = g.x; v1 = g.y;
                     }
-                    if (EPI == 2) {                                     // + input_tensor
-                        v0 = T::rnd(v0) + T::ld((uint16_t)(rw & 0xffff));
-                        v1 = T::rnd(v1) + T::ld((uint16_t)(rw >> 16));
+                    ow[e] = pack2<T>(v0, v1);
+                }
+                *(uint4*)(s_tr + lr * 256 + (((4 * j + lg) ^ lr) * 16)) = o;
+            }
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int tok = 4 * sidx + tq;
+                const uint4 t = *(const uint4*)(s_tr + tok * 256 + ((cc ^ tok) * 16));
+                pt_u4 o = {t.x, t.y, t.z, t.w};
+                if (EPI == 2) {                                         // + input_tensor
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t rw = rv[b * 4 + sidx][e];
+                        o[e] = pack2<T>(T::ld((uint16_t)(o[e] & 0xffff)) + T::ld((uint16_t)(rw & 0xffff)), T::ld((uint16_t)(o[e] >> 16)) + T::ld((uint16_t)(rw >> 16)));
                     }
-                    o[e] = pack2<T>(v0, v1);
                 }
                 // (the whole offset in the VGPR, soffset 0: for a 16-byte buffer store with an SGPR soffset hipcc does not pad the wait state the
-                //  store's data registers need before the next VALU write -- measured on gfx950: tools/hazard_probe.hip -- and this loop
-                //  recycles them at once)
-                __builtin_amdgcn_raw_buffer_store_b128(o, cbuf, (int)(vo + 64 * j), 0, AUX);
+                //  store's data registers need before the next VALU write -- measured on gfx950: tools/hazard_probe.hip)
+                const uint32_t vo = (uint32_t)(((wj * 64 + b * 16 + tok) * N + n0 + wi * 128 + 8 * cc) * 2);
+                __builtin_amdgcn_raw_buffer_store_b128(o, cbuf, (int)vo, 0, AUX);
             }
         }
     } else {
@@ -913,7 +932,7 @@ static __device__ __forceinline__ void pt_epilogue(const f4 (&acc)[8][4], const 
             const int64_t off0 = (int64_t)t0.x * HID * Lp + (tok0 - ((tok0 - (t0.y >> 16)) & ~(int64_t)7));
 #pragma unroll
             for (int a = 0; a < 8; ++a) {
-                const float bv = T::ld((uint16_t)(bq[a >> 1][(a & 1) * 2] & 0xffff));     // (words 0 and 2 of bq[a >> 1]: see the loads)
+                const float bv = T::ld((uint16_t)(bq4[a >> 1][(a & 1) * 2] & 0xffff));    // (words 0 and 2 of bq4[a >> 1]: see the loads)
                 const f4 s0 = acc[a][2 * jj], s1 = acc[a][2 * jj + 1];
                 const uint4 v = make_uint4(pack2<T>(s0[0] + bv, s0[1] + bv), pack2<T>(s0[2] + bv, s0[3] + bv),
                                            pack2<T>(s1[0] + bv, s1[1] + bv), pack2<T>(s1[2] + bv, s1[3] + bv));
@@ -955,7 +974,8 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     constexpr int FA = 8, FB = 4;
     constexpr bool VTR = (EPI == 4);                                 // V tile: token rows staged permuted, MFMA operands swapped
     constexpr uint32_t STG = 256 * 128;                              // bytes per operand stage
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // W0 | W1 | A0 | A1, 32 KiB each
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // W0 | W1 | A0 | A1, 32 KiB each | transposition 4 x 4 KiB | bias 2 x 512 B
+    constexpr uint32_t TR_OFF = 4 * STG, BIAS_OFF = TR_OFF + 4 * 4096;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave >> 2, wj = wave & 3;
@@ -1024,13 +1044,37 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 #pragma unroll
         for (int b = 0; b < FB; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
 
+    // the tile's 256 bias values reach LDS by LDS-DMA too (wave 0, two 256-byte pieces), double-buffered by tile parity: the next tile's
+    // are requested in a tile's second iteration -- not earlier: until the barrier behind the first, group B may still be reading the
+    // slot in the previous tile's epilogue -- and land under wave 0's wait of that iteration
+    int tp = 0;
+    auto stage_bias = [&](const int par, const int j) {
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(bias + tile_n0(j)), 0, 512, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(smem_raw + BIAS_OFF + par * 512), 4, (int)(lane * 4), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(smem_raw + BIAS_OFF + par * 512 + 256), 4, (int)(lane * 4), 256, 0, 0);
+    };
     int jc = slot;                                     // the tile being multiplied; the next one is jc + nslots
+    // EPI 2: the residual rows the epilogue adds were written a kernel or more ago and come from the Infinity Cache / HBM: ~2 us that
+    // both groups used to sit out between their last MFMA and their epilogue. Three iterations before the end, right behind its own
+    // wait (so the requests have a whole iteration to land before the wave waits again), every wave touches the 128 cache lines of
+    // its 64 x 128 residual piece with two 4-byte LDS-DMA loads per lane into its (idle) transposition slot: the lines are in L2
+    // when the epilogue asks for them
+    auto touch_residual = [&]() {
+        const __amdgpu_buffer_rsrc_t rr = rows_rsrc(R, tile_m0(jc), N);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int line = i * 64 + lane;            // 128-byte line `line & 1` of row `line >> 1` of the wave's 64 x 256 B
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_ptr)(smem_raw + TR_OFF + wj * 4096 + i * 256), 4,
+                                                     (int)((((wj * 64 + (line >> 1)) * N + tile_n0(jc) + wi * 128) * 2) + (line & 1) * 128), 0, 0, 0);
+        }
+    };
 #if ATLAS_TUNING
     if (diag >> 8) {                                   // experiment: workgroups start in four classes, (diag >> 8) x 0.25 us apart (are the CUs' store bursts the epilogue's cost?)
         const unsigned long long until = wall_clock64() + (unsigned long long)((blockIdx.x >> 3) & 3) * (unsigned long long)(diag >> 8) * 25ull;
         while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
     }
 #endif
+    if (wave == 0) stage_bias(0, jc);
     stage(0, jc, 0);
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's pieces of k-tile 0 have landed
     __builtin_amdgcn_s_barrier();
@@ -1051,6 +1095,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     auto iteration = [&](const int kt, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
         const bool has_next = jc + nslots < njobs;
+        if (wave == 0 && kt == 1 && has_next) stage_bias(tp ^ 1, jc + nslots);
         u4v fw0[FA], fa0[FB], fw1[FA], fa1[FB];
         {
             const uint32_t w0 = aw0 + buf * STG, w1 = aw1 + buf * STG, a0 = aa0 + buf * STG, a1 = aa1 + buf * STG;
@@ -1076,6 +1121,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         } else if (!skip_wait) {
             __builtin_amdgcn_s_waitcnt(0x0F70);        // B: its pieces of the next k-tile (issued a phase ago) have landed
         }
+        if (EPI == 2 && grpB && kt == nk - 3) touch_residual();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -1106,11 +1152,8 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
             // wait / barrier that follows: the lane's bias values and, for EPI 2, its 16 residual pieces
             const int n0 = tile_n0(jc);
             const int fl = pt_fresh_lane(), lr = fl & 15, lg = fl >> 4;
-            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(bias + n0), 0, 512, 0x00020000);
-            if constexpr (EPI != 4) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bq[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (wi * 128 + 8 * lg) * 2, 64 * j, 0);
-            } else {                                   // column 16 a + lr of the wave's 128: word (a & 1) * 2 of bq[a >> 1], low half
+            if constexpr (EPI == 4) {                  // column 16 a + lr of the wave's 128: word (a & 1) * 2 of bq[a >> 1], low half
+                const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(bias + n0), 0, 512, 0x00020000);
 #pragma unroll
                 for (int a = 0; a < 8; ++a) bq[a >> 1][(a & 1) * 2] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rb, (wi * 128 + a * 16 + lr) * 2, 0, 0);
                 const int64_t mlast = M - 1;
@@ -1121,18 +1164,18 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
                     tki[2 * jj + 1] = tokinfo[tok0 + 7 < mlast ? tok0 + 7 : mlast];
                 }
             }
-            if constexpr (EPI == 2) {
+            if constexpr (EPI == 2) {                  // the residual in the epilogue's transposed layout: (slice b, store s) = token 16 b + 4 s + (lane >> 4), chunk lane & 15
                 const __amdgpu_buffer_rsrc_t rr = rows_rsrc(R, tile_m0(jc), N);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const uint32_t vo = (uint32_t)(((wj * 64 + b * 16 + lr) * N + n0 + wi * 128 + 8 * lg) * 2);
+                for (int b = 0; b < 4; ++b)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) rv[b * 4 + j] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)vo, 64 * j, 0);
-                }
+                    for (int sidx = 0; sidx < 4; ++sidx)
+                        rv[b * 4 + sidx] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(((wj * 64 + b * 16 + 4 * sidx + lg) * N + n0 + wi * 128 + 8 * lr) * 2), 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (!grpB) __builtin_amdgcn_s_waitcnt(0x0F70); // A: its pieces of the next k-tile have landed (and its epilogue stores, if any, are out)
+        if (EPI == 2 && !grpB && kt == nk - 3) touch_residual();
         if (LAST) PT_STAMP(4);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -1156,11 +1199,11 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         if (grpB) skip_wait = true;
 #if ATLAS_TUNING
         if (diag & 1) { if (acc[0][0][0] == 12345.678f) C[0] = 0; }
-        else if ((diag & 12) == 4) pt_epilogue<T, EPI, 2>(acc, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp);
-        else if ((diag & 12) == 8) pt_epilogue<T, EPI, 16>(acc, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp);
+        else if ((diag & 12) == 4) pt_epilogue<T, EPI, 2>(acc, (const uint16_t*)(smem_raw + BIAS_OFF + tp * 512), smem_raw + TR_OFF + wj * 4096, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp);
+        else if ((diag & 12) == 8) pt_epilogue<T, EPI, 16>(acc, (const uint16_t*)(smem_raw + BIAS_OFF + tp * 512), smem_raw + TR_OFF + wj * 4096, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp);
         else
 #endif
-        pt_epilogue<T, EPI>(acc, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp);
+        pt_epilogue<T, EPI>(acc, (const uint16_t*)(smem_raw + BIAS_OFF + tp * 512), smem_raw + TR_OFF + wj * 4096, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp);
         __builtin_amdgcn_sched_barrier(0);
         PT_STAMP(7);
 #pragma unroll
@@ -1173,6 +1216,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         ++tstamp;
 #endif
         jc += nslots;
+        tp ^= 1;
         if (jc >= njobs) break;
     }
     if (!grpB) __builtin_amdgcn_s_barrier();           // A matches B's extra barrier
@@ -1465,7 +1509,7 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
 #if ATLAS_TUNING
                 if (g_pt_stamp_nth > 0 && ++g_pt_launches != g_pt_stamp_nth) dbg = nullptr;
 #endif
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 128 * 1024, stream, A, Wp, bp, R, C, VT, cu, n, tokinfo, Np, K, Lp, g_gemm_diag, dbg);
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 128 * 1024 + 4 * 4096 + 1024, stream, A, Wp, bp, R, C, VT, cu, n, tokinfo, Np, K, Lp, g_gemm_diag, dbg);
             };
             if constexpr (EPI == 3) {        // QKV projection: q | k columns -> [M, 1536], then the v columns -> V^T
                 go_pt(gemm_pt_kernel<T, 3>, W, bias, 2 * HID);
