@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_SO = os.environ.get("ATLAS_HIP_SO") or os.path.join(HERE, "lib", "libatlas_hip.so")   # ATLAS_HIP_SO: A/B runs of two builds (dev)
 TUNE_SO = os.path.join(HERE, "lib", "libatlas_hip_tune.so")   # the -DATLAS_TUNING=1 build: lib(tuning=True), tools/ and configuration tests only
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 DT_F16, DT_F32, DT_BF16 = 0, 1, 2
 STATUS_HEADER = 8
 SCAN_TRUST_PMAX = 1          # ATLAS_SCAN_TRUST_PMAX
@@ -23,7 +23,7 @@ D_FAST, K_FAST_MAX, K_EXACT_MAX = 768, 256, 2048
 
 SYMBOLS = [
     "atlas_abi_version", "atlas_build_info",
-    "atlas_scan_topk_workspace_bytes", "atlas_scan_topk", "atlas_scan_topk_ex", "atlas_scan_topk_flags",
+    "atlas_scan_topk_workspace_bytes", "atlas_scan_topk", "atlas_scan_topk_ex", "atlas_scan_topk_flags", "atlas_scan_topk_pack",
     "atlas_exact_topk_workspace_bytes", "atlas_exact_topk",
     "atlas_pack_candidates", "atlas_merge_packed",
     "atlas_pool_write", "atlas_slab_pmax",
@@ -94,6 +94,8 @@ def _bind(path):
     L.atlas_scan_topk_ex.argtypes = [vp, i32, vp, i64, i32, i32, i32, f32, vp, vp, vp, vp, sz, vp, vp, vp]
     L.atlas_scan_topk_flags.restype = i32
     L.atlas_scan_topk_flags.argtypes = [vp, i32, vp, i64, i32, i32, i32, f32, vp, vp, vp, vp, sz, vp, vp, vp, i32]
+    L.atlas_scan_topk_pack.restype = i32
+    L.atlas_scan_topk_pack.argtypes = [vp, i32, vp, i64, i32, i32, i32, f32, vp, vp, vp, vp, sz, vp, vp, vp, i32, i64, i64, vp]
     L.atlas_exact_topk_workspace_bytes.restype = sz
     L.atlas_exact_topk_workspace_bytes.argtypes = [i64, i32, i32, i32]
     L.atlas_exact_topk.restype = i32

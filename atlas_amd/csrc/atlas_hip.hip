@@ -108,6 +108,7 @@ struct MergeParams {
     int key_cap;                 // approximate-score keys that fit in LDS
     unsigned long long* dbg;     // optional per-phase cycle stamps of block 0 (tuning only; null in production)
     uint16_t* out_score; int64_t* out_idx; int32_t* out_status;
+    uint64_t* out_packed; int64_t id_mul, id_add;   // optional: the winners also leave as cross-shard packed candidates (atlas_scan_topk_pack)
 };
 
 // Canonical exact score (common.h exact_dot_f16) computed by ONE WAVE: lane j is chain j and adds the
@@ -423,11 +424,17 @@ merge_rescore_kernel(const MergeParams p) {
         uint32_t pos = 0;
         for (uint32_t j = 0; j < nsurv; ++j) pos += (s_key[j] > ki) ? 1u : 0u;
         if (pos < (uint32_t)k) {
-            o_score[pos] = f16_from_order_key((uint16_t)(ki >> 32));
-            o_idx[pos] = (int64_t)(0xffffffffu - (uint32_t)ki);
+            const uint16_t sc = f16_from_order_key((uint16_t)(ki >> 32));
+            const uint32_t row = 0xffffffffu - (uint32_t)ki;
+            o_score[pos] = sc;
+            o_idx[pos] = (int64_t)row;
+            if (p.out_packed) p.out_packed[(size_t)(p.q0 + q) * k + pos] = pack_candidate(sc, (uint64_t)((int64_t)row * p.id_mul + p.id_add));
         }
     }
-    for (uint32_t i = nsurv + tid; i < (uint32_t)k; i += NT) { o_score[i] = 0xfc00; o_idx[i] = -1; }
+    for (uint32_t i = nsurv + tid; i < (uint32_t)k; i += NT) {
+        o_score[i] = 0xfc00; o_idx[i] = -1;
+        if (p.out_packed) p.out_packed[(size_t)(p.q0 + q) * k + i] = 0ull;
+    }
     if (p.dbg && q == 0 && tid == 0) p.dbg[6] = __builtin_readcyclecounter();
     if (tid == 0) {
         *o_qst = ATLAS_Q_OK;
@@ -933,6 +940,19 @@ void atlas_tune_scan_plan(int64_t N, int k, int cus, int64_t* out) {
     out[7] = scan_plan_supported(pl) ? 1 : 0;
 }
 void atlas_tune_set_merge_stamps(unsigned long long* p) { g_merge_dbg = p; }
+// a kernel that does nothing but HOLD `wgs` CUs for `usec` microseconds (1024 threads + all of the LDS per workgroup: nothing else fits
+// beside it), for the contention test: what happens to a search when another stream owns part of the chip
+__global__ void __launch_bounds__(1024) atlas_spin_kernel(unsigned long long ticks, int* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned long long until = wall_clock64() + ticks;
+    while (wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
+    if (ticks == 0ull && smem[threadIdx.x] == 77) *sink = 1;
+}
+int atlas_tune_spin(int wgs, long long usec, void* stream) {
+    allow_lds(atlas_spin_kernel);
+    hipLaunchKernelGGL(atlas_spin_kernel, dim3(wgs), dim3(1024), 160 * 1024, (hipStream_t)stream, (unsigned long long)usec * 100ull, (int*)nullptr);
+    return (int)hipGetLastError();
+}
 void atlas_tune_set_scan_stamps(unsigned long long* p) { g_scan_dbg = p; }
 #endif
 
@@ -975,6 +995,14 @@ int atlas_scan_topk_ex(const void* q, int q_dtype, const void* slab_f16, int64_t
 int atlas_scan_topk_flags(const void* q, int q_dtype, const void* slab_f16, int64_t N, int B, int d, int k,
                           float pmax_hint, void* out_score_f16, int64_t* out_idx, int32_t* out_status, void* ws,
                           size_t ws_bytes, void* stream_, void* ev_scan_begin, void* ev_scan_end, int flags) {
+    return atlas_scan_topk_pack(q, q_dtype, slab_f16, N, B, d, k, pmax_hint, out_score_f16, out_idx, out_status, ws, ws_bytes, stream_,
+                                ev_scan_begin, ev_scan_end, flags, 1, 0, nullptr);
+}
+
+int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64_t N, int B, int d, int k,
+                         float pmax_hint, void* out_score_f16, int64_t* out_idx, int32_t* out_status, void* ws,
+                         size_t ws_bytes, void* stream_, void* ev_scan_begin, void* ev_scan_end, int flags,
+                         int64_t id_mul, int64_t id_add, uint64_t* out_packed) {
     if (flags & ~ATLAS_SCAN_TRUST_PMAX) return ATLAS_E_BADARG;
     if (!q || (!slab_f16 && N > 0) || !out_score_f16 || !out_idx || !out_status || !ws) return ATLAS_E_BADARG;
     if (B <= 0 || k <= 0 || N < 0 || q_dtype < 0 || q_dtype > 2 || !(pmax_hint >= 0.f)) return ATLAS_E_BADARG;
@@ -1042,6 +1070,7 @@ int atlas_scan_topk_flags(const void* q, int q_dtype, const void* slab_f16, int6
         mp.qflag = sp.qflag; mp.k = k; mp.q0 = q0; mp.key_cap = pl.key_cap;
         mp.dbg = g_merge_dbg;
         mp.out_score = (uint16_t*)out_score_f16; mp.out_idx = out_idx; mp.out_status = out_status;
+        mp.out_packed = out_packed; mp.id_mul = id_mul; mp.id_add = id_add;
         hipLaunchKernelGGL(merge, dim3(nq), dim3(MERGE_NT), pl.merge_lds, stream, mp);
     }
     return (int)hipGetLastError();

@@ -867,25 +867,22 @@ template <class T> static __device__ __forceinline__ uint32_t pack2(const float 
 // 16-token slice of the wave's tile takes a turn through a WAVE-PRIVATE 4 KiB of LDS (no barrier: a wave's LDS operations execute in
 // order) and leaves as 4 rows x 256 B per instruction; the residual of EPI 2 is fetched and added in that layout too.
 //   s_tr: this wave's 4 KiB: [16 tokens][16 chunks of 8 columns], chunk c of token t at 16-byte slot c ^ t (conflict-free both ways)
-//   s_bias: the tile's 256 bias values in LDS;  cbuf: descriptor of C's rows [m0, M) (stores past M fall out of bounds)
-//   rv: EPI 2: the residual piece of (slice b, store s) = rv[4 b + s];  EPI 4: bq word a = bias of column 16 a + lr, tki: see below
+//   cbuf: descriptor of C's rows [m0, M) (stores past M fall out of bounds);  bq4: the lane's 8 bias values of fragment pair j (packed)
+//   rv: EPI 2: the residual piece of (slice b, store s) = rv[4 b + s];  EPI 4: bq4 word a = bias of column 16 a + lr, tki: see below
 template <class T, int EPI, int AUX = 0>      // AUX: cache-policy bits of the C stores (0 = default; tuning builds A/B 2 = nt and 16 = sc1)
-static __device__ __forceinline__ void pt_epilogue(const f4 (&acc)[8][4], const uint16_t* __restrict__ s_bias, unsigned char* __restrict__ s_tr,
+static __device__ __forceinline__ void pt_epilogue(const f4 (&acc)[8][4], unsigned char* __restrict__ s_tr,
                                                    const pt_u4 (&bq4)[4], const pt_u4 (&rv)[16], const int2 (&tki)[4],
                                                    const __amdgpu_buffer_rsrc_t cbuf,
                                                    const int64_t m0, const int n0, const int wi, const int wj,
                                                    const int64_t M, const int N, uint16_t* __restrict__ VT, const int2* __restrict__ tokinfo, const int Lp) {
     const int lane = pt_fresh_lane(), lr = lane & 15, lg = lane >> 4;
     if constexpr (EPI != 4) {
-        uint4 bq[4];                                                    // the lane's 8 bias values of every fragment pair, packed
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bq[j] = *(const uint4*)(s_bias + wi * 128 + 32 * j + 8 * lg);
         const int tq = lane >> 4, cc = lane & 15;                       // transposed side: token 4 s + tq of the slice, column chunk cc
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint32_t bw[4] = {bq[j].x, bq[j].y, bq[j].z, bq[j].w};
+                const uint32_t bw[4] = {bq4[j][0], bq4[j][1], bq4[j][2], bq4[j][3]};
                 uint4 o;
                 uint32_t* ow = (uint32_t*)&o;
 #pragma unroll
@@ -974,8 +971,8 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     constexpr int FA = 8, FB = 4;
     constexpr bool VTR = (EPI == 4);                                 // V tile: token rows staged permuted, MFMA operands swapped
     constexpr uint32_t STG = 256 * 128;                              // bytes per operand stage
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // W0 | W1 | A0 | A1, 32 KiB each | transposition 4 x 4 KiB | bias 2 x 512 B
-    constexpr uint32_t TR_OFF = 4 * STG, BIAS_OFF = TR_OFF + 4 * 4096;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // W0 | W1 | A0 | A1, 32 KiB each | 8 x 4 KiB: one transposition slot per wave = all 160 KiB
+    constexpr uint32_t TR_OFF = 4 * STG;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave >> 2, wj = wave & 3;
@@ -1044,27 +1041,19 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 #pragma unroll
         for (int b = 0; b < FB; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    // the tile's 256 bias values reach LDS by LDS-DMA too (wave 0, two 256-byte pieces), double-buffered by tile parity: the next tile's
-    // are requested in a tile's second iteration -- not earlier: until the barrier behind the first, group B may still be reading the
-    // slot in the previous tile's epilogue -- and land under wave 0's wait of that iteration
-    int tp = 0;
-    auto stage_bias = [&](const int par, const int j) {
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(bias + tile_n0(j)), 0, 512, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(smem_raw + BIAS_OFF + par * 512), 4, (int)(lane * 4), 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(smem_raw + BIAS_OFF + par * 512 + 256), 4, (int)(lane * 4), 256, 0, 0);
-    };
     int jc = slot;                                     // the tile being multiplied; the next one is jc + nslots
     // EPI 2: the residual rows the epilogue adds were written a kernel or more ago and come from the Infinity Cache / HBM: ~2 us that
     // both groups used to sit out between their last MFMA and their epilogue. Three iterations before the end, right behind its own
     // wait (so the requests have a whole iteration to land before the wave waits again), every wave touches the 128 cache lines of
-    // its 64 x 128 residual piece with two 4-byte LDS-DMA loads per lane into its (idle) transposition slot: the lines are in L2
+    // its 64 x 128 residual piece with two 4-byte LDS-DMA loads per lane into its own (idle) transposition slot: the lines are in L2
     // when the epilogue asks for them
     auto touch_residual = [&]() {
         const __amdgpu_buffer_rsrc_t rr = rows_rsrc(R, tile_m0(jc), N);
+        const int fl = pt_fresh_lane();                // (not the kernel's `lane`: nothing lane-derived is carried through the k-loop)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int line = i * 64 + lane;            // 128-byte line `line & 1` of row `line >> 1` of the wave's 64 x 256 B
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_ptr)(smem_raw + TR_OFF + wj * 4096 + i * 256), 4,
+            const int line = i * 64 + fl;              // 128-byte line `line & 1` of row `line >> 1` of the wave's 64 x 256 B
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_ptr)(smem_raw + TR_OFF + wave * 4096 + i * 256), 4,
                                                      (int)((((wj * 64 + (line >> 1)) * N + tile_n0(jc) + wi * 128) * 2) + (line & 1) * 128), 0, 0, 0);
         }
     };
@@ -1074,7 +1063,6 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
     }
 #endif
-    if (wave == 0) stage_bias(0, jc);
     stage(0, jc, 0);
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's pieces of k-tile 0 have landed
     __builtin_amdgcn_s_barrier();
@@ -1084,6 +1072,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     }
     int buf = 0;
     bool skip_wait = false;                            // B: its wait of a tile's first iteration was taken before the epilogue
+    bool skip_b1 = false;                              // A: its first barrier of a tile was taken before the epilogue
     pt_u4 rv[16], bq[4];
     int2 tki[4];
 #pragma unroll
@@ -1095,7 +1084,6 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     auto iteration = [&](const int kt, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
         const bool has_next = jc + nslots < njobs;
-        if (wave == 0 && kt == 1 && has_next) stage_bias(tp ^ 1, jc + nslots);
         u4v fw0[FA], fa0[FB], fw1[FA], fa1[FB];
         {
             const uint32_t w0 = aw0 + buf * STG, w1 = aw1 + buf * STG, a0 = aa0 + buf * STG, a1 = aa1 + buf * STG;
@@ -1123,7 +1111,8 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         }
         if (EPI == 2 && grpB && kt == nk - 3) touch_residual();
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if (!skip_b1) __builtin_amdgcn_s_barrier();    // (group A took a tile's first barrier ahead of its epilogue: see the tile loop)
+        skip_b1 = false;
         __builtin_amdgcn_sched_barrier(0);
         if (kt == 0) PT_STAMP(9);
         if (LAST) PT_STAMP(2);
@@ -1152,8 +1141,11 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
             // wait / barrier that follows: the lane's bias values and, for EPI 2, its 16 residual pieces
             const int n0 = tile_n0(jc);
             const int fl = pt_fresh_lane(), lr = fl & 15, lg = fl >> 4;
-            if constexpr (EPI == 4) {                  // column 16 a + lr of the wave's 128: word (a & 1) * 2 of bq[a >> 1], low half
-                const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(bias + n0), 0, 512, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(bias + n0), 0, 512, 0x00020000);
+            if constexpr (EPI != 4) {                  // the lane's 8 bias values of every fragment pair
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bq[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (wi * 128 + 8 * lg) * 2, 64 * j, 0);
+            } else {                                   // column 16 a + lr of the wave's 128: word (a & 1) * 2 of bq[a >> 1], low half
 #pragma unroll
                 for (int a = 0; a < 8; ++a) bq[a >> 1][(a & 1) * 2] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rb, (wi * 128 + a * 16 + lr) * 2, 0, 0);
                 const int64_t mlast = M - 1;
@@ -1190,8 +1182,13 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 #pragma unroll 1
         for (int kt = 0; kt < nk - 1; ++kt) iteration(kt, std::false_type{});
         iteration(nk - 1, std::true_type{});
-        // epilogue of this tile: group A right behind its last MFMAs (group B is multiplying the same k-tile), group B behind its own
-        // (group A is multiplying the next tile's first). The stores stay in flight behind the wave's next wait.
+        // Epilogue of this tile, BOTH GROUPS SIDE BY SIDE: an epilogue is a chain of dependent VALU work (bias, GELU polynomial, packing)
+        // that one wave per SIMD runs at ~7 cycles per instruction; two waves per SIMD hide each other's latencies. The barrier between a
+        // group's reads and its MFMAs only keeps the two groups in opposite phases (no LDS hazard hangs on it: every buffer hand-over
+        // goes through the OTHER barrier), so group A takes the next tile's first one here, ahead of its epilogue -- it meets group B
+        // coming out of the tile's last MFMAs -- and then skips it in the next tile's first iteration (at the very end it is the
+        // barrier group B's last iteration still owes). The stores stay in flight behind the wave's next wait.
+        if (!grpB) { __builtin_amdgcn_s_barrier(); skip_b1 = true; }
         // group B waits here for its pieces of the next tile's k-tile 1, the bias and the residual (group A did so in front of the barrier:
         // for it this is a no-op that tells hipcc's wait insertion that nothing is in flight, so the epilogue carries no waits of its own)
         __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -1199,11 +1196,11 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         if (grpB) skip_wait = true;
 #if ATLAS_TUNING
         if (diag & 1) { if (acc[0][0][0] == 12345.678f) C[0] = 0; }
-        else if ((diag & 12) == 4) pt_epilogue<T, EPI, 2>(acc, (const uint16_t*)(smem_raw + BIAS_OFF + tp * 512), smem_raw + TR_OFF + wj * 4096, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp);
-        else if ((diag & 12) == 8) pt_epilogue<T, EPI, 16>(acc, (const uint16_t*)(smem_raw + BIAS_OFF + tp * 512), smem_raw + TR_OFF + wj * 4096, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp);
+        else if ((diag & 12) == 4) pt_epilogue<T, EPI, 2>(acc, smem_raw + TR_OFF + wave * 4096, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp);
+        else if ((diag & 12) == 8) pt_epilogue<T, EPI, 16>(acc, smem_raw + TR_OFF + wave * 4096, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp);
         else
 #endif
-        pt_epilogue<T, EPI>(acc, (const uint16_t*)(smem_raw + BIAS_OFF + tp * 512), smem_raw + TR_OFF + wj * 4096, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp);
+        pt_epilogue<T, EPI>(acc, smem_raw + TR_OFF + wave * 4096, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp);
         __builtin_amdgcn_sched_barrier(0);
         PT_STAMP(7);
 #pragma unroll
@@ -1216,10 +1213,8 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         ++tstamp;
 #endif
         jc += nslots;
-        tp ^= 1;
         if (jc >= njobs) break;
     }
-    if (!grpB) __builtin_amdgcn_s_barrier();           // A matches B's extra barrier
 #undef PT_STAMP
 }
 
@@ -1509,7 +1504,7 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
 #if ATLAS_TUNING
                 if (g_pt_stamp_nth > 0 && ++g_pt_launches != g_pt_stamp_nth) dbg = nullptr;
 #endif
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 128 * 1024 + 4 * 4096 + 1024, stream, A, Wp, bp, R, C, VT, cu, n, tokinfo, Np, K, Lp, g_gemm_diag, dbg);
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 160 * 1024, stream, A, Wp, bp, R, C, VT, cu, n, tokinfo, Np, K, Lp, g_gemm_diag, dbg);
             };
             if constexpr (EPI == 3) {        // QKV projection: q | k columns -> [M, 1536], then the v columns -> V^T
                 go_pt(gemm_pt_kernel<T, 3>, W, bias, 2 * HID);

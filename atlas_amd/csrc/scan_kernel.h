@@ -30,6 +30,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define QCHUNK 64                // queries per slab pass (4 MFMA column groups of 16)
 #define QROW_U4 98               // uint4 per query row of the LDS image: 96 of data + 2 of padding
 #define QIMG_U4 (QCHUNK * QROW_U4)   // 100 352 bytes
+// Every in-kernel wait for another workgroup is bounded in WALL-CLOCK time (100 MHz ticks): 40 us per hop, ten times what a hop takes when
+// all workgroups are resident (~3 us). A workgroup that is not running yet (CUs held by another stream's kernel) then costs the others 40 us
+// and a looser threshold, not milliseconds (the bound used to be 4 000 polls, and a poll under load is a ~1.5 us round trip)
+#define ATLAS_SPIN_TICKS 4000ull
 
 static __device__ __forceinline__ float neg_inf() { return bits_f32(0xff800000u); }
 static __device__ __forceinline__ float pos_inf() { return bits_f32(0x7f800000u); }
@@ -383,9 +387,10 @@ scan_kernel(const ScanParams p) {
         if (wave == NW - 1) {
             unsigned long long g = 0ull;
             const bool want = lane < p.nq;
-            for (int spin = 0; spin < 4000; ++spin) {
+            for (const unsigned long long spin_end = wall_clock64() + ATLAS_SPIN_TICKS; ; ) {
                 if (want && (g >> 32) == 0ull) g = __hip_atomic_load(gran + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__builtin_amdgcn_ballot_w64(want && (g >> 32) == 0ull) == 0ull) break;
+                if (wall_clock64() >= spin_end) break;
                 __builtin_amdgcn_s_sleep(2);
             }
             s_theta[lane] = want ? ((g >> 32) != 0ull ? bits_f32((uint32_t)g) : neg_inf()) : pos_inf();
@@ -521,7 +526,7 @@ scan_kernel(const ScanParams p) {
             if ((int)blockIdx.x < p.nq) {                  // this workgroup derives the threshold of query blockIdx.x
                 const int qq = blockIdx.x;
                 unsigned long long g[4] = {0ull, 0ull, 0ull, 0ull};
-                for (int spin = 0; spin < 4000; ++spin) {
+                for (const unsigned long long spin_end = wall_clock64() + ATLAS_SPIN_TICKS; ; ) {
                     bool missing = false;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -532,6 +537,7 @@ scan_kernel(const ScanParams p) {
                         }
                     }
                     if (__builtin_amdgcn_ballot_w64(missing) == 0ull) break;
+                    if (wall_clock64() >= spin_end) break;
                     __builtin_amdgcn_s_sleep(2);
                 }
                 float v[4];
@@ -543,9 +549,10 @@ scan_kernel(const ScanParams p) {
             }
             unsigned long long g = 0ull;
             const bool want = lane < p.nq;
-            for (int spin = 0; spin < 4000; ++spin) {
+            for (const unsigned long long spin_end = wall_clock64() + ATLAS_SPIN_TICKS; ; ) {
                 if (want && (uint32_t)(g >> 32) != tag) g = __hip_atomic_load(gran + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__builtin_amdgcn_ballot_w64(want && (uint32_t)(g >> 32) != tag) == 0ull) break;
+                if (wall_clock64() >= spin_end) break;
                 __builtin_amdgcn_s_sleep(2);
             }
             s_theta[lane] = want ? ((uint32_t)(g >> 32) == tag ? bits_f32((uint32_t)g) : neg_inf()) : pos_inf();

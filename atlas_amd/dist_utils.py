@@ -2,8 +2,8 @@
 
 Replaces the hot-path use of src/dist_utils.py (varsize_all_gather :46-69, varsize_gather :72-99,
 get_varsize :102-113). The reference issues 3 + 4*W collectives per search_knn call (SURVEY §2.3
-C1-C5); here a search is: one size all_gather + one padded fp16 query all_gather (C1+C2, C3 is
-redundant and dropped), one all_gather of packed (score,id) candidates (replaces C4+C5), and a
+C1-C5); here a search is: ONE fixed-size all_gather of [batch size | padded fp16 queries] (C1+C2 in one collective and one host
+sync, C3 is redundant and dropped), one all_gather of packed (score,id) candidates (replaces C4+C5), and a
 personalised exchange of the winning passages (every rank receives the k winners of ITS OWN queries
 only; no text collective at all with a node-local passage store attached).
 
@@ -33,31 +33,39 @@ def barrier() -> None:
         dist.barrier()
 
 
+_QUERY_CAP = 64          # rows per rank of the fixed-size query collective; grows (on every rank alike) when a batch exceeds it
+
+
 @torch.no_grad()
 def all_gather_queries(queries: torch.Tensor) -> Tuple[torch.Tensor, List[int]]:
     """(b_r, d) queries of any float dtype -> ((B, d) fp16 of all ranks in rank order, [b_0..b_{W-1}]).
 
-    fp16 on the wire: the scan casts with `.half()` anyway (src/index.py:117), so gathering the
-    fp32 originals (reference C2) moves twice the bytes for the same result.
+    ONE collective and ONE host sync per call (the reference: a size all-gather with W `.item()` syncs, then the padded fp32 queries,
+    src/dist_utils.py:46-69): every rank sends a fixed-size block [header row | cap query rows]; the header carries its batch size as
+    an int32. `cap` is process state that only grows: a batch beyond it is noticed by every rank in the same gathered headers, and all
+    of them repeat the call once with the larger block. fp16 on the wire: the scan casts with `.half()` anyway (src/index.py:117), so
+    gathering the fp32 originals moves twice the bytes for the same result.
     """
+    global _QUERY_CAP
     q16 = queries.to(torch.float16)
     if not is_initialized():
         return q16, [q16.shape[0]]
     W = dist.get_world_size()
-    size = torch.tensor([q16.shape[0]], device=q16.device, dtype=torch.int64)
-    sizes = [torch.zeros_like(size) for _ in range(W)]
-    dist.all_gather(sizes, size)
-    sizes = [int(s.item()) for s in sizes]
-    mx = max(sizes)
-    d = q16.shape[1]
-    padded = q16
-    if q16.shape[0] != mx:
-        padded = torch.zeros((mx, d), dtype=torch.float16, device=q16.device)
-        padded[: q16.shape[0]] = q16
-    out = [torch.empty((mx, d), dtype=torch.float16, device=q16.device) for _ in range(W)]
-    dist.all_gather(out, padded.contiguous())
-    allq = torch.cat([o[:n] for o, n in zip(out, sizes)], dim=0)
-    return allq, sizes
+    b, d = q16.shape
+    while True:
+        cap = _QUERY_CAP
+        block = torch.zeros((cap + 1, d), dtype=torch.float16, device=q16.device)
+        block[0].view(torch.int32)[0] = b
+        block[1 : 1 + min(b, cap)] = q16[:cap]
+        out = torch.empty((W * (cap + 1), d), dtype=torch.float16, device=q16.device)
+        dist.all_gather_into_tensor(out, block)
+        out = out.view(W, cap + 1, d)
+        sizes = out[:, 0].contiguous().view(torch.int32)[:, 0].tolist()          # the one host sync
+        if max(sizes) <= cap:
+            break
+        _QUERY_CAP = (max(sizes) + 63) // 64 * 64                                    # same decision on every rank: same headers
+    allq = torch.cat([out[r, 1 : 1 + n] for r, n in enumerate(sizes)], dim=0)
+    return allq, [int(n) for n in sizes]
 
 
 @torch.no_grad()

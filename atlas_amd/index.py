@@ -89,6 +89,7 @@ class HipDistributedIndex(object):
         self._pmax_version = None              # torch version counter of the slab when _pmax was measured
         self._ws = None
         self._ws_exact = None
+        self._last_packed = None
         self._gid_mode = "round_robin"  # how local rows map to global passage ids
         self._gid_offset = 0
         self._gid_bounds = None         # contiguous mode: cumulative shard sizes of all ranks
@@ -286,9 +287,11 @@ class HipDistributedIndex(object):
                                       out_i.data_ptr(), ws.data_ptr(), ws.numel(), stream), "atlas_exact_topk")
         return out_s, out_i
 
-    def _local_topk(self, q: torch.Tensor, k: int):
+    def _local_topk(self, q: torch.Tensor, k: int, pack=None):
         """Fused scan + top-k over this shard. Returns device (scores fp16 [B,k], rows int64 [B,k])
         and their host copies (numpy), after the status word has been checked.
+        pack = (id_mul, id_add): the merge kernel also emits the winners as cross-shard packed candidates (one launch less in front of
+        the all-gather); they are left in `self._last_packed` ((B, k) int64, device), or None when a query took another path.
 
         Protocol (include/atlas_hip.h): the scan certifies its pruning margin with an upper bound
         on the row norms; if a larger row is met the call is repeated once with the measured
@@ -299,6 +302,7 @@ class HipDistributedIndex(object):
         B = q.shape[0]
         if q.device != self._slab.device:
             q = q.to(self._slab.device)
+        self._last_packed = None
         if B == 0:      # an empty batch (atlas.py:106 builds one; ranks with no queries still take part in the collectives)
             s = torch.empty((0, k), dtype=torch.float16, device=q.device)
             i = torch.empty((0, k), dtype=torch.int64, device=q.device)
@@ -345,10 +349,13 @@ class HipDistributedIndex(object):
         out = torch.empty(total, dtype=torch.uint8, device=q.device)
         stream = torch.cuda.current_stream(q.device).cuda_stream
         base = out.data_ptr()
+        packed = torch.empty((B, k), dtype=torch.int64, device=q.device) if pack is not None else None
+        id_mul, id_add = pack if pack is not None else (1, 0)
         reruns = 0
         while True:
-            rc = L.atlas_scan_topk_flags(q.data_ptr(), code, self._slab.data_ptr(), N, B, d, k, float(self._pmax),
-                                         base + off_s, base + off_i, base, ws.data_ptr(), ws.numel(), stream, None, None, call_flags)
+            rc = L.atlas_scan_topk_pack(q.data_ptr(), code, self._slab.data_ptr(), N, B, d, k, float(self._pmax),
+                                        base + off_s, base + off_i, base, ws.data_ptr(), ws.numel(), stream, None, None, call_flags,
+                                        int(id_mul), int(id_add), packed.data_ptr() if packed is not None else None)
             if rc != 0:
                 # a launch that failed half-way may have left the workspace's per-call state (tile-pool ticket, flags) behind: the
                 # next search starts from a fresh zero-filled one
@@ -390,6 +397,7 @@ class HipDistributedIndex(object):
             rows.index_copy_(0, sel_t, ei)
             h_scores[sel] = es.cpu().numpy()
             h_rows[sel] = ei.cpu().numpy()
+        self._last_packed = packed if n_fb == 0 else None        # (exact-path rows are packed by the caller)
         self.last_search_stats = {
             "path": "scan", "reruns": reruns, "fallback_queries": n_fb, "pmax": self._pmax, "pmax_trusted": bool(call_flags & _lib.SCAN_TRUST_PMAX),
             "candidates": int(st[_lib.ST_N_CANDIDATES]), "rescored": int(st[_lib.ST_N_RESCORED]),
@@ -418,15 +426,18 @@ class HipDistributedIndex(object):
         bounds = np.cumsum([0] + list(allsizes))
         if topk > self._slab.shape[0]:
             raise RuntimeError(f"selected index k out of range (topk={topk} > {self._slab.shape[0]} passages in shard)")
-        scores_d, rows_d, scores, rows = self._local_topk(allqueries, topk)
-        if not dist_utils.is_initialized():
+        distributed = dist_utils.is_initialized()
+        scores_d, rows_d, scores, rows = self._local_topk(allqueries, topk, pack=self._gid_params() if distributed else None)
+        if not distributed:
             doc_map = self.doc_map                       # (tolist() converts in C: half the host time of per-element int() / float())
             docs = [[doc_map[x] for x in sample] for sample in rows.tolist()]
             return docs, scores.astype(np.float64).tolist()
 
         rank = dist_utils.get_rank()
         id_mul, id_add = self._gid_params()
-        packed = self._pack(scores_d, rows_d, scores, rows, id_mul, id_add)             # (B, k) int64, device
+        packed = self._last_packed                                                       # straight from the merge kernel, or ...
+        if packed is None:
+            packed = self._pack(scores_d, rows_d, scores, rows, id_mul, id_add)         # (B, k) int64, device
         gathered = dist_utils.all_gather_packed(packed)                                  # (W, B, k): ONE collective
         merged = self._merge(gathered, topk)                                             # (B, k) numpy, W*k -> k per query
         m_scores, m_gid = unpack_candidates_host(merged)

@@ -6,8 +6,8 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" = one pass of the hot path over one batch of 64 synthetic queries with everything resident in HBM:
-  C-ABI atlas_scan_topk (prep + fused MFMA scan/top-k + merge/exact-rescore kernels) on this rank's shard,
-  and for N > 1 the cross-rank step: pack -> ONE RCCL all-gather of (score,id) pairs -> W*k->k merge kernel.
+  C-ABI atlas_scan_topk (fused MFMA scan/top-k + merge/exact-rescore kernels) on this rank's shard,
+  and for N > 1 the cross-rank step: ONE RCCL all-gather of the packed (score,id) pairs the merge emitted -> W*k->k merge kernel.
 Workload: a fixed corpus of --passages (default 32M = enwiki-dec2018, BASELINE.json north_star target; fits one
 GPU: 49.2 GB) rows x 768 fp16, round-robin sharded over the N ranks (strong scaling: total work fixed),
 64 queries, top-40. `value` = 64 * K / (max-over-ranks wall time of K steps), barrier + synchronize on both sides.
@@ -166,12 +166,13 @@ def main():
         ee = ev[1].cuda_event if ev else None
         # the call of HipDistributedIndex._local_topk: pmax was measured by the product call above (atlas_slab_pmax) and nothing has
         # written to the slab since, so the scan takes it as certified (ATLAS_SCAN_TRUST_PMAX) instead of re-measuring every row's norm
-        rc = L.atlas_scan_topk_flags(q.data_ptr(), _lib.DT_F32, slab.data_ptr(), rows, B, D, k, pmax, out_s.data_ptr(),
-                                     out_i.data_ptr(), out_st.data_ptr(), ws.data_ptr(), ws.numel(), stream, eb, ee, _lib.SCAN_TRUST_PMAX)
+        # (N > 1: the merge kernel emits the packed (score, global id) pairs itself -- global id = row * world + rank -- so the scan is followed
+        #  by the all-gather directly)
+        rc = L.atlas_scan_topk_pack(q.data_ptr(), _lib.DT_F32, slab.data_ptr(), rows, B, D, k, pmax, out_s.data_ptr(),
+                                    out_i.data_ptr(), out_st.data_ptr(), ws.data_ptr(), ws.numel(), stream, eb, ee, _lib.SCAN_TRUST_PMAX,
+                                    world, rank, packed.data_ptr() if world > 1 else None)
         assert rc == 0, rc
         if world > 1:
-            rc = L.atlas_pack_candidates(out_s.data_ptr(), out_i.data_ptr(), B * k, world, rank, packed.data_ptr(), stream)
-            assert rc == 0, rc
             if backend == "nccl":
                 dist.all_gather_into_tensor(gathered, packed)          # ONE collective: 8*B*k bytes per rank
             else:                                                       # gloo logic check: stage through the host

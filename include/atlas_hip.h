@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ATLAS_ABI_VERSION 6
+#define ATLAS_ABI_VERSION 7
 
 #define ATLAS_WS_STATE_BYTES (1u << 20)   /* head of a scan workspace that must be zero before the workspace's first use */
 
@@ -131,6 +131,16 @@ int atlas_scan_topk_flags(const void* q, int q_dtype, const void* slab_f16, int6
                        int k, float pmax_hint, void* out_score_f16, int64_t* out_idx,
                        int32_t* out_status, void* ws, size_t ws_bytes, void* stream,
                        void* ev_scan_begin, void* ev_scan_end, int flags);
+
+/* The same call that ALSO emits the winners as cross-shard packed candidates (see atlas_pack_candidates below): out_packed [B x k]
+ * uint64, global_id = row * id_mul + id_add, padding entries 0. The distributed search_knn (src/index.py:134-151) hands these straight
+ * to its one all-gather: no pack kernel between the merge and the collective. out_packed may be NULL (= atlas_scan_topk_flags).
+ * Queries flagged ATLAS_Q_FALLBACK carry no valid packed row: the caller packs what atlas_exact_topk returns for them. */
+int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64_t N, int B, int d,
+                         int k, float pmax_hint, void* out_score_f16, int64_t* out_idx,
+                         int32_t* out_status, void* ws, size_t ws_bytes, void* stream,
+                         void* ev_scan_begin, void* ev_scan_end, int flags,
+                         int64_t id_mul, int64_t id_add, uint64_t* out_packed);
 
 /* ---- search: exact reference-order path (any d, any k <= 2048) --------------------
  * Same contract and same canonical result as atlas_scan_topk, computed without MFMA:

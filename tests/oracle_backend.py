@@ -7,7 +7,8 @@ import torch
 from oracle import oracle
 
 
-def oracle_local_topk(self, q, k):
+def oracle_local_topk(self, q, k, pack=None):
+    self._last_packed = None                  # (the host packing path is what these tests exercise)
     slab = self._slab.cpu().numpy()
     q16 = q.detach().cpu().to(torch.float16).numpy()
     s, i = oracle.search(q16, slab, k)

@@ -87,10 +87,12 @@ def _worker(rank, W, port, N, batches, k, out_dir, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("W,batches,mode", [(2, (3, 5), "round_robin"), (3, (4, 0, 2), "round_robin"), (2, (2, 2), "contiguous")])
+# (70 queries on one rank: beyond the 64 rows of the fixed-size query collective -- every rank sees it in the headers and repeats the call)
+@pytest.mark.parametrize("W,batches,mode", [(2, (3, 5), "round_robin"), (3, (4, 0, 2), "round_robin"), (2, (2, 2), "contiguous"),
+                                            (2, (70, 1), "round_robin")])
 def test_distributed_search_equals_union(W, batches, mode, tmp_path, oracle_mod):
     N, k = 1500, 12
-    port = 29600 + W * 7 + len(mode)
+    port = 29600 + W * 7 + len(mode) + sum(batches)
     mp.spawn(_worker, args=(W, port, N, batches, k, str(tmp_path), mode), nprocs=W, join=True)
     P = synth.passages_f16(N, 768, 61)
     Q = synth.queries_f32(sum(batches), 768, 62)

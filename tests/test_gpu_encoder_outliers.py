@@ -7,7 +7,9 @@ the set is synthetic; a real `facebook/contriever` directory is used when one ex
 Tolerances (stated per pooling, fp16 model): the HIP encoder is held to the torch restatement run in fp16 on the same GPU (both round to
 fp16 at the same places: the difference is summation order) and the fp32 restatement is reported next to it -- with outliers the fp16 MODEL
 itself moves away from the fp32 one by more than any kernel detail, and that distance is the yardstick:
-    |hip - ref_fp16| <= max(3e-3 * max|ref|, 0.5 * max|ref_fp16 - ref_fp32|)   average / sqrt / cls pooling
+    per dimension d (outlier dimensions are ~300 x the ordinary ones; scale_d = max_n |ref_fp32[n, d]|, floored at 5 % of the median):
+    max_d max_n |hip - ref_fp16| / scale_d <= max(4e-3, 0.5 * the same measure of ref_fp16 - ref_fp32)      average / sqrt / cls pooling
+    and cosine >= 0.9995 against the fp32 model over the ordinary dimensions
 """
 import os
 
@@ -46,10 +48,8 @@ def _pair(layers, pooling, seed=21):
     from atlas_amd import retrievers
     from oracle.contriever_ref import BertConfigLite, ContrieverRef
 
-    ref32 = trained_like(ContrieverRef(BertConfigLite(num_hidden_layers=layers), seed=seed, pooling=pooling).randomize_affine()).eval()
-    cfg = retrievers.BertConfigLite(num_hidden_layers=layers)
-    cfg.pooling = pooling
-    mine = retrievers.Contriever(cfg)
+    ref32 = trained_like(ContrieverRef(BertConfigLite(num_hidden_layers=layers), seed=seed).randomize_affine()).eval()
+    mine = retrievers.Contriever(retrievers.BertConfigLite(num_hidden_layers=layers), pooling=pooling)
     mine.load_state_dict(ref32.state_dict(), strict=True)
     return ref32, mine.half().eval().cuda().requires_grad_(False)
 
@@ -74,18 +74,21 @@ def test_outlier_weights(pooling, n, L, layers, gpu_index_cls):
     ref32, mine = _pair(layers, pooling)
     ids, mask = _batch(n, L, seed=n + L)
     ids, mask = ids.cuda(), mask.cuda()
-    want32 = ref32.cuda()(ids, mask).float().cpu()
-    want16 = copy.deepcopy(ref32).half().cuda()(ids, mask).float().cpu()
+    want32 = ref32.cuda()(ids, mask, pooling=pooling).float().cpu()
+    want16 = copy.deepcopy(ref32).half().cuda()(ids, mask, pooling=pooling).float().cpu()
     got = mine(ids, mask).float().cpu()
     assert torch.isfinite(got).all() and torch.isfinite(want16).all(), "overflow / NaN with outlier weights"
-    scale = want32.abs().max()
-    model_gap = (want16 - want32).abs().max()
-    err16 = (got - want16).abs().max()
-    err32 = (got - want32).abs().max()
-    cos = torch.nn.functional.cosine_similarity(got, want32, dim=1).min()
-    print(f"pooling={pooling} n={n} L={L} layers={layers}: max|e| = {scale:.2f}; hip vs torch-fp16 {err16 / scale:.2e}, hip vs torch-fp32 {err32 / scale:.2e}, "
-          f"torch-fp16 vs torch-fp32 {model_gap / scale:.2e}; min cos vs fp32 = {cos:.6f}")
-    assert err16 <= max(3e-3 * scale, 0.5 * model_gap), (float(err16 / scale), float(model_gap / scale))
+    # per DIMENSION: the outlier dimensions are ~300 x the others, a global max|e| would hide everything that happens in the ordinary ones
+    scale = want32.abs().amax(dim=0).clamp_min(0.05 * want32.abs().amax(dim=0).median())
+    model_gap = ((want16 - want32).abs().amax(dim=0) / scale).max()
+    err16 = ((got - want16).abs().amax(dim=0) / scale).max()
+    err32 = ((got - want32).abs().amax(dim=0) / scale).max()
+    ordinary = scale < 10 * scale.median()
+    cos = torch.nn.functional.cosine_similarity(got[:, ordinary], want32[:, ordinary], dim=1).min()
+    print(f"pooling={pooling} n={n} L={L} layers={layers}: max|e| = {want32.abs().max():.1f} (median dimension {scale.median():.2f}); per-dimension relative "
+          f"error: hip vs torch-fp16 {err16:.2e}, hip vs torch-fp32 {err32:.2e}, torch-fp16 vs torch-fp32 {model_gap:.2e}; "
+          f"min cos vs fp32 over the {int(ordinary.sum())} ordinary dimensions = {cos:.6f}")
+    assert err16 <= max(4e-3, 0.5 * model_gap), (float(err16), float(model_gap))
     assert cos >= 0.9995
 
 

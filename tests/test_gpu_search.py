@@ -522,3 +522,50 @@ def test_other_exponent_buckets(scale, gpu_index_cls, oracle_mod):
     es, ei = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, k)
     parity.assert_identical(s, i, es, ei, f"scale={scale}")
     assert idx.last_search_stats["max_err_over_eps"] < 0.25
+
+
+def test_search_beside_a_kernel_that_holds_part_of_the_chip(gpu_index_cls):
+    """The scan launches one workgroup per CU and its workgroups exchange thresholds inside the kernel: what if another
+    stream's kernel owns CUs, so that some scan workgroups start late? Every in-kernel wait is bounded in wall-clock time (40 us a hop) and a
+    missing partner only loosens a threshold: the result must stay bit-exact with no query sent to the exact path. The time is measured and
+    reported; with static row ranges a workgroup that cannot start until a CU frees up costs about one more range time (a ~2x scan for
+    any number of held CUs >= 1), so the bound asserted here is 3x -- not the 1.3x a range-stealing scan would meet."""
+    import ctypes
+    import time
+
+    from atlas_amd import _lib
+
+    T = _lib.lib(tuning=True)
+    T.atlas_tune_spin.argtypes, T.atlas_tune_spin.restype = [ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p], ctypes.c_int
+    N, B, k = 2_000_000, 64, 40
+    g = torch.Generator(device="cuda").manual_seed(77)
+    slab = torch.randn((N, 768), generator=g, device="cuda")
+    slab = (slab / slab.norm(dim=1, keepdim=True)).half()
+    q = torch.randn((B, 768), generator=g, device="cuda")
+    idx = gpu_index_cls()
+    idx._set_slab(slab)
+    s0, i0 = idx._compute_scores_and_indices(q, k)
+    s0, i0 = s0.clone(), i0.clone()
+
+    def timed(n=5):
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            s, i = idx._compute_scores_and_indices(q, k)
+            ts.append(time.perf_counter() - t)
+            assert torch.equal(s, s0) and torch.equal(i, i0), "result changed under contention"
+            assert idx.last_search_stats["fallback_queries"] == 0, idx.last_search_stats
+        return float(np.median(ts))
+
+    quiet = timed()
+    side = torch.cuda.Stream()
+    report = []
+    for held in (8, 32):
+        assert T.atlas_tune_spin(held, 60_000, side.cuda_stream) == 0      # holds `held` CUs for 60 ms
+        time.sleep(0.003)
+        busy = timed()
+        side.synchronize()
+        report.append((held, busy / quiet))
+    print("synchronous search at 2M rows: quiet %.3f ms; " % (quiet * 1e3) + "; ".join(f"{h} CUs held: {r:.2f}x" for h, r in report))
+    assert all(r < 3.0 for _, r in report), report
