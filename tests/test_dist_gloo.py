@@ -62,7 +62,8 @@ def _worker(rank, W, port, N, batches, k, out_dir, mode):
         docs, scores = idx.search_knn(Q, k)
     du0.exchange_objects = real_exchange
     # the text exchange is personalised: a rank receives the k winners of each of ITS OWN queries and nothing else
-    assert received == [batches[rank] * k] * 2, (received, batches[rank] * k)
+    # (a passage that wins for several of the rank's queries travels once: only the small batches are sure to have k distinct winners each)
+    assert received[0] == received[1] <= batches[rank] * k and (batches[rank] > 8 or received[0] == batches[rank] * k), (received, batches[rank] * k)
     # the same search with a node-local passage store attached: no text collective, same documents
     from atlas_amd.passage_store import PassageStore
     spath = os.path.join(out_dir, "store_" + mode)
