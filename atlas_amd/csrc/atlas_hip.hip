@@ -912,6 +912,17 @@ void allow_lds(KernelT kern) {   // opt in to the full 160 KiB of LDS (idempoten
 
 }  // namespace
 
+#if ATLAS_TUNING
+// a kernel that does nothing but HOLD `wgs` CUs for `usec` microseconds (1024 threads + all of the LDS per workgroup: nothing else fits
+// beside it), for the contention test: what happens to a search when another stream owns part of the chip
+__global__ void __launch_bounds__(1024) atlas_spin_kernel(unsigned long long ticks, int* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned long long until = wall_clock64() + ticks;
+    while (wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
+    if (ticks == 0ull && smem[threadIdx.x] == 77) *sink = 1;
+}
+#endif
+
 extern "C" {
 
 // test hook, deliberately not in include/atlas_hip.h: the device's double -> fp16 conversions, elementwise
@@ -940,14 +951,6 @@ void atlas_tune_scan_plan(int64_t N, int k, int cus, int64_t* out) {
     out[7] = scan_plan_supported(pl) ? 1 : 0;
 }
 void atlas_tune_set_merge_stamps(unsigned long long* p) { g_merge_dbg = p; }
-// a kernel that does nothing but HOLD `wgs` CUs for `usec` microseconds (1024 threads + all of the LDS per workgroup: nothing else fits
-// beside it), for the contention test: what happens to a search when another stream owns part of the chip
-__global__ void __launch_bounds__(1024) atlas_spin_kernel(unsigned long long ticks, int* sink) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const unsigned long long until = wall_clock64() + ticks;
-    while (wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
-    if (ticks == 0ull && smem[threadIdx.x] == 77) *sink = 1;
-}
 int atlas_tune_spin(int wgs, long long usec, void* stream) {
     allow_lds(atlas_spin_kernel);
     hipLaunchKernelGGL(atlas_spin_kernel, dim3(wgs), dim3(1024), 160 * 1024, (hipStream_t)stream, (unsigned long long)usec * 100ull, (int*)nullptr);
