@@ -151,8 +151,7 @@ static __device__ __forceinline__ float wave_sum(float x) {
 // ---- the reference's LayerNorm on one 768-vector held 12 per lane ----
 // The lane's values are elements 8 l .. 8 l + 7 and 512 + 4 l .. 512 + 4 l + 3 of the row: one 16-byte and one 8-byte access per lane, both
 // contiguous across the wave (round 2 held element 64 i + l: twelve 2-byte accesses). This mapping and the order the statistics are summed
-// in (the lane's twelve values in that order, then the xor butterfly) are shared by every LayerNorm here -- embeddings, the stand-alone
-// kernel, the one folded into the persistent GEMM -- so all of them give the same bits.
+// in (the lane's twelve values in that order, then the xor butterfly) are shared by every LayerNorm here, so all of them give the same bits.
 template <class T> static __device__ __forceinline__ void ln_load12(const typename T::elem* __restrict__ row, const int lane, float (&x)[12]) {
     if constexpr (sizeof(typename T::elem) == 2) {
         const uint4 a = *(const uint4*)(row + 8 * lane);
@@ -274,27 +273,6 @@ ln_kernel(const typename T::elem* __restrict__ in, const int* __restrict__ Tdev,
     const int lane = threadIdx.x & 63;
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= *Tdev) return;
-    float x[12], w[12], b[12], o[12];
-    ln_load12<T>(in + (size_t)t * HID, lane, x);
-    ln_load12<T>(lnw, lane, w);
-    ln_load12<T>(lnb, lane, b);
-    layer_norm_768<T>(x, w, b, eps, o);
-    ln_store12<T>(out + (size_t)t * HID, lane, o);
-}
-
-// the rows the persistent GEMM did NOT normalise itself (gemm_pt_kernel<T, 2, true>): token tiles beyond the full rounds of their XCD's
-// `nslots` workgroups -- none for a batch whose token tiles divide evenly (512 x 128 tokens on 256 CUs), the last few of a ragged one
-template <class T>
-__global__ void __launch_bounds__(256)
-ln_tail_kernel(const typename T::elem* __restrict__ in, const int* __restrict__ Tdev, int nslots, const typename T::elem* __restrict__ lnw,
-               const typename T::elem* __restrict__ lnb, float eps, typename T::elem* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t M = *Tdev;
-    if (t >= M) return;
-    const int tt = (int)(t >> 8), xcd = tt & 7, ntt = (int)((M + 255) >> 8);
-    const int ntt_x = ntt > xcd ? (ntt - xcd + 7) >> 3 : 0;
-    if ((tt >> 3) < (ntt_x / nslots) * nslots) return;                // folded into the GEMM
     float x[12], w[12], b[12], o[12];
     ln_load12<T>(in + (size_t)t * HID, lane, x);
     ln_load12<T>(lnw, lane, w);
@@ -1003,82 +981,17 @@ static __device__ __forceinline__ void pt_epilogue(const f4 (&acc)[8][4], unsign
     }
 }
 
-// The LayerNorm that follows out-proj and FFN-2 (BertSelfOutput / BertOutput, modeling_bert.py:382-387, 461-466), folded into the kernel:
-// one wave normalises 32 of the 256 token rows the workgroup has just completed (u read back with L1-bypassing loads: the lines were
-// written by this very CU, a kernel boundary's worth of visibility is not needed), x written. Same arithmetic as ln_kernel.
-template <class T>
-static __device__ __forceinline__ void pt_layer_norm(const typename T::elem* __restrict__ U, typename T::elem* __restrict__ X, const int64_t m0, const int64_t M,
-                                                     const typename T::elem* __restrict__ lnw, const typename T::elem* __restrict__ lnb, const float eps, const int wave) {
-    typedef typename T::elem E;
-    const int lane = pt_fresh_lane();
-    float w[12], b[12];
-    ln_load12<T>(lnw, lane, w);
-    ln_load12<T>(lnb, lane, b);
-    int64_t rem = (M - m0) * (int64_t)HID * 2;
-    if (rem > 0xfffffff0ll) rem = 0xfffffff0ll;
-    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)(U + (size_t)m0 * HID), 0, (int)rem, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(X + (size_t)m0 * HID), 0, (int)rem, 0x00020000);
-    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
-    // four tokens per step; the NEXT step's rows are requested before this step's results are stored: gfx9 counts loads and stores in one
-    // vmcnt, in issue order -- a load issued behind a store cannot be waited for without waiting for the store's round trip as well
-    auto fetch = [&](pt_u4 (&a)[4], u2v (&c)[4], const int i0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {                                   // rows past M read as zeros and are dropped on store
-            const int vo = ((wave * 32 + i0 + i) * HID) * 2;
-            a[i] = __builtin_amdgcn_raw_buffer_load_b128(ru, vo + 16 * lane, 0, 16 /* sc1: not from this CU's L1 */);
-            c[i] = __builtin_amdgcn_raw_buffer_load_b64(ru, vo + 1024 + 8 * lane, 0, 16);
-        }
-    };
-    auto finish = [&](const pt_u4 (&a)[4], const u2v (&c)[4], const int i0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t wd[6] = {a[i][0], a[i][1], a[i][2], a[i][3], c[i][0], c[i][1]};
-            float x[12], o[12];
-#pragma unroll
-            for (int e = 0; e < 6; ++e) { x[2 * e] = T::ld((uint16_t)(wd[e] & 0xffff)); x[2 * e + 1] = T::ld((uint16_t)(wd[e] >> 16)); }
-            layer_norm_768<T>(x, w, b, eps, o);
-            pt_u4 oa; u2v oc;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) oa[e] = (uint32_t)T::st(o[2 * e]) | ((uint32_t)T::st(o[2 * e + 1]) << 16);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) oc[e] = (uint32_t)T::st(o[8 + 2 * e]) | ((uint32_t)T::st(o[9 + 2 * e]) << 16);
-            const int vo = ((wave * 32 + i0 + i) * HID) * 2;
-            __builtin_amdgcn_raw_buffer_store_b128(oa, rx, vo + 16 * lane, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(oc, rx, vo + 1024 + 8 * lane, 0, 0);
-        }
-    };
-    pt_u4 a0[4], a1[4]; u2v c0[4], c1[4];
-    fetch(a0, c0, 0);
-#pragma unroll 1
-    for (int i0 = 0; i0 < 32; i0 += 8) {
-        fetch(a1, c1, i0 + 4);
-        __builtin_amdgcn_sched_barrier(0);
-        finish(a0, c0, i0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i0 + 8 < 32) fetch(a0, c0, i0 + 8);
-        __builtin_amdgcn_sched_barrier(0);
-        finish(a1, c1, i0 + 4);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 // EPI 1: C = dt(gelu(dt(acc + bias)))   2: C = dt(dt(acc + bias) + R)   3: C = dt(acc + bias)   4: V^T = dt(acc + bias), transposed per passage
 // (the QKV projection is two launches: its q | k columns with EPI 3 into [M, 1536], its v columns with EPI 4 into V^T)
-// LNF (EPI 2, N = 768): X = LayerNorm(C) is produced here too. A workgroup then takes WHOLE token tiles -- the three column tiles of one
-// 256-token tile one after the other -- and normalises the tile's rows behind the third; no other workgroup is involved. Token tiles that
-// do not fill a round of the XCD's workgroups (ragged batches) are still split by column tile, so that the last round costs one tile time
-// and not three; their rows are left to ln_tail_kernel.
-template <class T, int EPI, bool LNF = false>
+template <class T, int EPI>
 __global__ void __launch_bounds__(512)
 gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* __restrict__ W, const typename T::elem* __restrict__ bias,
                const typename T::elem* __restrict__ R, typename T::elem* __restrict__ C, typename T::elem* __restrict__ VT,
                const int* __restrict__ cu, int n, const int2* __restrict__ tokinfo, int N, int K, int Lp,
                int diag /* tuning build only: bit 0 = no epilogue, bits 2-3 = store policy (1 nt, 2 sc1), bits 8.. = start stagger; 0 in production */,
-               unsigned long long* __restrict__ dbg /* tuning build only: 100 MHz stamps of workgroup 0 around its tile boundaries; null in production */,
-               const typename T::elem* __restrict__ lnw, const typename T::elem* __restrict__ lnb, float eps, typename T::elem* __restrict__ X /* LNF only */) {
+               unsigned long long* __restrict__ dbg /* tuning build only: 100 MHz stamps of workgroup 0 around its tile boundaries; null in production */) {
     typedef typename T::elem E;
     static_assert(sizeof(E) == 2, "16-bit dtypes only");
-    static_assert(!LNF || EPI == 2, "the folded LayerNorm follows a residual epilogue");
 #if ATLAS_TUNING
     int tstamp = 0;                                                  // tile counter of the stamps
 #define PT_STAMP(i) do { if (dbg != nullptr && blockIdx.x == 0 && tstamp < 8 && pt_fresh_lane() == 0) dbg[((int)wave * 8 + tstamp) * 16 + (i)] = wall_clock64(); } while (0)
@@ -1098,28 +1011,16 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     const int ncol = N >> 8;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
     const int ntt = (int)((M + 255) >> 8);
-    const int ntt_x = ntt > xcd ? (ntt - xcd + 7) >> 3 : 0;                 // token tiles of this XCD: xcd, xcd + 8, ...
-    // The workgroup's tiles, as steps st = 0, 1, ...: the (token tile, column tile) pairs of the XCD are dealt out round-robin, pair
-    // l = slot + st * nslots = column tile l % ncol of the XCD's token tile l / ncol. LNF: the token tiles of full rounds (the first
-    // `whole` of the XCD) are dealt out whole instead -- steps [0, nfold): token tile slot + (st / ncol) * nslots, column tile st % ncol.
-    const int whole = LNF ? (ntt_x / nslots) * nslots : 0;
-    const int nfold = LNF ? (whole / nslots) * ncol : 0;
-    const int npairs = (ntt_x - whole) * ncol;
-    const int nsteps = nfold + (slot < npairs ? (npairs - slot + nslots - 1) / nslots : 0);
-    if (nsteps == 0) return;
+    const int njobs = (ntt > xcd ? (ntt - xcd + 7) >> 3 : 0) * ncol;        // (token tile, column tile) pairs of this XCD
+    if (slot >= njobs) return;
     const int nk = K >> 6;                                                    // k-tiles of 128 bytes per tile (>= 2)
     const uint32_t K2 = (uint32_t)K * 2u;
 
-    // Operands go through buffer descriptors: W rows [n0, n0 + 256) and rows [m0, M) of the activations / the output / the residual
-    // (all SGPR arithmetic, redone where it is needed rather than carried: the kernel has no scalar registers to spare)
-    auto tile_n0 = [&](const int st) {
-        if (LNF && st < nfold) return (st % ncol) << 8;
-        return ((slot + (st - nfold) * nslots) % ncol) << 8;
-    };
-    auto tile_m0 = [&](const int st) {
-        const int unit = (LNF && st < nfold) ? slot + (st / ncol) * nslots : whole + (slot + (st - nfold) * nslots) / ncol;
-        return (int64_t)(unit * 8 + xcd) << 8;
-    };
+    // tile j of this XCD: column tile j % ncol of token tile (j / ncol) * 8 + xcd. Operands go through buffer descriptors: W rows
+    // [n0, n0 + 256) and rows [m0, M) of the activations / the output / the residual (all SGPR arithmetic, redone where it is needed
+    // rather than carried: the kernel has no scalar registers to spare)
+    auto tile_n0 = [&](const int j) { return (j % ncol) << 8; };
+    auto tile_m0 = [&](const int j) { return (int64_t)((j / ncol) * 8 + xcd) << 8; };
     auto rows_rsrc = [&](const E* base, const int64_t m0, const int ld) {      // rows [m0, M) of a [M, ld] tensor
         int64_t rem = (M - m0) * (int64_t)ld * 2;
         if (rem > 0xfffffff0ll) rem = 0xfffffff0ll;
@@ -1140,7 +1041,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     const uint32_t va = VTR ? ((uint32_t)(64 * (wave >> 1) + 32 * (wave & 1)) + perm_lane) * K2 + chb
                             : (uint32_t)(wave * 32 + (lane >> 3)) * K2 + chb;
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    auto stage = [&](const int buf, const int j, const int kt) {       // k-tile kt of the tile of step j -> stage buffer buf
+    auto stage = [&](const int buf, const int j, const int kt) {       // k-tile kt of tile j -> stage buffer buf
         const uint32_t kb = (uint32_t)kt * 128u;
         const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)tile_n0(j) * K), 0, (int)(256u * K2), 0x00020000);
         const __amdgpu_buffer_rsrc_t ra = rows_rsrc(A, tile_m0(j), K);
@@ -1170,7 +1071,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 #pragma unroll
         for (int b = 0; b < FB; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    int jc = 0;                                        // the step (tile) being multiplied
+    int jc = slot;                                     // the tile being multiplied; the next one is jc + nslots
     // EPI 2: the residual rows the epilogue adds were written a kernel or more ago and come from the Infinity Cache / HBM: ~2 us that
     // both groups used to sit out between their last MFMA and their epilogue. Three iterations before the end, right behind its own
     // wait (so the requests have a whole iteration to land before the wave waits again), every wave touches the 128 cache lines of
@@ -1212,7 +1113,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     // One iteration = one k-tile; phases as in gemm_pp_kernel. The k-tiles staged here (one and two steps on) may be the next tile's.
     auto iteration = [&](const int kt, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
-        const bool has_next = jc + 1 < nsteps;
+        const bool has_next = jc + nslots < njobs;
         u4v fw0[FA], fa0[FB], fw1[FA], fa1[FB];
         {
             const uint32_t w0 = aw0 + buf * STG, w1 = aw1 + buf * STG, a0 = aa0 + buf * STG, a1 = aa1 + buf * STG;
@@ -1234,7 +1135,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         if (LAST) PT_STAMP(1);
         if (!grpB) {                                   // A stages the k-tile after this one (after its reads: see gemm_pp_kernel)
             if (!LAST) stage(buf ^ 1, jc, kt + 1);
-            else if (has_next) stage(buf ^ 1, jc + 1, 0);
+            else if (has_next) stage(buf ^ 1, jc + nslots, 0);
         } else if (!skip_wait) {
             __builtin_amdgcn_s_waitcnt(0x0F70);        // B: its pieces of the next k-tile (issued a phase ago) have landed
         }
@@ -1246,8 +1147,8 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         if (kt == 0) PT_STAMP(9);
         if (LAST) PT_STAMP(2);
         if (grpB) {                                    // B stages two k-tiles on, into the buffer both groups have finished reading
-            if (!LAST) { if (kt + 2 < nk) stage(buf, jc, kt + 2); else if (has_next) stage(buf, jc + 1, 0); }
-            else if (has_next) stage(buf, jc + 1, 1);
+            if (!LAST) { if (kt + 2 < nk) stage(buf, jc, kt + 2); else if (has_next) stage(buf, jc + nslots, 0); }
+            else if (has_next) stage(buf, jc + nslots, 1);
         }
         if constexpr (VTR) {                           // activations as the MFMA A operand: C^T fragments, the same products in the same order
 #pragma unroll
@@ -1341,13 +1242,8 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 #if ATLAS_TUNING
         ++tstamp;
 #endif
-        if (LNF && jc < nfold && jc % ncol == ncol - 1) {  // the token tile is complete: its LayerNorm, by all eight waves
-            __builtin_amdgcn_s_waitcnt(0x0F70);            // this wave's rows of u are out ...
-            __builtin_amdgcn_s_barrier();                  // ... and everybody's
-            pt_layer_norm<T>(C, X, tile_m0(jc), M, lnw, lnb, eps, wave);
-        }
-        ++jc;
-        if (jc >= nsteps) break;
+        jc += nslots;
+        if (jc >= njobs) break;
     }
 #undef PT_STAMP
 }
@@ -1616,13 +1512,10 @@ static int encoder_device_cus() {     // CU count of the current device, asked e
     return cus;
 }
 
-// the LayerNorm behind a residual GEMM: x = LayerNorm(C). The persistent kernel folds it in; the other configurations launch ln_kernel
-template <class T> struct LnArgs { const typename T::elem* w; const typename T::elem* b; float eps; typename T::elem* x; };
-
 template <class T, int EPI>
 static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, const typename T::elem* W, const typename T::elem* bias,
                         const typename T::elem* R, typename T::elem* C, typename T::elem* VT, int64_t Mmax, const int* cu, int n,
-                        const int2* tokinfo, int N, int K, int Lp, const LnArgs<T> ln = LnArgs<T>{nullptr, nullptr, 0.f, nullptr}) {
+                        const int2* tokinfo, int N, int K, int Lp) {
     auto go = [&](auto kern, int bcol, int btok, int nthreads) {
         const size_t lds = (size_t)(bcol + btok) * 128 * 2;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1641,17 +1534,11 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
 #if ATLAS_TUNING
                 if (g_pt_stamp_nth > 0 && ++g_pt_launches != g_pt_stamp_nth) dbg = nullptr;
 #endif
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 160 * 1024, stream, A, Wp, bp, R, C, VT, cu, n, tokinfo, Np, K, Lp, g_gemm_diag, dbg,
-                                   ln.w, ln.b, ln.eps, ln.x);
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 160 * 1024, stream, A, Wp, bp, R, C, VT, cu, n, tokinfo, Np, K, Lp, g_gemm_diag, dbg);
             };
             if constexpr (EPI == 3) {        // QKV projection: q | k columns -> [M, 1536], then the v columns -> V^T
                 go_pt(gemm_pt_kernel<T, 3>, W, bias, 2 * HID);
                 go_pt(gemm_pt_kernel<T, 4>, W + (size_t)2 * HID * K, bias + 2 * HID, HID);
-            } else if constexpr (EPI == 2) {
-                if (ln.x != nullptr && N == HID) {       // + the LayerNorm that follows, folded in; ragged leftovers: ln_tail_kernel
-                    go_pt(gemm_pt_kernel<T, 2, true>, W, bias, N);
-                    hipLaunchKernelGGL(ln_tail_kernel<T>, dim3((unsigned)((Mmax + 3) / 4)), dim3(256), 0, stream, C, cu + n, (int)(grid / 8), ln.w, ln.b, ln.eps, ln.x);
-                } else go_pt(gemm_pt_kernel<T, 2>, W, bias, N);
             } else {
                 go_pt(gemm_pt_kernel<T, EPI>, W, bias, N);
             }
@@ -2142,19 +2029,15 @@ int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int
             else if (Lp <= 256) att(attention_kernel<T, 16>);
             else att(attention_kernel<T, 32>);
         }
-        const bool fold_ln = (cfg == 9) && sizeof(E) == 2;         // the persistent kernel normalises its own rows
-        launch_gemm<T, 2>(cfg, stream, ctx, (const E*)ly.o_w, (const E*)ly.o_b, x, u, (E*)nullptr, M, cu, n, tokinfo, HID, HID, Lp,
-                          LnArgs<T>{(const E*)ly.ln1_w, (const E*)ly.ln1_b, w->eps, fold_ln ? x : (E*)nullptr});
-        if (!fold_ln)
-            hipLaunchKernelGGL(ln_kernel<T>, dim3(tok_blocks), dim3(256), 0, stream, u, cu + n, (const E*)ly.ln1_w, (const E*)ly.ln1_b,
-                               w->eps, x);
+        launch_gemm<T, 2>(cfg, stream, ctx, (const E*)ly.o_w, (const E*)ly.o_b, x, u, (E*)nullptr, M, cu, n, tokinfo, HID, HID, Lp);
+        hipLaunchKernelGGL(ln_kernel<T>, dim3(tok_blocks), dim3(256), 0, stream, u, cu + n, (const E*)ly.ln1_w, (const E*)ly.ln1_b,
+                           w->eps, x);
         launch_gemm<T, 1>(cfg, stream, x, (const E*)ly.ff1_w, (const E*)ly.ff1_b, (const E*)nullptr, hbuf, (E*)nullptr, M, cu, n,
                           tokinfo, 4 * HID, HID, Lp);
         launch_gemm<T, 2>(cfg, stream, hbuf, (const E*)ly.ff2_w, (const E*)ly.ff2_b, x, u, (E*)nullptr, M, cu, n, tokinfo, HID,
-                          4 * HID, Lp, LnArgs<T>{(const E*)ly.ln2_w, (const E*)ly.ln2_b, w->eps, fold_ln ? x : (E*)nullptr});
-        if (!fold_ln)
-            hipLaunchKernelGGL(ln_kernel<T>, dim3(tok_blocks), dim3(256), 0, stream, u, cu + n, (const E*)ly.ln2_w, (const E*)ly.ln2_b,
-                               w->eps, x);
+                          4 * HID, Lp);
+        hipLaunchKernelGGL(ln_kernel<T>, dim3(tok_blocks), dim3(256), 0, stream, u, cu + n, (const E*)ly.ln2_w, (const E*)ly.ln2_b,
+                           w->eps, x);
     }
     // rows written contiguously at out (which may point into the passage slab: slab + row_offset * 768)
     hipLaunchKernelGGL(pool_packed_kernel<T>, dim3((unsigned)n), dim3(192), 0, stream, x, cu, tokinfo, w->pooling, out, out_rows);

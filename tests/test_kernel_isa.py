@@ -1,0 +1,88 @@
+"""What the compiled hot kernels look like (CPU: hipcc cross-compiles gfx950 here; ~1 minute): properties of the ISA that measurements
+depend on and that a compiler or source change can silently break.
+
+  * no scratch (register spills) in the steady state: the persistent refresh GEMMs use none at all; the scan kernels -- at the 128-VGPR cap
+    of their 16-wave workgroups -- keep a few spilled values, but never touch them inside the slab loop (a scratch access counts in vmcnt
+    and would drain the ring of slab loads);
+  * no 16-byte buffer store whose data registers the very next instruction overwrites while its soffset is an SGPR: hipcc's hazard
+    recognizer does not pad that sequence and gfx950 corrupts the store (measured: tools/hazard_probe.hip, profiles/r03/hazard_probe.txt).
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "atlas_amd", "csrc")
+
+
+def _asm(name):
+    """device ISA of csrc/<name>.hip with the product build's flags (atlas_amd/build.py), cached by source mtime"""
+    from atlas_amd import build
+
+    src = os.path.join(CSRC, name + ".hip")
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "atlas_hip.h")]
+    out = os.path.join("/tmp", f"atlas_isa_{name}_{int(max(os.path.getmtime(d) for d in deps))}.s")
+    if not os.path.exists(out):
+        subprocess.check_call([build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-w",
+                               "-mllvm", "-amdgpu-mfma-vgpr-form=1", src, "-o", out])
+    return open(out).read()
+
+
+def _functions(asm):
+    return {f.split(":", 1)[0]: f for f in re.split(r"\n(?=_Z\w+:)", asm) if f.startswith("_Z")}
+
+
+def _scratch_bytes(body):
+    return int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+
+
+def test_persistent_gemm_has_no_scratch_and_a_clean_loop():
+    fns = {k: v for k, v in _functions(_asm("encoder")).items() if "gemm_pt_kernel" in k}
+    assert len(fns) == 8, sorted(fns)                        # fp16 / bf16 x EPI 1, 2, 3, 4
+    for name, body in fns.items():
+        assert _scratch_bytes(body) == 0, f"{name} spills {_scratch_bytes(body)} bytes"
+        assert "scratch_" not in body, name
+        # every block of 64 MFMAs (one k-tile) is free of waits on the vector-memory counter: the LDS-DMA pipeline is never drained mid-tile
+        runs = re.findall(r"(?:\s*v_mfma[^\n]*\n){64}", body)
+        assert len(runs) >= 2, (name, len(runs))
+
+
+def test_scan_keeps_its_spills_out_of_the_slab_loop():
+    fns = {k: v for k, v in _functions(_asm("atlas_hip")).items() if "scan_kernelILi16ELi1ELi8E" in k}
+    assert len(fns) == 2, sorted(fns)                        # the certifying twin and the one that trusts pmax
+    for name, body in fns.items():
+        lines = [l.strip() for l in body.split("\n")]
+        mf = [i for i, l in enumerate(lines) if l.startswith("v_mfma")]
+        # the ring revolution: 8 k-steps x 4 MFMAs in one straight run of code
+        first = next(i for i in mf if sum(1 for j in mf if i <= j < i + 400) >= 32)
+        last = [j for j in mf if first <= j < first + 400][31]
+        loop = lines[first:last + 1]
+        assert sum(l.startswith("v_mfma") for l in loop) == 32
+        assert not any(l.startswith("scratch_") for l in loop), f"{name}: scratch access inside the ring revolution"
+        assert not any(re.match(r"s_waitcnt.*vmcnt\(0\)", l) for l in loop), f"{name}: the ring is drained inside a revolution"
+        assert _scratch_bytes(body) <= 64, (name, _scratch_bytes(body))
+
+
+def test_no_unpadded_overwrite_of_store_data():
+    for unit in ("encoder", "atlas_hip"):
+        cur = prev = None
+        bad = []
+        for line in _asm(unit).split("\n"):
+            t = line.strip()
+            if re.match(r"^_Z\w+:", t):
+                cur, prev = t.split(":")[0], None
+                continue
+            if not t or t.startswith(";") or t.startswith("."):
+                continue
+            if prev:
+                m = re.match(r"buffer_store_dwordx[34] v\[(\d+):(\d+)\], \w+, s\[\d+:\d+\], (s\d+|m0)\b", prev)
+                d = re.match(r"v_\w+ v(\d+)\b|v_\w+ v\[(\d+):(\d+)\]", t)
+                if m and d:
+                    lo, hi = int(m.group(1)), int(m.group(2))
+                    regs = range(int(d.group(1)), int(d.group(1)) + 1) if d.group(1) else range(int(d.group(2)), int(d.group(3)) + 1)
+                    if any(lo <= r <= hi for r in regs):
+                        bad.append((cur, prev, t))
+            prev = t
+        assert not bad, bad[:3]
