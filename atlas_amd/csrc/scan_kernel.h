@@ -519,7 +519,9 @@ scan_kernel(const ScanParams p) {
         if (tid < p.nq) {
             float m = s_tmax[tid];
             for (int w = 1; w < NW; ++w) m = fmaxf(m, s_tmax[w * 64 + tid]);
-            __hip_atomic_store(gmax + (size_t)tid * G + blockIdx.x, ((unsigned long long)tag << 32) | (unsigned long long)f32_bits(m),
+            uint32_t to = (uint32_t)tid;                   // the granule's address is formed here, not hoisted over the slab loop into scratch
+            asm volatile("" : "+v"(to));
+            __hip_atomic_store(gmax + (size_t)to * G + blockIdx.x, ((unsigned long long)tag << 32) | (unsigned long long)f32_bits(m),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (wave == NW - 1) {
@@ -674,6 +676,11 @@ scan_kernel(const ScanParams p) {
                 // would force vmcnt(0) in front of every ring slot.) Only when the buffer is full do entries
                 // go straight to the global lists, and that branch drains itself.
                 const uint32_t rrel = (uint32_t)row0 + (uint32_t)lgrp * 4u;
+                // (everything below that depends on the lane's query is formed HERE, from a value hipcc cannot trace back to the lane id:
+                //  otherwise the four per-lane list pointers and the shifted query tags are hoisted out of the slab loop and, at the
+                //  128-register cap, kept in scratch -- and a kernel with a private segment pays ~12 us per launch for it)
+                uint32_t lrow_o = (uint32_t)lrow;
+                asm volatile("" : "+v"(lrow_o));
                 bool spilled = false;
 #pragma unroll
                 for (int pf = 0; pf < PF; ++pf)
@@ -683,7 +690,7 @@ scan_kernel(const ScanParams p) {
                         for (int r = 0; r < 4; ++r) {
                             const float v = acc[pf][qf][r];
                             if (v > th[qf]) {
-                                const uint32_t qq = (uint32_t)(qf * 16 + lrow);
+                                const uint32_t qq = (uint32_t)(qf * 16) + lrow_o;
                                 const uint32_t slot = atomicAdd(&s_flag[2], 1u);
                                 if (slot < (uint32_t)p.buf_cap) {
                                     s_buf[slot] = make_uint2(f32_bits(v), (qq << 26) | (rrel + (uint32_t)(pf * 16 + r)));
