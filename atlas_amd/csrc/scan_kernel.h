@@ -172,6 +172,8 @@ static __device__ __forceinline__ float initial_theta(const float (&v)[4], const
     return (valid >= (uint32_t)k) ? prune_threshold(f32_from_order_key(kth), eps) : neg_inf();
 }
 
+#include "merge_kernel.h"
+
 // ------------------------------------------------------------------------------------------
 // scan
 // ------------------------------------------------------------------------------------------
@@ -204,7 +206,19 @@ struct ScanParams {
     int flush_at;             // buffer fill at which a flush into the global lists is requested
     float pmax2_hint;
     unsigned long long* dbg;  // tuning build only (atlas_tune_set_scan_stamps): 8 wall-clock stamps (100 MHz, common to all XCDs) per workgroup; null in production
+#if ATLAS_TUNING
+    // EXPERIMENT, tuning build only (atlas_tune_set_scan_fused; tools/fused_timeline.py): the merge inside the scan -- the LAST nq workgroups
+    // to finish their ranges stay and run the merge of one query each once every workgroup has handed over. Measured and NOT adopted:
+    // the kernel boundary it removes costs 2.3 us (last hand-over -> first merge instruction), the in-kernel hand-off that replaces it
+    // (L2 write-back, returning arrival atomic, published tag, poll, invalidate) 6.5-10 us: profiles/r03/fused_timeline.txt
+    int fused;                // 0: the caller launches merge_rescore_kernel behind the scan
+    uint32_t* fuse;           // per-workspace words: [0] arrivals (zero between calls) [1] tag of the last call in which a workgroup gave its query up
+                              // [2] tag of the last call whose hand-over is complete; [64 + q] state of query q (FUSE_*, FREE between calls)
+    MergeParams mp;
+#endif
 };
+enum : uint32_t { FUSE_FREE = 0u, FUSE_ABANDONED = 1u, FUSE_MERGING = 2u };
+#define ATLAS_FUSE_WAIT_TICKS 10000ull   // 100 us: how long a finished workgroup waits for the slowest one before it leaves its query to it
 
 struct ScanSmem {   // byte offsets into dynamic LDS
     static constexpr int q_off = 0;                       // 100352 B: the query image (fill_query_image)
@@ -779,6 +793,85 @@ scan_kernel(const ScanParams p) {
     ATLAS_SCAN_STAMP(5);        // [5] hand-over done
 #if ATLAS_TUNING
     if (p.dbg && tid < 120) p.dbg[2048 + blockIdx.x * 120 + tid] = (tid < c_seq) ? ((unsigned long long*)(smem + ScanSmem::buf_off + (size_t)p.buf_cap * 8))[tid] : 0ull;
+#endif
+#if ATLAS_TUNING
+    // Fused merge (experiment, see ScanParams). Arrival = one returning atomic per workgroup, behind a release fence that covers every list entry, length and
+    // norm / flag word this workgroup wrote. Arrival number t decides: the first G - nq workgroups leave; workgroup t >= G - nq owns
+    // query t - (G - nq) and waits until the last arriver has published the call's tag. The wait is BOUNDED (a workgroup that has not
+    // even started -- CUs held by another stream's kernel -- can be a whole scan away): a workgroup that gives up marks its query
+    // ABANDONED and leaves, and the last arriver, which by construction finds everything complete, merges the abandoned queries itself
+    // after its own. abandon: CAS(FREE -> ABANDONED), note the call's tag in fuse[1], re-check fuse[2] (the last arriver may have looked
+    // before the mark: then this workgroup takes its query back, CAS(ABANDONED -> MERGING)); last arriver: publish the tag in fuse[2],
+    // THEN read fuse[1], THEN CAS(ABANDONED -> MERGING) per query: exactly one of the two merges every query. (Tags are unique per
+    // call: nothing but the arrival counter and the states of merged queries has to be put back.)
+    if constexpr (NW * 64 == 1024) {
+        if (p.fused) {
+            uint32_t* s_fz = (uint32_t*)(smem + ScanSmem::flag_off);       // [4], [5]: free from here on (the tile tickets used [8..15])
+            const uint32_t G = gridDim.x, first = G - (uint32_t)p.nq;
+            // release: every wave waits for ITS stores to reach the L2, then ONE thread writes the L2 back and arrives (a fence in every
+            // thread is 16 L2 write-backs per workgroup, all of them in the last microseconds of the scan: +160 us per search, measured)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
+            if (tid == 0) {
+                __threadfence();
+                s_fz[4] = atomicAdd(&p.fuse[0], 1u);
+            }
+            __syncthreads();
+            const uint32_t t = s_fz[4];
+            if (t < first || t >= G) return;                               // (>= G: a workspace whose state words were not zero before its first use)
+            const bool last = t == G - 1u;
+            const int myq = (int)(t - first);
+            if (tid == 0) {
+                uint32_t mine = 1u;
+                if (last) {
+                    p.fuse[0] = 0u;                                        // (nobody else arrives in this call)
+                    __hip_atomic_store(&p.fuse[2], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    const unsigned long long end = wall_clock64() + ATLAS_FUSE_WAIT_TICKS;
+                    while (__hip_atomic_load(&p.fuse[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) {
+                        if (wall_clock64() >= end) {
+                            uint32_t expect = FUSE_FREE;
+                            __hip_atomic_compare_exchange_strong(&p.fuse[64 + myq], &expect, (uint32_t)FUSE_ABANDONED, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_exchange(&p.fuse[1], tag, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                            if (__hip_atomic_load(&p.fuse[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == tag) {
+                                expect = FUSE_ABANDONED;
+                                mine = __hip_atomic_compare_exchange_strong(&p.fuse[64 + myq], &expect, (uint32_t)FUSE_MERGING, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+                            } else mine = 0u;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                }
+                if (mine) __threadfence();                                 // acquire: the other workgroups' lists (one invalidate for the CU)
+                s_fz[5] = mine;
+            }
+            __syncthreads();
+            if (s_fz[5] == 0u) return;
+            // (one copy of the merge in the kernel: the last arriver comes round again for the queries whose workgroups gave up)
+            for (int qq = myq, scan_from = 0; ; ) {
+                merge_rescore_body<1024>(p.mp, qq, smem);
+                __syncthreads();
+                if (tid == 0) {
+                    __hip_atomic_store(&p.fuse[64 + qq], (uint32_t)FUSE_FREE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    int next = -1;
+                    if (last && __hip_atomic_load(&p.fuse[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == tag) {
+                        for (int c = scan_from; c < p.nq && next < 0; ++c) {
+                            uint32_t expect = FUSE_ABANDONED;
+                            if (c != myq && __hip_atomic_compare_exchange_strong(&p.fuse[64 + c], &expect, (uint32_t)FUSE_MERGING, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                next = c;
+                        }
+                    }
+                    s_fz[4] = (uint32_t)next;
+                }
+                __syncthreads();
+                const int next = (int)s_fz[4];
+                if (next < 0) return;
+                qq = next;
+                scan_from = next + 1;
+                __syncthreads();
+            }
+        }
+    }
 #endif
 }
 

@@ -81,7 +81,7 @@ if what in ("scan", "both"):
         for qn, q, qdt in (("f32 queries", q32, _lib.DT_F32), ("f16 queries", q32.half(), _lib.DT_F16)):
             res = {n: [] for n, _ in libs}
             ref = None
-            wss = {n: torch.empty(h.atlas_scan_topk_workspace_bytes(N, B, D, k), dtype=torch.uint8, device="cuda") for n, h in libs}
+            wss = {n: torch.zeros(h.atlas_scan_topk_workspace_bytes(N, B, D, k), dtype=torch.uint8, device="cuda") for n, h in libs}   # (the head of a workspace holds state: zero before its first use)
             for r in range(rounds):
                 for n, h in libs:
                     ws = wss[n]
