@@ -73,12 +73,17 @@ static __device__ __forceinline__ uint4 q8_to_f16(const QRaw r, const int q_dtyp
     for (int i = 0; i < 4; ++i) o[i] = pack_h2(bits_f32(w[i] << 16), bits_f32(w[i] & 0xffff0000u));
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
-// queries [q0, q0 + nq) of `q` -> s_q; rows >= nq are zero. All loads of a batch are in flight before the first conversion.
+// queries [q0, q0 + nq) of `q` -> s_q; rows >= nq are zero. All loads of a batch are in flight before the first conversion: the element
+// type is switched on ONCE per phase, outside the chunk loops -- with the switch inside load_q8 / q8_to_f16 every fp32 chunk was its own
+// basic block (second half loaded, WAITED for and converted, then the first half requested): six serialised trips to the L2 per thread.
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // `after_first_loads` runs once, when the first batch of loads has been issued and before anything waits for them
 template <int NT, class Hook = NoHook>
 static __device__ __forceinline__ void fill_query_image(uint4* __restrict__ s_q, const void* __restrict__ q, const int q_dtype,
-                                                        const int q0, const int nq, const int tid, Hook after_first_loads = Hook()) {
+                                                        const int q0, const int nq, const int tid, Hook after_first_loads = Hook(),
+                                                        const int rot = 0) {
+    // rot (< CH): the chunk this workgroup starts with. Every workgroup reads the same 98-196 KiB at the same moment; in the same order,
+    // the 32 CUs of an XCD ask one L2 channel after the other for the same lines -- rotated, they spread over the channels.
     constexpr int CH = QCHUNK * (D_FAST / 8);          // 6144 chunks of 8 elements
     constexpr int PER = CH / NT;                       // 6 per thread with 1024 threads, 24 with 256
     constexpr int BATCH = PER % 6 == 0 ? 6 : PER % 4 == 0 ? 4 : PER % 3 == 0 ? 3 : PER % 2 == 0 ? 2 : 1;   // loads in flight per thread
@@ -86,17 +91,55 @@ static __device__ __forceinline__ void fill_query_image(uint4* __restrict__ s_q,
 #pragma unroll 1
     for (int b0 = 0; b0 < PER; b0 += BATCH) {
         QRaw raw[BATCH];
+        size_t elem[BATCH];
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            const int c = tid + (b0 + u) * NT, qi = c / (D_FAST / 8), kc = c - qi * (D_FAST / 8);
+            int c = tid + (b0 + u) * NT + rot;
+            c -= c >= CH ? CH : 0;
+            const int qi = c / (D_FAST / 8), kc = c - qi * (D_FAST / 8);
             const int qs = qi < nq ? qi : 0;                                         // clamped: loads stay unconditional
-            raw[u] = load_q8(q, q_dtype, (size_t)(q0 + qs) * D_FAST + (size_t)kc * 8);
+            elem[u] = (size_t)(q0 + qs) * D_FAST + (size_t)kc * 8;
         }
+        if (q_dtype == ATLAS_DT_F32) {
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) { const uint4* p = (const uint4*)((const float*)q + elem[u]); raw[u].a = p[0]; raw[u].b = p[1]; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) { raw[u].a = *(const uint4*)((const uint16_t*)q + elem[u]); raw[u].b = make_uint4(0, 0, 0, 0); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (b0 == 0) after_first_loads();
+        // every load of the batch is issued and waited for HERE, together: hipcc otherwise requests an fp32 chunk's second half, waits,
+        // converts it (two registers instead of four) and only then requests the first half -- a trip to the L2 per chunk
+        auto pin = [](uint4& v) {
+            u32x4 t = {v.x, v.y, v.z, v.w};
+            asm volatile("" : "+v"(t));
+            v = make_uint4(t[0], t[1], t[2], t[3]);
+        };
+        if (q_dtype == ATLAS_DT_F32) {
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) { pin(raw[u].a); pin(raw[u].b); }
+        } else {
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) pin(raw[u].a);
+        }
+        uint4 h[BATCH];
+        if (q_dtype == ATLAS_DT_F32) {
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) h[u] = q8_to_f16(raw[u], ATLAS_DT_F32);
+        } else if (q_dtype == ATLAS_DT_F16) {
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) h[u] = raw[u].a;
+        } else {
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) h[u] = q8_to_f16(raw[u], ATLAS_DT_BF16);
+        }
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            const int c = tid + (b0 + u) * NT, qi = c / (D_FAST / 8), kc = c - qi * (D_FAST / 8);
-            s_q[qi * QROW_U4 + kc] = qi < nq ? q8_to_f16(raw[u], q_dtype) : make_uint4(0, 0, 0, 0);
+            int c = tid + (b0 + u) * NT + rot;
+            c -= c >= CH ? CH : 0;
+            const int qi = c / (D_FAST / 8), kc = c - qi * (D_FAST / 8);
+            s_q[qi * QROW_U4 + kc] = qi < nq ? h[u] : make_uint4(0, 0, 0, 0);
         }
     }
 }
@@ -335,20 +378,24 @@ scan_kernel(const ScanParams p) {
     };
 
     u32x4 abuf[RING][PF];
+    auto ring_prologue = [&]() {
 #pragma unroll
-    for (int s = 0; s < RING - 1; ++s) {
+        for (int s = 0; s < RING - 1; ++s) {
 #pragma unroll
-        for (int pf = 0; pf < PF; ++pf)
-            abuf[s][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)vo[pf], fill_step * 64, AUX & 31);
-        fill_advance(false);
-        // keep issue order == ring order: hipcc's waitcnt for slot 0 is the minimum over the loop
-        // entry and the back edge, so a shuffled prologue would cost ring depth on every revolution
-        __builtin_amdgcn_sched_barrier(0);
-    }
+            for (int pf = 0; pf < PF; ++pf)
+                abuf[s][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)vo[pf], fill_step * 64, AUX & 31);
+            fill_advance(false);
+            // keep issue order == ring order: hipcc's waitcnt for slot 0 is the minimum over the loop
+            // entry and the back edge, so a shuffled prologue would cost ring depth on every revolution
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
 
-    // the query image is built in LDS AFTER the first ring loads are in flight (their HBM latency overlaps it), straight from the
-    // caller's tensor; then every wave derives eps and the initial threshold of its share of the queries
-    ATLAS_SCAN_STAMP(1);        // [1] ring prologue issued
+    // The query image is built in LDS straight from the caller's tensor, and its loads go out FIRST; the ring's first slab loads follow
+    // them (the image loader's hook below) and are in flight while the image is converted. A wave's loads return in order: with the ring
+    // first (rounds 1-2) the image -- L2 hits -- sat behind 29 MB of cold slab requests of all 256 workgroups, and nothing streamed
+    // while it was converted: image in LDS 12.5 us after entry (profiles/r03/scan_wg_times_1m_4m.txt). Then every wave derives eps and
+    // the initial threshold of its share of the queries.
     // Initial thresholds. Deriving one (the k-th largest of 512 sample maxima, a bit search with ballots) costs ~1 us for one wave --
     // but 64 of them on every CU were 30 us of start-up (4 waves share a SIMD). So the last wave of workgroup q derives the threshold of
     // query q alone -- its inputs (the query's row, for eps, and the sample maxima) are requested before the image loads and it works
@@ -370,6 +417,12 @@ scan_kernel(const ScanParams p) {
         trow[1] = load_q8(p.q, p.q_dtype, base + (size_t)(64 + (lane & 31)) * 8);           // chunks 64..95 (lanes >= 32 repeat them)
     }
     fill_query_image<NW * 64>(s_q, p.q, p.q_dtype, p.q0, p.nq, tid, [&]() {
+        // EVERY wave's image loads are queued before ANY wave's slab loads (a raw barrier: nothing is waited for). The CU's L1 serves its
+        // queue in order and holds a bounded number of misses: slab loads (cold HBM, all 256 workgroups at once) queued in front of
+        // another wave's image loads (L2 hits) kept the image barrier waiting until ~10 us after entry (tools stamps, round 3)
+        __builtin_amdgcn_s_barrier();
+        ring_prologue();
+        ATLAS_SCAN_STAMP(1);    // [1] image loads and ring prologue issued
         if (!theta_wave) return;
         float ss = 0.f;
 #pragma unroll
@@ -386,7 +439,7 @@ scan_kernel(const ScanParams p) {
         const float th = initial_theta(tv, p.sample_blocks, p.k, query_eps(ss, p.pmax), lane);
         if (lane == 0) __hip_atomic_store(gran + blockIdx.x, (1ull << 32) | (unsigned long long)f32_bits(th), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ATLAS_SCAN_STAMP_LANE0(6);   // [6] threshold of query blockIdx.x published
-    });
+    }, (int)((blockIdx.x >> 3) & 31u) * (QCHUNK * (D_FAST / 8) / 32));       // (workgroup b runs on XCD b % 8: b >> 3 numbers the CUs of an XCD)
     if (tid < 64) s_cnt[tid] = 0;
     if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; }
     if (tid < 4) s_tk[tid] = 0ull;      // sequence number 0 is never asked for (LDS keeps the previous kernel's words)
