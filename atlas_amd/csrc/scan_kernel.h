@@ -80,10 +80,7 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // `after_first_loads` runs once, when the first batch of loads has been issued and before anything waits for them
 template <int NT, class Hook = NoHook>
 static __device__ __forceinline__ void fill_query_image(uint4* __restrict__ s_q, const void* __restrict__ q, const int q_dtype,
-                                                        const int q0, const int nq, const int tid, Hook after_first_loads = Hook(),
-                                                        const int rot = 0) {
-    // rot (< CH): the chunk this workgroup starts with. Every workgroup reads the same 98-196 KiB at the same moment; in the same order,
-    // the 32 CUs of an XCD ask one L2 channel after the other for the same lines -- rotated, they spread over the channels.
+                                                        const int q0, const int nq, const int tid, Hook after_first_loads = Hook()) {
     constexpr int CH = QCHUNK * (D_FAST / 8);          // 6144 chunks of 8 elements
     constexpr int PER = CH / NT;                       // 6 per thread with 1024 threads, 24 with 256
     constexpr int BATCH = PER % 6 == 0 ? 6 : PER % 4 == 0 ? 4 : PER % 3 == 0 ? 3 : PER % 2 == 0 ? 2 : 1;   // loads in flight per thread
@@ -94,9 +91,7 @@ static __device__ __forceinline__ void fill_query_image(uint4* __restrict__ s_q,
         size_t elem[BATCH];
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            int c = tid + (b0 + u) * NT + rot;
-            c -= c >= CH ? CH : 0;
-            const int qi = c / (D_FAST / 8), kc = c - qi * (D_FAST / 8);
+            const int c = tid + (b0 + u) * NT, qi = c / (D_FAST / 8), kc = c - qi * (D_FAST / 8);
             const int qs = qi < nq ? qi : 0;                                         // clamped: loads stay unconditional
             elem[u] = (size_t)(q0 + qs) * D_FAST + (size_t)kc * 8;
         }
@@ -136,9 +131,7 @@ static __device__ __forceinline__ void fill_query_image(uint4* __restrict__ s_q,
         }
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            int c = tid + (b0 + u) * NT + rot;
-            c -= c >= CH ? CH : 0;
-            const int qi = c / (D_FAST / 8), kc = c - qi * (D_FAST / 8);
+            const int c = tid + (b0 + u) * NT, qi = c / (D_FAST / 8), kc = c - qi * (D_FAST / 8);
             s_q[qi * QROW_U4 + kc] = qi < nq ? h[u] : make_uint4(0, 0, 0, 0);
         }
     }
@@ -393,9 +386,11 @@ scan_kernel(const ScanParams p) {
 
     // The query image is built in LDS straight from the caller's tensor, and its loads go out FIRST; the ring's first slab loads follow
     // them (the image loader's hook below) and are in flight while the image is converted. A wave's loads return in order: with the ring
-    // first (rounds 1-2) the image -- L2 hits -- sat behind 29 MB of cold slab requests of all 256 workgroups, and nothing streamed
-    // while it was converted: image in LDS 12.5 us after entry (profiles/r03/scan_wg_times_1m_4m.txt). Then every wave derives eps and
-    // the initial threshold of its share of the queries.
+    // first (rounds 1-2) the image sat behind 29 MB of cold slab requests of all 256 workgroups, and nothing streamed while it was
+    // converted: image in LDS 12.5 us after entry. Now 11.4 us (1M-row step -1.8 us, profiles/r03/scan_startup.txt): what is left is the
+    // CU's own path -- 196 KiB of fp32 queries + 112 KiB of ring per CU at the ~23 GB/s a CU gets when all 256 ask at once (the queries
+    // do not survive in L2 from call to call: a scan streams gigabytes through it); reading the image in a rotated order per CU (L2
+    // channel spread) measured no different. Then every wave derives eps and the initial threshold of its share of the queries.
     // Initial thresholds. Deriving one (the k-th largest of 512 sample maxima, a bit search with ballots) costs ~1 us for one wave --
     // but 64 of them on every CU were 30 us of start-up (4 waves share a SIMD). So the last wave of workgroup q derives the threshold of
     // query q alone -- its inputs (the query's row, for eps, and the sample maxima) are requested before the image loads and it works
@@ -439,7 +434,7 @@ scan_kernel(const ScanParams p) {
         const float th = initial_theta(tv, p.sample_blocks, p.k, query_eps(ss, p.pmax), lane);
         if (lane == 0) __hip_atomic_store(gran + blockIdx.x, (1ull << 32) | (unsigned long long)f32_bits(th), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ATLAS_SCAN_STAMP_LANE0(6);   // [6] threshold of query blockIdx.x published
-    }, (int)((blockIdx.x >> 3) & 31u) * (QCHUNK * (D_FAST / 8) / 32));       // (workgroup b runs on XCD b % 8: b >> 3 numbers the CUs of an XCD)
+    });
     if (tid < 64) s_cnt[tid] = 0;
     if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; }
     if (tid < 4) s_tk[tid] = 0ull;      // sequence number 0 is never asked for (LDS keeps the previous kernel's words)
