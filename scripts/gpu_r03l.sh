@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 3, session l: the parked first tile -- parity of the search path, then same-process A/B against the committed build and the timeline
+OUT=gpurun_out/r03l; mkdir -p $OUT
+timeout 900 python -m pytest tests/test_gpu_search.py tests/test_gpu_parity_32m.py tests/test_gpu_end_to_end.py -m gpu -q --no-header -x -p no:cacheprovider > $OUT/pytest_search.log 2>&1; echo "pytest rc=$?" | tee $OUT/summary.log
+tail -5 $OUT/pytest_search.log | tee -a $OUT/summary.log
+timeout 900 python tools/lib_ab.py scan head=tools/ab/head.so park=tools/ab/park.so 5 2>&1 | grep -v amdgpu.ids | tee $OUT/scan_builds.txt
+timeout 600 python tools/scan_wg_times.py 1000000 2>&1 | grep -v amdgpu.ids | tee $OUT/scan_wg_times.txt
