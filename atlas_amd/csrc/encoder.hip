@@ -899,8 +899,7 @@ template <class T> static __device__ __forceinline__ uint32_t pack2(const float 
 //   s_tr: this wave's 4 KiB: [16 tokens][16 chunks of 8 columns], chunk c of token t at 16-byte slot c ^ t (conflict-free both ways)
 //   cbuf: descriptor of C's rows [m0, M) (stores past M fall out of bounds);  bq4: the lane's 8 bias values of fragment pair j (packed)
 //   rv: EPI 2: the residual piece of (slice b, store s) = rv[4 b + s];  EPI 4: bq4 word a = bias of column 16 a + lr, tki: see below
-//   B0, B1: the 16-token slices [B0, B1) of the wave's 64 tokens are written (EPI 4: the 32-token halves [B0 / 2, B1 / 2))
-template <class T, int EPI, int AUX = 0, int B0 = 0, int B1 = 4>      // AUX: cache-policy bits of the C stores (0 = default; tuning builds A/B 2 = nt and 16 = sc1)
+template <class T, int EPI, int AUX = 0>      // AUX: cache-policy bits of the C stores (0 = default; tuning builds A/B 2 = nt and 16 = sc1)
 static __device__ __forceinline__ void pt_epilogue(const f4 (&acc)[8][4], unsigned char* __restrict__ s_tr,
                                                    const pt_u4 (&bq4)[4], const pt_u4 (&rv)[16], const int2 (&tki)[4],
                                                    const __amdgpu_buffer_rsrc_t cbuf,
@@ -910,7 +909,7 @@ static __device__ __forceinline__ void pt_epilogue(const f4 (&acc)[8][4], unsign
     if constexpr (EPI != 4) {
         const int tq = lane >> 4, cc = lane & 15;                       // transposed side: token 4 s + tq of the slice, column chunk cc
 #pragma unroll
-        for (int b = B0; b < B1; ++b) {
+        for (int b = 0; b < 4; ++b) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t bw[4] = {bq4[j][0], bq4[j][1], bq4[j][2], bq4[j][3]};
@@ -952,7 +951,7 @@ static __device__ __forceinline__ void pt_epilogue(const f4 (&acc)[8][4], unsign
         // they belong to one passage (layout note at the top of the file), ragged batches included; the few groups that straddle two
         // passages or the end of the batch go out token by token
 #pragma unroll
-        for (int jj = B0 / 2; jj < B1 / 2; ++jj) {
+        for (int jj = 0; jj < 2; ++jj) {
             const int64_t tok0 = m0 + wj * 64 + 32 * jj + 8 * lg;
             const int2 t0 = tki[2 * jj], t7 = tki[2 * jj + 1];
             const bool whole = (tok0 + 7 < M) && (t0.x == t7.x);
@@ -1220,34 +1219,25 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         // Epilogue of this tile, BOTH GROUPS SIDE BY SIDE: an epilogue is a chain of dependent VALU work (bias, GELU polynomial, packing)
         // that one wave per SIMD runs at ~7 cycles per instruction; two waves per SIMD hide each other's latencies. The barrier between a
         // group's reads and its MFMAs only keeps the two groups in opposite phases (no LDS hazard hangs on it: every buffer hand-over
-        // goes through the OTHER barrier), so group A takes the next tile's first one here, inside its epilogue -- it meets group B
+        // goes through the OTHER barrier), so group A takes the next tile's first one here, ahead of its epilogue -- it meets group B
         // coming out of the tile's last MFMAs -- and then skips it in the next tile's first iteration (at the very end it is the
-        // barrier group B's last iteration still owes). Group A writes the first of its four slices (two of EPI 4's two halves: one)
-        // in front of that barrier, while group B is still multiplying. The stores stay in flight behind the wave's next wait.
+        // barrier group B's last iteration still owes). The stores stay in flight behind the wave's next wait. (Group A writing a first
+        // slice in front of that barrier, while group B still multiplies, was measured: nothing on the full batch, -1.9 % on the ragged
+        // one -- profiles/r03/enc_builds_split_epilogue.txt.)
         // (The wait: group B's pieces of the next tile's k-tile 1, the bias and the residual; group A waited in front of the tile's last
         // barrier -- for it this is a no-op that tells hipcc's wait insertion that nothing is in flight.)
         __builtin_amdgcn_s_waitcnt(0x0F70);
         PT_STAMP(6);
         if (grpB) skip_wait = true;
-#define PT_EPILOGUE(AUX, B0, B1) pt_epilogue<T, EPI, AUX, B0, B1>(acc, smem_raw + TR_OFF + wave * 4096, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp)
-        constexpr int BSPLIT = (EPI == 4) ? 2 : 1;
+#define PT_EPILOGUE(AUX) pt_epilogue<T, EPI, AUX>(acc, smem_raw + TR_OFF + wave * 4096, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp)
+        if (!grpB) { __builtin_amdgcn_s_barrier(); skip_b1 = true; }
 #if ATLAS_TUNING
-        if (diag & 1) { if (!grpB) { __builtin_amdgcn_s_barrier(); skip_b1 = true; } if (acc[0][0][0] == 12345.678f) C[0] = 0; }
-        else if ((diag & 12) == 4) { if (!grpB) { __builtin_amdgcn_s_barrier(); skip_b1 = true; } PT_EPILOGUE(2, 0, 4); }
-        else if ((diag & 12) == 8) { if (!grpB) { __builtin_amdgcn_s_barrier(); skip_b1 = true; } PT_EPILOGUE(16, 0, 4); }
+        if (diag & 1) { if (acc[0][0][0] == 12345.678f) C[0] = 0; }
+        else if ((diag & 12) == 4) PT_EPILOGUE(2);
+        else if ((diag & 12) == 8) PT_EPILOGUE(16);
         else
 #endif
-        if constexpr (T::DT == ATLAS_DT_BF16 && EPI == 2) {      // (the two-piece form does not fit the register file with bf16's conversions: no slice ahead of the barrier)
-            if (!grpB) { __builtin_amdgcn_s_barrier(); skip_b1 = true; }
-            PT_EPILOGUE(0, 0, 4);
-        } else if (!grpB) {
-            PT_EPILOGUE(0, 0, BSPLIT);
-            __builtin_amdgcn_s_barrier();
-            skip_b1 = true;
-            PT_EPILOGUE(0, BSPLIT, 4);
-        } else {
-            PT_EPILOGUE(0, 0, 4);
-        }
+        PT_EPILOGUE(0);
 #undef PT_EPILOGUE
         __builtin_amdgcn_sched_barrier(0);
         PT_STAMP(7);
