@@ -403,6 +403,8 @@ const ScanVariant kVariants[] = {
     {12, 2, 4, scan_kernel<12, 2, 4>, "scan_kernel<12,2,4>"},
     {16, 1, 8, scan_kernel<16, 1, 8, 2>, "scan_kernel<16,1,8,nt>"},
     {16, 1, 8, scan_kernel<16, 1, 8, 16>, "scan_kernel<16,1,8,sc1>"},
+    {16, 1, 8, scan_kernel<16, 1, 8, 64, 1>, "scan_kernel<16,1,8> trusted pmax + 1 unused query fragment (80-query proxy)"},
+    {16, 1, 8, scan_kernel<16, 1, 8, 64, 2>, "scan_kernel<16,1,8> trusted pmax + 2 unused query fragments (96-query proxy)"},
 #endif
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);

@@ -268,7 +268,9 @@ struct ScanSmem {   // byte offsets into dynamic LDS
 // AUX & 31 = cache-policy bits of the slab loads (0 = default, 2 = nt: rows are read once by one CU)
 // AUX & 64 = the caller's pmax is certified (ATLAS_SCAN_TRUST_PMAX): the row norms are not measured (4 v_dot2 per MFMA less; the
 //            kernel runs at the board's power limit and that VALU work was 4.6 % of its time, profiles/r02/scan_power.txt)
-template <int NW, int PF, int RING, int AUX = 0>
+// QX (tuning experiment only): extra 16-query fragments per slab k-step, fed from image rows 0 .. 16 QX - 1 again and never kept -- the
+// matrix-pipe, LDS-read and register cost of a pass over 64 + 16 QX queries without its larger image (profiles/r03/scan_96_query_proxy.txt)
+template <int NW, int PF, int RING, int AUX = 0, int QX = 0>
 __global__ void __launch_bounds__(NW * 64)
 scan_kernel(const ScanParams p) {
     // RING slots of PF fragments: RING-1 k-steps of loads in flight while one slot is consumed
@@ -464,11 +466,11 @@ scan_kernel(const ScanParams p) {
     __syncthreads();
     ATLAS_SCAN_STAMP(2);        // [2] query image, eps and thresholds in LDS
 
-    f32x4 acc[PF][4];
+    f32x4 acc[PF][4 + QX];
 #pragma unroll
     for (int pf = 0; pf < PF; ++pf)
 #pragma unroll
-        for (int qf = 0; qf < 4; ++qf) acc[pf][qf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int qf = 0; qf < 4 + QX; ++qf) acc[pf][qf] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float nrm[PF];
 #pragma unroll
     for (int pf = 0; pf < PF; ++pf) nrm[pf] = 0.f;
@@ -650,15 +652,16 @@ scan_kernel(const ScanParams p) {
                 abuf[fill][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)vo[pf], fill_step * 64, AUX & 31);
             fill_advance(j == 0);
             __builtin_amdgcn_sched_barrier(0);
-            uint4 b[4];
+            uint4 b[4 + QX];
 #pragma unroll
-            for (int qf = 0; qf < 4; ++qf) b[qf] = (qf < 2 ? bq0 : bq2)[(qf & 1) * 16 * QROW_U4 + j * 4];
+            for (int qf = 0; qf < 4 + QX; ++qf)           // (extra fragments: rows shifted by 8, so that they are LDS reads of their own)
+                b[qf] = ((qf & 3) < 2 ? bq0 : bq2)[((qf & 1) * 16 + (qf >= 4 ? 8 : 0)) * QROW_U4 + j * 4];
 #pragma unroll
             for (int pf = 0; pf < PF; ++pf) {
                 const u32x4 a = abuf[j][pf];
                 const f16x8 av = __builtin_bit_cast(f16x8, a);
 #pragma unroll
-                for (int qf = 0; qf < 4; ++qf)
+                for (int qf = 0; qf < 4 + QX; ++qf)
                     acc[pf][qf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
                         av, __builtin_bit_cast(f16x8, b[qf]), acc[pf][qf], 0, 0, 0);
                 // row sum of squares (certifies pmax_hint): 4 x v_dot2_f32_f16
@@ -731,6 +734,15 @@ scan_kernel(const ScanParams p) {
                 for (int qf = 0; qf < 4; ++qf)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) any |= acc[pf][qf][r] > th[qf];
+            if constexpr (QX > 0) {                          // (the extra fragments are looked at, so that they are computed, and never pass)
+                const float never = p.pmax * 1e30f;
+#pragma unroll
+                for (int pf = 0; pf < PF; ++pf)
+#pragma unroll
+                    for (int qf = 4; qf < 4 + QX; ++qf)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) any |= acc[pf][qf][r] > never;
+            }
             if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
                 // Candidates go to a workgroup-wide LDS buffer: LDS traffic is counted in lgkmcnt, so the
                 // ring of HBM loads (vmcnt) is not disturbed. (gfx9 counts loads and stores in one vmcnt
@@ -775,7 +787,7 @@ scan_kernel(const ScanParams p) {
         for (int pf = 0; pf < PF; ++pf) {
             nrm[pf] = 0.f;
 #pragma unroll
-            for (int qf = 0; qf < 4; ++qf) acc[pf][qf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int qf = 0; qf < 4 + QX; ++qf) acc[pf][qf] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 
         wg_barrier_lds();

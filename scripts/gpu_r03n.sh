@@ -1,0 +1,3 @@
+#!/bin/bash
+OUT=gpurun_out/r03n; mkdir -p $OUT
+timeout 900 python tools/scan_q96_proxy.py 4000000 32000000 2>&1 | grep -v amdgpu.ids | tee $OUT/scan_96_query_proxy.txt
