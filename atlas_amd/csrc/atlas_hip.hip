@@ -21,6 +21,7 @@
 #include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <vector>
 
 #ifndef ATLAS_TUNING
 #define ATLAS_TUNING 0
@@ -403,13 +404,15 @@ const ScanVariant kVariants[] = {
     {12, 2, 4, scan_kernel<12, 2, 4>, "scan_kernel<12,2,4>"},
     {16, 1, 8, scan_kernel<16, 1, 8, 2>, "scan_kernel<16,1,8,nt>"},
     {16, 1, 8, scan_kernel<16, 1, 8, 16>, "scan_kernel<16,1,8,sc1>"},
-    {16, 1, 8, scan_kernel<16, 1, 8, 64, 1>, "scan_kernel<16,1,8> trusted pmax + 1 unused query fragment (80-query proxy)"},
-    {16, 1, 8, scan_kernel<16, 1, 8, 64, 2>, "scan_kernel<16,1,8> trusted pmax + 2 unused query fragments (96-query proxy)"},
 #endif
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 // the production variant without the row-norm measurement, for callers that pass a certified pmax (ATLAS_SCAN_TRUST_PMAX)
 const ScanVariant kTrusted = {16, 1, 8, scan_kernel<16, 1, 8, 64>, "scan_kernel<16,1,8> (trusted pmax)"};
+// 96 queries per slab pass (6 MFMA column groups): the passes of batches above 64 queries (scan_kernel.h: NQF; chunk_plan below)
+const ScanVariant kWide = {16, 1, 8, scan_kernel<16, 1, 8, 0, 6>, "scan_kernel<16,1,8,96q>"};
+const ScanVariant kWideTrusted = {16, 1, 8, scan_kernel<16, 1, 8, 64, 6>, "scan_kernel<16,1,8,96q> (trusted pmax)"};
+constexpr int QWIDE = 96;
 
 constexpr int MERGE_NT = 1024;
 constexpr int SAMPLE_MAX = 16384;
@@ -420,6 +423,8 @@ unsigned long long* g_scan_dbg = nullptr;    // atlas_tune_set_scan_stamps
 int scan_variant_index() { return (g_scan_variant >= 0 && g_scan_variant < kNumVariants) ? g_scan_variant : 0; }
 int g_scan_coop = 1;                         // atlas_tune_set_scan_coop: 0 = sample kernel + early threshold exchange (A/B)
 bool scan_coop_enabled() { return g_scan_coop != 0; }
+int g_scan_wide = 1;                         // atlas_tune_set_scan_wide: 0 = batches above 64 queries in 64-query passes only (A/B)
+bool scan_wide_enabled() { return g_scan_wide != 0; }
 int g_scan_fused = 0;                        // atlas_tune_set_scan_fused: 1 = the merge inside the scan (experiment, not adopted)
 bool scan_fused_enabled() { return g_scan_fused != 0; }
 #else
@@ -427,6 +432,7 @@ constexpr unsigned long long* g_merge_dbg = nullptr;
 constexpr unsigned long long* g_scan_dbg = nullptr;
 constexpr int scan_variant_index() { return 0; }
 constexpr bool scan_coop_enabled() { return true; }
+constexpr bool scan_wide_enabled() { return true; }
 #endif
 // run-time tile pool at the end of the slab: share of a workgroup's tiles that is NOT pre-assigned, and its cap
 #if ATLAS_TUNING
@@ -444,6 +450,8 @@ struct ScanPlan {
     int64_t pool_begin;  // rows [pool_begin, N) are handed out at run time, a tile at a time (scan_kernel.h: fill_next_tile)
     int pool_rows, pool_tiles;
     int keep_max, cap, tile, buf_cap, flush_at;
+    int nqp;             // most queries of one slab pass this plan is laid out for (64, or 96 for batches above 64)
+    int buf_cap_wide, flush_at_wide; size_t scan_lds_wide;   // the 96-query pass: its image leaves 11.5 KiB for candidates
     int S; int64_t sample_stride;     // sample pre-pass: S rows (0 = none), tile j starts at j*sample_stride
     int key_cap;
     int total_cap;
@@ -458,8 +466,9 @@ int device_cus() {       // the current device's CU count, asked every time (no 
     return cus;
 }
 
-ScanPlan make_plan(int64_t N, int d, int k, int cus, const ScanVariant& v) {
+ScanPlan make_plan(int64_t N, int d, int k, int cus, const ScanVariant& v, int nqp = QCHUNK) {
     ScanPlan pl{};
+    pl.nqp = nqp;
     // one workgroup per CU (the 96 KB query image allows exactly one resident workgroup);
     // every workgroup gets a contiguous, 16-row aligned range of equal size
     const int64_t frags = (N + 15) / 16;
@@ -514,19 +523,23 @@ ScanPlan make_plan(int64_t N, int d, int k, int cus, const ScanVariant& v) {
     size_t o = 0;
     // state that lives across calls (zero before the first use of a workspace, ATLAS_WS_STATE_BYTES): the per-query fallback flags
     // (cleared again by the merge block that reads them) and the call counter that tags the granules of coop scans
-    pl.off_qflag = o;  o += 256;
+    // (laid out for 96 queries per pass whatever the batch: a workspace keeps its state words where they are when the batch size changes)
+    pl.off_qflag = o;  o += 512;
     pl.off_epoch = o;  o += 256;
     pl.off_fuse = o;   o += 512;                         // fused merge: arrivals, tags, per-query states (scan_kernel.h)
-    pl.off_gran = o;   o += 512;
-    pl.off_gmax = o;   o += (size_t)QCHUNK * 1024 * 8;
+    pl.off_gran = o;   o += 1024;
+    pl.off_gmax = o;   o += (size_t)QWIDE * 1024 * 8;
     pl.off_q16 = o;    o += (size_t)QCHUNK * D_FAST * 2;
     pl.off_sample = o; o += (size_t)QCHUNK * SAMPLE_MAX * 4;
-    pl.off_list_cnt = o; o += align_up((size_t)pl.G * 64 * 4, 256);      // every scan workgroup overwrites its 64 words: no reset
+    pl.off_list_cnt = o; o += align_up((size_t)pl.G * nqp * 4, 256);     // every scan workgroup overwrites its words: no reset
     pl.off_wg_stat = o;  o += align_up((size_t)pl.G * 2 * 4, 256);
     pl.total_cap = 131072;                // most candidates of one query the merge takes on (beyond: exact path)
-    pl.off_lists = o;  o += (size_t)pl.G * 64 * pl.cap * 8;
+    pl.off_lists = o;  o += (size_t)pl.G * nqp * pl.cap * 8;
     pl.total = align_up(o, 256);
     pl.scan_lds = (size_t)ScanSmem::buf_off + (size_t)pl.buf_cap * 8 + (ATLAS_TUNING ? 1024 : 0);     // tuning build: + per-tile stamps (its buffer is 128 entries shorter)
+    pl.buf_cap_wide = (int)((160 * 1024 - (size_t)ScanSmemT<QWIDE>::buf_off) / 8) - (ATLAS_TUNING ? 128 : 0);
+    pl.flush_at_wide = pl.buf_cap_wide * 3 / 4;
+    pl.scan_lds_wide = (size_t)ScanSmemT<QWIDE>::buf_off + (size_t)pl.buf_cap_wide * 8 + (ATLAS_TUNING ? 1024 : 0);
     const size_t merge_fixed = align_up((size_t)d * 2, 16) + 64 * 4 + (size_t)MERGE_SMAX * (4 + 4 + 8) + (size_t)(MERGE_GMAX + 8) * 4;
     pl.key_cap = (int)((160 * 1024 - 1024 - merge_fixed) / 4);
     pl.merge_lds = merge_fixed + (size_t)pl.key_cap * 4;
@@ -534,10 +547,10 @@ ScanPlan make_plan(int64_t N, int d, int k, int cus, const ScanVariant& v) {
 }
 
 // the ranges the scan kernel's 32-bit offsets and 26-bit candidate rows can express
-bool scan_plan_supported(const ScanPlan& pl) {
+bool scan_plan_supported(const ScanPlan& pl, const int row_bits = 26) {
     // per-lane byte offsets inside one workgroup's range are 32-bit (buffer voffset)
     if ((pl.rows_per_wg + 2 * pl.tile) * (int64_t)(D_FAST * 2) >= (int64_t)0xfff00000ll) return false;
-    if (pl.rows_per_wg + 2 * pl.tile + pl.pool_rows >= (1 << 26)) return false;        // buffer entries carry 26-bit (virtual) rows
+    if (pl.rows_per_wg + 2 * pl.tile + pl.pool_rows >= (1 << row_bits)) return false;  // buffer entries carry 26-bit (96-query pass: 25-bit) virtual rows
     if ((int64_t)pl.pool_rows * (D_FAST * 2) >= (int64_t)0xfff00000ll) return false;     // one descriptor spans the pool
     return true;
 }
@@ -591,6 +604,7 @@ extern "C" int atlas_dbg_f64_to_f16(const double* in, uint16_t* out, int n, void
 void atlas_tune_set_scan_variant(int v) { g_scan_variant = v; }
 void atlas_tune_set_scan_coop(int c) { g_scan_coop = c; }
 void atlas_tune_set_scan_fused(int f) { g_scan_fused = f; }
+void atlas_tune_set_scan_wide(int f) { g_scan_wide = f; }
 void atlas_tune_set_scan_pool(int permille, int max_per_wg) { g_pool_permille = permille; g_pool_max = max_per_wg; }
 // the launch plan of a scan over N rows on a device with `cus` CUs, for host-side checks of its invariants (no GPU needed):
 // out = {G, rows_per_wg, pool_begin, pool_rows, pool_tiles, tile, pool_tile, supported (the range checks of atlas_scan_topk)}
@@ -622,11 +636,10 @@ const char* atlas_build_info(void) {
 }
 
 size_t atlas_scan_topk_workspace_bytes(int64_t N, int B, int d, int k) {
-    (void)B;
     if (N < 0 || d <= 0 || k <= 0) return 0;
     size_t mx = 0;     // the variant is a run-time choice: size for the largest
     for (int v = 0; v < kNumVariants; ++v) {
-        const size_t t = make_plan(N, d, k, device_cus(), kVariants[v]).total;
+        const size_t t = make_plan(N, d, k, device_cus(), kVariants[v], B > QCHUNK ? QWIDE : QCHUNK).total;
         mx = t > mx ? t : mx;
     }
     return mx;
@@ -664,24 +677,47 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
     // same shape, same plan; the trusted twin exists for the production variant only
     const bool trusted = (flags & ATLAS_SCAN_TRUST_PMAX) && scan_variant_index() == 0;
     const ScanVariant& var = trusted ? kTrusted : kVariants[scan_variant_index()];
-    const ScanPlan pl = make_plan(N, d, k, device_cus(), var);
+    // Batches above 64 queries: which passes take 96 queries? A 96-query pass costs ~1.10 of a 64-query pass (profiles/r03/
+    // scan_96_query_proxy.txt); f(n) = min(1 + f(n - 64), 1.10 + f(n - 96)) picks e.g. 64 + 64 for 128, 96 + 96 for 192, 5 x 96 + 32 for 512.
+    // Wide passes need the coop exchange (one granule slot per query and workgroup) and the production shape.
+    ScanPlan pl = make_plan(N, d, k, device_cus(), var);
+    const bool wide_ok = B > QCHUNK && scan_variant_index() == 0 && pl.S > 0 && pl.G >= QWIDE && pl.G <= 256 && scan_coop_enabled() &&
+                         scan_wide_enabled() && scan_plan_supported(pl, 25);
+    if (wide_ok) pl = make_plan(N, d, k, device_cus(), var, QWIDE);
     if (!scan_plan_supported(pl)) return ATLAS_E_UNSUPPORTED;
     if (ws_bytes < pl.total) return ATLAS_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     unsigned char* w = (unsigned char*)ws;
+    std::vector<int> chunk;                     // queries of every pass, in order
+    if (!wide_ok) {
+        for (int r = B; r > 0; r -= QCHUNK) chunk.push_back(r < QCHUNK ? r : QCHUNK);
+    } else {
+        std::vector<float> f((size_t)B + 1, 0.f);
+        std::vector<unsigned char> take((size_t)B + 1, 0);
+        for (int n = 1; n <= B; ++n) {
+            const float c64 = 1.0f + f[n > QCHUNK ? n - QCHUNK : 0], c96 = 1.10f + f[n > QWIDE ? n - QWIDE : 0];
+            take[n] = c96 < c64 ? 1 : 0;
+            f[n] = take[n] ? c96 : c64;
+        }
+        for (int r = B; r > 0;) { const int c = take[r] ? QWIDE : QCHUNK; chunk.push_back(r < c ? r : c); r -= c; }
+    }
+    const ScanVariant& wide = trusted ? kWideTrusted : kWide;
 
     auto merge = merge_rescore_kernel<MERGE_NT>;
     allow_lds(var.kern);
+    if (wide_ok) allow_lds(wide.kern);
     allow_lds(merge);
     allow_lds(sample_scores_kernel);
 
     hipError_t e = hipSuccess;
-    for (int q0 = 0; q0 < B; q0 += QCHUNK) {
-        const int nq = (B - q0 < QCHUNK) ? (B - q0) : QCHUNK;
+    int q0 = 0;
+    for (size_t ci = 0; ci < chunk.size(); q0 += chunk[ci], ++ci) {
+        const int nq = chunk[ci];
+        const bool is_wide = nq > QCHUNK;
         // initial thresholds: the scan derives them from the tile maxima of an evenly spread sample; small shards
         // start at -inf. Whoever runs first clears the per-call state (per-query fallback flags, status header).
         // coop scan: the workgroups' first tiles are the sample (one launch less); needs one granule per (query, workgroup) lane slot
-        const bool coop = pl.S > 0 && pl.G >= QCHUNK && pl.G <= 256 && scan_coop_enabled();
+        const bool coop = pl.S > 0 && pl.G >= (is_wide ? QWIDE : QCHUNK) && pl.G <= 256 && scan_coop_enabled();
         if (coop) {
             // nothing to launch: workgroup 0 of the scan clears the status header, the flags were cleared by the previous merge
         } else if (pl.S > 0) {
@@ -691,7 +727,7 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
             sm.qflag = (uint32_t*)(w + pl.off_qflag); sm.theta_gran = (unsigned long long*)(w + pl.off_gran); sm.q16 = (uint4*)(w + pl.off_q16); sm.out_status = out_status;
             hipLaunchKernelGGL(sample_scores_kernel, dim3(pl.S / 64), dim3(SAMPLE_NT), (size_t)QIMG_U4 * 16, stream, sm);
         } else {
-            e = hipMemsetAsync(w + pl.off_qflag, 0, 256, stream);
+            e = hipMemsetAsync(w + pl.off_qflag, 0, 512, stream);
             if (e == hipSuccess && q0 == 0) e = hipMemsetAsync(out_status, 0, ATLAS_STATUS_HEADER * 4, stream);
             if (e != hipSuccess) return (int)e;
         }
@@ -710,7 +746,7 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
         sp.qflag = (uint32_t*)(w + pl.off_qflag);
         sp.pool_begin = pl.pool_begin; sp.pool_rows = pl.pool_rows; sp.pool_tiles = pl.pool_tiles; sp.ticket = (uint32_t*)(w + pl.off_epoch + 128);
         sp.rows_per_wg = pl.rows_per_wg; sp.nq = nq; sp.k = k; sp.cap = pl.cap; sp.keep_max = pl.keep_max;
-        sp.buf_cap = pl.buf_cap; sp.flush_at = pl.flush_at;
+        sp.buf_cap = is_wide ? pl.buf_cap_wide : pl.buf_cap; sp.flush_at = is_wide ? pl.flush_at_wide : pl.flush_at;
         sp.pmax2_hint = pmax_hint * pmax_hint;
         sp.dbg = g_scan_dbg;
         if (q0 == 0 && ev_scan_begin) (void)hipEventRecord((hipEvent_t)ev_scan_begin, stream);
@@ -725,12 +761,13 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
         mp.out_packed = out_packed; mp.id_mul = id_mul; mp.id_add = id_add;
 #if ATLAS_TUNING
         // experiment (scan_kernel.h, ScanParams::fused): the merge inside the scan's last nq workgroups
-        const bool fused = coop && var.nw * 64 == MERGE_NT && pl.G >= nq && pl.merge_lds <= pl.scan_lds && scan_fused_enabled();
+        const bool fused = !is_wide && coop && var.nw * 64 == MERGE_NT && pl.G >= nq && pl.merge_lds <= pl.scan_lds && scan_fused_enabled();
         sp.fused = fused ? 1 : 0; sp.fuse = (uint32_t*)(w + pl.off_fuse); sp.mp = mp;
 #else
         constexpr bool fused = false;
 #endif
-        hipLaunchKernelGGL(var.kern, dim3(pl.G), dim3(var.nw * 64), pl.scan_lds, stream, sp);
+        if (is_wide) hipLaunchKernelGGL(wide.kern, dim3(pl.G), dim3(wide.nw * 64), pl.scan_lds_wide, stream, sp);
+        else hipLaunchKernelGGL(var.kern, dim3(pl.G), dim3(var.nw * 64), pl.scan_lds, stream, sp);
         if (q0 == 0 && ev_scan_end) (void)hipEventRecord((hipEvent_t)ev_scan_end, stream);
         if (!fused) hipLaunchKernelGGL(merge, dim3(nq), dim3(MERGE_NT), pl.merge_lds, stream, mp);
     }

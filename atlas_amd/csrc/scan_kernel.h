@@ -78,10 +78,10 @@ static __device__ __forceinline__ uint4 q8_to_f16(const QRaw r, const int q_dtyp
 // basic block (second half loaded, WAITED for and converted, then the first half requested): six serialised trips to the L2 per thread.
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // `after_first_loads` runs once, when the first batch of loads has been issued and before anything waits for them
-template <int NT, class Hook = NoHook>
+template <int NT, class Hook = NoHook, int NQ = QCHUNK>
 static __device__ __forceinline__ void fill_query_image(uint4* __restrict__ s_q, const void* __restrict__ q, const int q_dtype,
                                                         const int q0, const int nq, const int tid, Hook after_first_loads = Hook()) {
-    constexpr int CH = QCHUNK * (D_FAST / 8);          // 6144 chunks of 8 elements
+    constexpr int CH = NQ * (D_FAST / 8);              // 6144 chunks of 8 elements (64 queries)
     constexpr int PER = CH / NT;                       // 6 per thread with 1024 threads, 24 with 256
     constexpr int BATCH = PER % 6 == 0 ? 6 : PER % 4 == 0 ? 4 : PER % 3 == 0 ? 3 : PER % 2 == 0 ? 2 : 1;   // loads in flight per thread
     static_assert(CH % NT == 0 && PER % BATCH == 0, "chunks must divide over the threads");
@@ -256,23 +256,32 @@ struct ScanParams {
 enum : uint32_t { FUSE_FREE = 0u, FUSE_ABANDONED = 1u, FUSE_MERGING = 2u };
 #define ATLAS_FUSE_WAIT_TICKS 10000ull   // 100 us: how long a finished workgroup waits for the slowest one before it leaves its query to it
 
-struct ScanSmem {   // byte offsets into dynamic LDS
-    static constexpr int q_off = 0;                       // 100352 B: the query image (fill_query_image)
-    static constexpr int theta_off = QIMG_U4 * 16;        // 64 f32
-    static constexpr int cnt_off = theta_off + 256;       // 64 u32
-    static constexpr int flag_off = cnt_off + 256;        // 64 B: [0],[1] flush/compaction request by tile parity, [2] buffer fill
-    static constexpr int aux_off = flag_off + 64;         // 768 B: [0, 256) per-wave norm maxima (final hand-over), [256, 512) per-query eps
-    static constexpr int buf_off = aux_off + 768;         // buf_cap x {u32 score bits, u32 (query<<26)|row}
+template <int NQ>
+struct ScanSmemT {  // byte offsets into dynamic LDS; NQ = queries per slab pass (64, or 96 for the second half of big batches)
+    static constexpr int q_off = 0;                       // the query image (fill_query_image): NQ rows of 1568 bytes
+    static constexpr int theta_off = NQ * QROW_U4 * 16;   // NQ f32
+    static constexpr int cnt_off = theta_off + NQ * 4;    // NQ u32
+    static constexpr int flag_off = cnt_off + NQ * 4;     // 64 B: [0],[1] flush/compaction request by tile parity, [2] buffer fill, [8..15] tile tickets
+    static constexpr int aux_off = flag_off + 64;         // [0, 256) per-wave norm maxima (final hand-over), [256, 256 + 4 NQ) per-query eps
+    static constexpr int buf_off = aux_off + 256 + NQ * 4 + (NQ == 64 ? 256 : 0);   // buf_cap x {u32 score bits, u32 (query << QSHIFT) | row}   (64: the layout of rounds 1-2)
 };
+typedef ScanSmemT<64> ScanSmem;
 
 // AUX & 31 = cache-policy bits of the slab loads (0 = default, 2 = nt: rows are read once by one CU)
 // AUX & 64 = the caller's pmax is certified (ATLAS_SCAN_TRUST_PMAX): the row norms are not measured (4 v_dot2 per MFMA less; the
 //            kernel runs at the board's power limit and that VALU work was 4.6 % of its time, profiles/r02/scan_power.txt)
-// QX (tuning experiment only): extra 16-query fragments per slab k-step, fed from image rows 0 .. 16 QX - 1 again and never kept -- the
-// matrix-pipe, LDS-read and register cost of a pass over 64 + 16 QX queries without its larger image (profiles/r03/scan_96_query_proxy.txt)
-template <int NW, int PF, int RING, int AUX = 0, int QX = 0>
+// NQF = 16-query fragments per slab k-step: 4 (64 queries per pass: every search of up to 64 queries) or 6 (96 queries per pass, round 3:
+//       batches above 64 queries -- a rank of an N-GPU search scores ALL gathered queries -- read the slab once per 96 instead of once
+//       per 64. The stream is 10 % slower under 6 MFMAs + 6 LDS reads per 16-byte load -- the kernel sits at the board's power limit --
+//       for 50 % more queries per byte: x 1.36, profiles/r03/scan_96_query_proxy.txt. The 147 KiB image leaves 11.5 KiB of candidate
+//       buffer (1 480 entries instead of 7 680: a flush per ~1 100 candidates), and candidate entries carry a 7-bit query + 25-bit row)
+template <int NW, int PF, int RING, int AUX = 0, int NQF = 4>
 __global__ void __launch_bounds__(NW * 64)
 scan_kernel(const ScanParams p) {
+    constexpr int NQ = 16 * NQF;                           // queries per pass
+    constexpr int QSHIFT = NQ > 64 ? 25 : 26;              // candidate entry: (query << QSHIFT) | virtual row
+    constexpr uint32_t ROWMASK = (1u << QSHIFT) - 1u;
+    typedef ScanSmemT<NQ> ScanSmem;
     // RING slots of PF fragments: RING-1 k-steps of loads in flight while one slot is consumed
     static_assert(KSTEPS % RING == 0 && RING >= 2, "prefetch ring must divide the k-steps");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -413,7 +422,7 @@ scan_kernel(const ScanParams p) {
         trow[0] = load_q8(p.q, p.q_dtype, base + (size_t)lane * 8);                         // chunks 0..63
         trow[1] = load_q8(p.q, p.q_dtype, base + (size_t)(64 + (lane & 31)) * 8);           // chunks 64..95 (lanes >= 32 repeat them)
     }
-    fill_query_image<NW * 64>(s_q, p.q, p.q_dtype, p.q0, p.nq, tid, [&]() {
+    auto image_hook = [&]() {
         // EVERY wave's image loads are queued before ANY wave's slab loads (a raw barrier: nothing is waited for). The CU's L1 serves its
         // queue in order and holds a bounded number of misses: slab loads (cold HBM, all 256 workgroups at once) queued in front of
         // another wave's image loads (L2 hits) kept the image barrier waiting until ~10 us after entry (tools stamps, round 3)
@@ -436,14 +445,15 @@ scan_kernel(const ScanParams p) {
         const float th = initial_theta(tv, p.sample_blocks, p.k, query_eps(ss, p.pmax), lane);
         if (lane == 0) __hip_atomic_store(gran + blockIdx.x, (1ull << 32) | (unsigned long long)f32_bits(th), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ATLAS_SCAN_STAMP_LANE0(6);   // [6] threshold of query blockIdx.x published
-    });
-    if (tid < 64) s_cnt[tid] = 0;
+    };
+    fill_query_image<NW * 64, decltype(image_hook), NQ>(s_q, p.q, p.q_dtype, p.q0, p.nq, tid, image_hook);
+    if (tid < NQ) s_cnt[tid] = 0;
     if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; }
     if (tid < 4) s_tk[tid] = 0ull;      // sequence number 0 is never asked for (LDS keeps the previous kernel's words)
     __syncthreads();
     float* s_eps = (float*)(smem + ScanSmem::aux_off + 256);
     if (wave == NW - 1) ATLAS_SCAN_STAMP_LANE0(1);   // [1] (re-stamped) image barrier passed
-    for (int qq = wave; qq < QCHUNK; qq += NW) {
+    for (int qq = wave; qq < NQ; qq += NW) {
         const float eps = qq < p.nq ? query_eps(image_row_sumsq(s_q, qq, lane), p.pmax) : 0.f;
         if (lane == 0) s_eps[qq] = eps;
     }
@@ -460,17 +470,17 @@ scan_kernel(const ScanParams p) {
             s_theta[lane] = want ? ((g >> 32) != 0ull ? bits_f32((uint32_t)g) : neg_inf()) : pos_inf();
             ATLAS_SCAN_STAMP_LANE0(7);   // [7] all thresholds collected
         }
-    } else if (tid < 64) {
+    } else if (tid < NQ) {
         s_theta[tid] = (tid < p.nq) ? neg_inf() : pos_inf();      // query slots beyond nq never collect anything
     }
     __syncthreads();
     ATLAS_SCAN_STAMP(2);        // [2] query image, eps and thresholds in LDS
 
-    f32x4 acc[PF][4 + QX];
+    f32x4 acc[PF][NQF];
 #pragma unroll
     for (int pf = 0; pf < PF; ++pf)
 #pragma unroll
-        for (int qf = 0; qf < 4 + QX; ++qf) acc[pf][qf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int qf = 0; qf < NQF; ++qf) acc[pf][qf] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float nrm[PF];
 #pragma unroll
     for (int pf = 0; pf < PF; ++pf) nrm[pf] = 0.f;
@@ -496,9 +506,9 @@ scan_kernel(const ScanParams p) {
         const uint32_t nbuf = s_flag[2] < (uint32_t)p.buf_cap ? s_flag[2] : (uint32_t)p.buf_cap;
         for (uint32_t i = tid; i < nbuf; i += NW * 64) {
             const uint2 e = s_buf[i];
-            const uint32_t qq = e.y >> 26;
+            const uint32_t qq = e.y >> QSHIFT;
             const uint32_t gs = atomicAdd(&s_cnt[qq], 1u);
-            if (gs < (uint32_t)p.cap) my_lists[qq * qstride + gs] = make_uint2(e.x, global_row(e.y & 0x03ffffffu));
+            if (gs < (uint32_t)p.cap) my_lists[qq * qstride + gs] = make_uint2(e.x, global_row(e.y & ROWMASK));
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);     // list stores complete before anyone reads them back
         wg_barrier_lds();
@@ -571,24 +581,27 @@ scan_kernel(const ScanParams p) {
     // collects the G maxima of query q, takes their k-th largest (scores of distinct rows -> a certified threshold) and publishes it; every
     // workgroup collects the 64 thresholds, then filters the tile it is still holding in registers. Two hops of ~3 us. Every wait is
     // bounded: a maximum or threshold that has not arrived counts as -inf (slower, never wrong), so nothing depends on co-residency.
-    auto first_tile_exchange = [&](const float (&tm)[4]) {
+    auto first_tile_exchange = [&](const float (&tm)[NQF]) {
         float* s_tmax = (float*)s_buf;                     // [NW][64] scratch: the candidate buffer is still empty
         gu64* gmax = (gu64*)p.gran_max;
         const uint32_t G = gridDim.x;
         if (lgrp == 0) {
 #pragma unroll
-            for (int qf = 0; qf < 4; ++qf) s_tmax[wave * 64 + qf * 16 + lrow] = tm[qf];
+            for (int qf = 0; qf < NQF; ++qf) s_tmax[wave * NQ + qf * 16 + lrow] = tm[qf];
         }
         wg_barrier_lds();
         if (tid < p.nq) {
             float m = s_tmax[tid];
-            for (int w = 1; w < NW; ++w) m = fmaxf(m, s_tmax[w * 64 + tid]);
+            for (int w = 1; w < NW; ++w) m = fmaxf(m, s_tmax[w * NQ + tid]);
             uint32_t to = (uint32_t)tid;                   // the granule's address is formed here, not hoisted over the slab loop into scratch
             asm volatile("" : "+v"(to));
             __hip_atomic_store(gmax + (size_t)to * G + blockIdx.x, ((unsigned long long)tag << 32) | (unsigned long long)f32_bits(m),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (wave == NW - 1) {
+            // (granule addresses are formed HERE, from a lane index hipcc cannot trace back: hoisted over the slab loop they end up in scratch)
+            uint32_t lane_o = (uint32_t)lane;
+            asm volatile("" : "+v"(lane_o));
             if ((int)blockIdx.x < p.nq) {                  // this workgroup derives the threshold of query blockIdx.x
                 const int qq = blockIdx.x;
                 unsigned long long g[4] = {0ull, 0ull, 0ull, 0ull};
@@ -596,7 +609,7 @@ scan_kernel(const ScanParams p) {
                     bool missing = false;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const uint32_t i = (uint32_t)lane + 64u * u;
+                        const uint32_t i = lane_o + 64u * u;
                         if (i < G && (uint32_t)(g[u] >> 32) != tag) {
                             g[u] = __hip_atomic_load(gmax + (size_t)qq * G + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             missing |= (uint32_t)(g[u] >> 32) != tag;
@@ -613,21 +626,37 @@ scan_kernel(const ScanParams p) {
                 if (lane == 0) __hip_atomic_store(gran + qq, ((unsigned long long)tag << 32) | (unsigned long long)f32_bits(th), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ATLAS_SCAN_STAMP_LANE0(6);   // [6] threshold of query blockIdx.x published
             }
-            unsigned long long g = 0ull;
-            const bool want = lane < p.nq;
+            constexpr int QR = (NQ + 63) / 64;             // rounds of 64 queries
+            unsigned long long g[QR];
+#pragma unroll
+            for (int u = 0; u < QR; ++u) g[u] = 0ull;
             for (const unsigned long long spin_end = wall_clock64() + ATLAS_SPIN_TICKS; ; ) {
-                if (want && (uint32_t)(g >> 32) != tag) g = __hip_atomic_load(gran + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__builtin_amdgcn_ballot_w64(want && (uint32_t)(g >> 32) != tag) == 0ull) break;
+                bool missing = false;
+#pragma unroll
+                for (int u = 0; u < QR; ++u) {
+                    const int qi = (int)lane_o + 64 * u;
+                    if (qi < p.nq && (uint32_t)(g[u] >> 32) != tag) {
+                        g[u] = __hip_atomic_load(gran + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        missing |= (uint32_t)(g[u] >> 32) != tag;
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(missing) == 0ull) break;
                 if (wall_clock64() >= spin_end) break;
                 __builtin_amdgcn_s_sleep(2);
             }
-            s_theta[lane] = want ? ((uint32_t)(g >> 32) == tag ? bits_f32((uint32_t)g) : neg_inf()) : pos_inf();
+#pragma unroll
+            for (int u = 0; u < QR; ++u) {
+                const int qi = lane + 64 * u;
+                if (qi < NQ) s_theta[qi] = qi < p.nq ? ((uint32_t)(g[u] >> 32) == tag ? bits_f32((uint32_t)g[u]) : neg_inf()) : pos_inf();
+            }
             ATLAS_SCAN_STAMP_LANE0(7);   // [7] all thresholds collected
         }
         wg_barrier_lds();
     };
     if (p.coop && ntiles == 0) {               // a workgroup without rows still owes the others its (empty) maxima
-        const float none[4] = {neg_inf(), neg_inf(), neg_inf(), neg_inf()};
+        float none[NQF];
+#pragma unroll
+        for (int qf = 0; qf < NQF; ++qf) none[qf] = neg_inf();
         first_tile_exchange(none);
     }
 
@@ -641,6 +670,7 @@ scan_kernel(const ScanParams p) {
         // query group 3 does not fit the 16-bit immediate of ds_read_b128)
         const uint4* bq0 = s_q + lrow * QROW_U4 + lgrp + cstep * 4;
         const uint4* bq2 = bq0 + 32 * QROW_U4;
+        const uint4* bq4 = bq0 + 64 * QROW_U4;             // (NQF == 6)
 #pragma unroll
         for (int j = 0; j < RING; ++j) {
             // refill the slot freed by the previous step first (its loads stay in flight for
@@ -652,16 +682,15 @@ scan_kernel(const ScanParams p) {
                 abuf[fill][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)vo[pf], fill_step * 64, AUX & 31);
             fill_advance(j == 0);
             __builtin_amdgcn_sched_barrier(0);
-            uint4 b[4 + QX];
+            uint4 b[NQF];
 #pragma unroll
-            for (int qf = 0; qf < 4 + QX; ++qf)           // (extra fragments: rows shifted by 8, so that they are LDS reads of their own)
-                b[qf] = ((qf & 3) < 2 ? bq0 : bq2)[((qf & 1) * 16 + (qf >= 4 ? 8 : 0)) * QROW_U4 + j * 4];
+            for (int qf = 0; qf < NQF; ++qf) b[qf] = (qf < 2 ? bq0 : qf < 4 ? bq2 : bq4)[(qf & 1) * 16 * QROW_U4 + j * 4];
 #pragma unroll
             for (int pf = 0; pf < PF; ++pf) {
                 const u32x4 a = abuf[j][pf];
                 const f16x8 av = __builtin_bit_cast(f16x8, a);
 #pragma unroll
-                for (int qf = 0; qf < 4 + QX; ++qf)
+                for (int qf = 0; qf < NQF; ++qf)
                     acc[pf][qf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
                         av, __builtin_bit_cast(f16x8, b[qf]), acc[pf][qf], 0, 0, 0);
                 // row sum of squares (certifies pmax_hint): 4 x v_dot2_f32_f16
@@ -694,28 +723,24 @@ scan_kernel(const ScanParams p) {
                 x += __shfl_xor(x, 32);
                 pm = fmaxf(pm, x);
             }
-            // rows past the end of this workgroup's range never become candidates
-            if (row0 + PF * 16 > nrows) {
-#pragma unroll
-                for (int pf = 0; pf < PF; ++pf)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (row0 + pf * 16 + lgrp * 4 + r >= nrows) {
-#pragma unroll
-                            for (int qf = 0; qf < 4; ++qf) acc[pf][qf][r] = neg_inf();
-                        }
-            }
         }
-        if (p.coop && c_seq == 0) {            // workgroup-uniform: the end of every wave's FIRST tile
-            float tm[4];
+        // rows past the end of this workgroup's range never become candidates (a per-row flag that the maxima and the filter look at: writing
+        // -inf into the accumulators of a partial tile made hipcc keep two copies of them -- with 24 accumulators, in scratch)
+        bool vr[PF][4];
 #pragma unroll
-            for (int qf = 0; qf < 4; ++qf) {
+        for (int pf = 0; pf < PF; ++pf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vr[pf][r] = row0 + pf * 16 + lgrp * 4 + r < nrows;
+        if (p.coop && c_seq == 0) {            // workgroup-uniform: the end of every wave's FIRST tile
+            float tm[NQF];
+#pragma unroll
+            for (int qf = 0; qf < NQF; ++qf) {
                 float m = neg_inf();
                 if (have_rows) {
 #pragma unroll
                     for (int pf = 0; pf < PF; ++pf)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[pf][qf][r]);
+                        for (int r = 0; r < 4; ++r) m = fmaxf(m, vr[pf][r] ? acc[pf][qf][r] : neg_inf());
                 }
                 m = fmaxf(m, __shfl_xor(m, 16));
                 tm[qf] = fmaxf(m, __shfl_xor(m, 32));
@@ -724,25 +749,16 @@ scan_kernel(const ScanParams p) {
         }
         if (have_rows) {
             // threshold filter: lane l owns query 16*qf + (l&15) in acc[.][qf]
-            float th[4];
+            float th[NQF];
 #pragma unroll
-            for (int qf = 0; qf < 4; ++qf) th[qf] = s_theta[qf * 16 + lrow];
+            for (int qf = 0; qf < NQF; ++qf) th[qf] = s_theta[qf * 16 + lrow];
             bool any = false;
 #pragma unroll
             for (int pf = 0; pf < PF; ++pf)
 #pragma unroll
-                for (int qf = 0; qf < 4; ++qf)
+                for (int qf = 0; qf < NQF; ++qf)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) any |= acc[pf][qf][r] > th[qf];
-            if constexpr (QX > 0) {                          // (the extra fragments are looked at, so that they are computed, and never pass)
-                const float never = p.pmax * 1e30f;
-#pragma unroll
-                for (int pf = 0; pf < PF; ++pf)
-#pragma unroll
-                    for (int qf = 4; qf < 4 + QX; ++qf)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) any |= acc[pf][qf][r] > never;
-            }
+                    for (int r = 0; r < 4; ++r) any |= vr[pf][r] && acc[pf][qf][r] > th[qf];
             if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
                 // Candidates go to a workgroup-wide LDS buffer: LDS traffic is counted in lgkmcnt, so the
                 // ring of HBM loads (vmcnt) is not disturbed. (gfx9 counts loads and stores in one vmcnt
@@ -759,15 +775,15 @@ scan_kernel(const ScanParams p) {
 #pragma unroll
                 for (int pf = 0; pf < PF; ++pf)
 #pragma unroll
-                    for (int qf = 0; qf < 4; ++qf)
+                    for (int qf = 0; qf < NQF; ++qf)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float v = acc[pf][qf][r];
-                            if (v > th[qf]) {
+                            if (vr[pf][r] && v > th[qf]) {
                                 const uint32_t qq = (uint32_t)(qf * 16) + lrow_o;
                                 const uint32_t slot = atomicAdd(&s_flag[2], 1u);
                                 if (slot < (uint32_t)p.buf_cap) {
-                                    s_buf[slot] = make_uint2(f32_bits(v), (qq << 26) | (rrel + (uint32_t)(pf * 16 + r)));
+                                    s_buf[slot] = make_uint2(f32_bits(v), (qq << QSHIFT) | (rrel + (uint32_t)(pf * 16 + r)));
                                     if (slot >= (uint32_t)p.flush_at) s_flag[par] = 1u;   // request a flush
                                 } else {
                                     const uint32_t gs = atomicAdd(&s_cnt[qq], 1u);
@@ -787,7 +803,7 @@ scan_kernel(const ScanParams p) {
         for (int pf = 0; pf < PF; ++pf) {
             nrm[pf] = 0.f;
 #pragma unroll
-            for (int qf = 0; qf < 4 + QX; ++qf) acc[pf][qf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int qf = 0; qf < NQF; ++qf) acc[pf][qf] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 
         wg_barrier_lds();
@@ -827,9 +843,9 @@ scan_kernel(const ScanParams p) {
         const uint32_t nbuf = s_flag[2] < (uint32_t)p.buf_cap ? s_flag[2] : (uint32_t)p.buf_cap;
         for (uint32_t i = tid; i < nbuf; i += NW * 64) {
             const uint2 e = s_buf[i];
-            const uint32_t qq = e.y >> 26;
+            const uint32_t qq = e.y >> QSHIFT;
             const uint32_t gs = atomicAdd(&s_cnt[qq], 1u);
-            if (gs < (uint32_t)p.cap) my_lists[qq * qstride + gs] = make_uint2(e.x, global_row(e.y & 0x03ffffffu));
+            if (gs < (uint32_t)p.cap) my_lists[qq * qstride + gs] = make_uint2(e.x, global_row(e.y & ROWMASK));
         }
         // largest row norm^2 of the workgroup (x1.001: v_dot2 accumulates in fp32): waves -> LDS -> one word
 #pragma unroll
@@ -837,7 +853,7 @@ scan_kernel(const ScanParams p) {
         float* s_pm = (float*)(smem + ScanSmem::aux_off);
         if (lane == 0) s_pm[wave] = pm;
         wg_barrier_lds();
-        if (tid < 64) {
+        if (tid < NQ) {
             uint32_t c = (tid < p.nq) ? s_cnt[tid] : 0u;
             if (c > (uint32_t)p.cap) { p.qflag[tid] = 1u; c = 0u; }          // a list overflowed -> exact path
             p.list_cnt[(size_t)tid * gridDim.x + blockIdx.x] = c;
@@ -864,7 +880,7 @@ scan_kernel(const ScanParams p) {
     // before the mark: then this workgroup takes its query back, CAS(ABANDONED -> MERGING)); last arriver: publish the tag in fuse[2],
     // THEN read fuse[1], THEN CAS(ABANDONED -> MERGING) per query: exactly one of the two merges every query. (Tags are unique per
     // call: nothing but the arrival counter and the states of merged queries has to be put back.)
-    if constexpr (NW * 64 == 1024) {
+    if constexpr (NW * 64 == 1024 && NQF == 4) {
         if (p.fused) {
             uint32_t* s_fz = (uint32_t*)(smem + ScanSmem::flag_off);       // [4], [5]: free from here on (the tile tickets used [8..15])
             const uint32_t G = gridDim.x, first = G - (uint32_t)p.nq;

@@ -51,6 +51,29 @@ def test_scan_bit_exact_vs_oracle(N, B, k, ps, gpu_index_cls, oracle_mod):
     assert st["max_err_over_eps"] < 0.25, st        # measured MFMA error vs the certified bound
 
 
+@pytest.mark.parametrize("N,B,k,ps", [(100000, 96, 40, 301), (100000, 97, 40, 302), (100000, 160, 40, 303), (120000, 192, 40, 304),
+                                     (100000, 200, 100, 305), (70000, 512, 40, 306), (70000, 80, 256, 307), (40000, 300, 40, 308)])
+def test_batches_above_64_queries_bit_exact_vs_oracle(N, B, k, ps, gpu_index_cls, oracle_mod):
+    """a rank of an N-GPU search scores ALL gathered queries (index.py:127-131): batches above 64 run as a mix of 64- and 96-query slab
+    passes (96 + 1, 64 + 96, 96 + 96, 96 + 96 + 8, 5 x 96 + 32, one pass of 80; the 40k-row shard is too small for the wide pass)"""
+    P = synth.passages_f16(N, 768, ps)
+    Q = synth.queries_f32(B, 768, ps + 1)
+    idx = _index(gpu_index_cls, P)
+    s, i = _search(idx, Q, k)
+    es, ei = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, k)
+    parity.assert_identical(s, i, es, ei, f"N={N} B={B} k={k}")
+    st = idx.last_search_stats
+    # (k = 256 on a 70k-row shard: the k-th of the 256 first-tile maxima is no threshold at all, every row is a candidate and some queries'
+    #  bands outgrow the merge -- they take the exact path, with 64-query passes as well: correct, and not what this test is about)
+    assert st["path"] == "scan" and (k > 128 or st["fallback_queries"] == 0), st
+    # same again with duplicated passages in the shard: the flush / compaction path of the wide pass's small candidate buffer
+    P2 = np.concatenate([P[: N // 2], P[: N // 2]])
+    idx2 = _index(gpu_index_cls, P2)
+    s2, i2 = _search(idx2, Q[:B], k)
+    es2, ei2 = oracle_mod.search(oracle_mod.f32_to_f16(Q), P2, k)
+    parity.assert_identical(s2, i2, es2, ei2, f"duplicated halves, N={N} B={B} k={k}")
+
+
 @pytest.mark.parametrize("case", ["a10k", "b3k", "c_dups", "d_k128"])
 def test_scan_vs_reference_golden(case, gpu_index_cls, oracle_mod):
     """HIP path vs the outputs of the reference's own DistributedIndex (tie-/1-ulp-aware, see parity.py)."""
