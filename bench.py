@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--refresh-batches", type=int, default=30, help="timed 512-passage encoder batches for the index-refresh leg (0 = skip)")
     ap.add_argument("--refresh-len", type=int, default=128, help="tokens per passage in the refresh leg")
     ap.add_argument("--refresh-stream-seconds", type=float, default=15.0, help="sustained streamed-refresh leg from the token store, with rocm-smi power / clock samples (0 = skip)")
-    ap.add_argument("--batch-sweep", type=str, default="64,128,256,512", help="query-batch sizes timed on the 4M-row prefix (a rank of an N-GPU search scores ALL gathered queries; N=1 only; '' = skip)")
+    ap.add_argument("--batch-sweep", type=str, default="64,96,128,192,256,512", help="query-batch sizes timed on the 4M-row prefix (a rank of an N-GPU search scores ALL gathered queries; N=1 only; '' = skip)")
     ap.add_argument("--shard-sweep", type=str, default="1000000,4000000,8000000,16000000",
                     help="prefix sizes of the slab timed like the headline: configs[1] and the per-GPU shards of an 8 / 4 / 2-GPU run (N=1 only; '' = skip)")
     ap.add_argument("--oracle-query", type=int, default=31, help="query of the batch held to the CPU oracle at full size in the cpu_baseline leg (-1 = skip)")
@@ -328,7 +328,18 @@ def main():
             del sub
 
     # ---- larger query batches on the 4M-row prefix (the shard of an 8-GPU run): a rank of a distributed search scores ALL gathered
-    # queries (src/index.py:127-131), B_total = W x b_r; the scan takes them 64 at a time, one slab pass each
+    # queries (src/index.py:127-131), B_total = W x b_r; the scan takes them in slab passes of 64 or 96 queries (atlas_hip.hip: the
+    # chunk plan; a 96-query pass costs ~1.10 of a 64-query pass)
+    def pass_plan(n):
+        f, take = [0.0] * (n + 1), [0] * (n + 1)
+        for m in range(1, n + 1):
+            c64, c96 = 1.0 + f[max(m - 64, 0)], 1.10 + f[max(m - 96, 0)]
+            take[m], f[m] = (96, c96) if c96 < c64 else (64, c64)
+        out = []
+        while n > 0:
+            out.append(min(n, take[n])); n -= take[n]
+        return out
+
     batch_sweep = None
     if world == 1 and args.batch_sweep and rows >= 4_000_000:
         batch_sweep = {}
@@ -361,8 +372,9 @@ def main():
             sel_b = torch.tensor(sorted({min(Bb - 1, j * (Bb // 8) + 3) for j in range(8)}), device=dev)
             es_b, ei_b = subb._exact_topk(qb[sel_b], k)
             assert torch.equal(o_s[sel_b], es_b) and torch.equal(o_i[sel_b], ei_b), f"B={Bb}: scan disagrees with the exact path"
-            passes = (Bb + 63) // 64
-            batch_sweep[str(Bb)] = {"ms_per_step": dtb * 1e3, "queries_per_s": Bb / dtb, "slab_passes": passes,
+            plan_b = pass_plan(Bb) if Bb > 64 else [Bb]
+            passes = len(plan_b)
+            batch_sweep[str(Bb)] = {"ms_per_step": dtb * 1e3, "queries_per_s": Bb / dtb, "slab_passes": passes, "queries_per_pass": plan_b,
                                     "bytes_read_per_query": passes * n_b * D * 2 / Bb, "step_frac_of_hbm_peak": passes * n_b * D * 2 / dtb / 1e9 / HBM_PEAK_GBS,
                                     "parity_checked": {"rows": n_b, "queries_exact": int(sel_b.numel())}}
         del subb
