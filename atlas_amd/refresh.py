@@ -38,6 +38,12 @@ class HalfMirror:
         return self.copy
 
 
+# Tokens of one streamed refresh batch: 256 token tiles of 256 = 32 per XCD, whole rounds of tiles for the 32 workgroups of an XCD in every
+# GEMM of the encoder (csrc/encoder.hip: gemm_pt_kernel). Batches formed by passage COUNT (512 x ~132 tokens = 264 tiles) run one round
+# more, nearly empty: 32.8k -> 34.4k passages/s, same process, slab bit-identical (profiles/r03/streamed_token_budget.txt)
+TOKEN_BUDGET = 65536
+
+
 class IndexRefresher:
     def __init__(self, index, contriever_fp16, max_batch: int, max_len: int, depth: int = 3):
         """index: HipDistributedIndex with its slab allocated (init_embeddings); contriever_fp16: atlas_amd.retrievers.Contriever
@@ -46,11 +52,12 @@ class IndexRefresher:
         self.dev = index._slab.device
         self.copy_stream = torch.cuda.Stream(device=self.dev)
         self.depth, self.max_batch, self.max_len = depth, max_batch, max_len
+        # (staging holds max_batch x max_len token slots; a batch cut by tokens may have up to 2 x max_batch shorter passages in them)
         mk = lambda: torch.empty((max_batch, max_len), dtype=torch.int64).pin_memory()     # noqa: E731
-        self._pin = [(mk(), mk(), torch.empty(max_batch, dtype=torch.int64).pin_memory()) for _ in range(depth)]
+        self._pin = [(mk(), mk(), torch.empty(2 * max_batch, dtype=torch.int64).pin_memory()) for _ in range(depth)]
         self._dev = [(torch.empty((max_batch, max_len), dtype=torch.int64, device=self.dev),
                       torch.empty((max_batch, max_len), dtype=torch.int64, device=self.dev),
-                      torch.empty(max_batch, dtype=torch.int64, device=self.dev)) for _ in range(depth)]
+                      torch.empty(2 * max_batch, dtype=torch.int64, device=self.dev)) for _ in range(depth)]
         self._ready = [torch.cuda.Event() for _ in range(depth)]      # H2D of the slot finished
         self._free = [torch.cuda.Event() for _ in range(depth)]       # encoder finished reading the slot
         self._used = [False] * depth
@@ -102,12 +109,21 @@ class IndexRefresher:
         return row - row_offset
 
     @torch.no_grad()
-    def run_store(self, store: TokenStore, batch_size: Optional[int] = None, bucket: bool = True, repeat: int = 1) -> int:
+    def run_store(self, store: TokenStore, batch_size: Optional[int] = None, bucket: bool = True, repeat: int = 1,
+                  token_budget: Optional[int] = None) -> int:
         """One refresh of the whole shard from a token store (`repeat` > 1: back-to-back refreshes, for sustained-rate timing).
-        Row r of the slab receives the embedding of passage r of the store. Asynchronous like `run`."""
+        Row r of the slab receives the embedding of passage r of the store. Asynchronous like `run`.
+        token_budget: batches are cut by tokens (TokenStore.plan); default: TOKEN_BUDGET when the batches are formed by length and
+        batch_size passages of the store's mean length reach it, else by passage count."""
         batch_size = batch_size or self.max_batch
         assert batch_size <= self.max_batch and store.max_length <= self.max_len and len(store) == self.index._slab.shape[0]
-        plan = store.plan(batch_size, bucket)
+        if token_budget is None and bucket and len(store) and batch_size * store.n_tokens / len(store) >= 0.75 * TOKEN_BUDGET:
+            token_budget = TOKEN_BUDGET
+        plan = store.plan(batch_size, bucket, token_budget)
+        if token_budget:                                               # every group has to fit the staging buffers as [n, L]
+            slots = self.max_batch * self.max_len
+            plan = [g for grp in plan for g in ([grp] if grp.shape[0] * int(store.lengths[grp].max()) <= slots
+                                                else [grp[: grp.shape[0] // 2], grp[grp.shape[0] // 2:]])]
         for _ in range(repeat):
             for rows in plan:
                 s = self._slot()

@@ -75,10 +75,24 @@ class TokenStore:
         return cls(torch.from_numpy(np.ascontiguousarray(flat, dtype=np.int32)), off, max_length)
 
     # ------------------------------------------------------------------ batches
-    def plan(self, batch_size: int, bucket: bool = True) -> List[np.ndarray]:
-        """the row groups of one refresh: by token count (stable, so equal lengths stay in passage order) or by position"""
+    def plan(self, batch_size: int, bucket: bool = True, token_budget: Optional[int] = None) -> List[np.ndarray]:
+        """the row groups of one refresh: by token count (stable, so equal lengths stay in passage order) or by position.
+        token_budget: groups are cut by TOKENS instead of passages -- each takes passages (in that order) while their real tokens fit the
+        budget, at most 2 * batch_size of them. The encoder works on packed tokens in 256-token tiles dealt to 8 x 32 workgroups: a batch
+        of 65 536 tokens is 3 / 6 / 12 full rounds of tiles for its GEMMs, a batch of 512 passages x 132 tokens one round more with a
+        few tiles in it (atlas_amd.refresh.TOKEN_BUDGET). Which passages share a batch does not change any embedding."""
         order = np.argsort(self.lengths, kind="stable") if bucket else np.arange(len(self), dtype=np.int64)
-        return [order[a: a + batch_size] for a in range(0, len(self), batch_size)]
+        if not token_budget:
+            return [order[a: a + batch_size] for a in range(0, len(self), batch_size)]
+        cum = np.zeros(len(self) + 1, dtype=np.int64)
+        np.cumsum(self.lengths[order], out=cum[1:])
+        groups, a, cap = [], 0, 2 * batch_size
+        while a < len(self):
+            b = int(np.searchsorted(cum, cum[a] + token_budget, side="right")) - 1      # most passages whose tokens fit
+            b = min(max(b, a + 1), a + cap, len(self))
+            groups.append(order[a:b])
+            a = b
+        return groups
 
     def fill(self, rows: np.ndarray, ids_out: torch.Tensor, mask_out: torch.Tensor) -> int:
         """write the [n, L] int64 `input_ids` / `attention_mask` of the passages `rows` into the (pinned) staging tensors;

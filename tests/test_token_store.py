@@ -47,6 +47,22 @@ def test_bucketed_plan_covers_every_row_once_and_pads_less():
     assert lens_sorted == sorted(lens_sorted)
 
 
+def test_token_budget_plan_covers_every_row_once_within_budget():
+    rng = np.random.default_rng(3)
+    lists = [[7] * int(n) for n in rng.integers(1, 200, size=5000)]
+    store = TokenStore.from_token_lists(lists)
+    for budget, bs in ((4096, 64), (65536, 512), (100, 8)):
+        plan = store.plan(bs, True, budget)
+        assert sorted(np.concatenate(plan).tolist()) == list(range(5000))
+        for g in plan[:-1]:
+            tok = int(store.lengths[g].sum())
+            # a group holds as many passages as fit the budget (or one passage longer than it, or the cap of 2 x batch_size passages)
+            assert tok <= budget or len(g) == 1
+            assert len(g) == 2 * bs or tok + int(store.lengths[plan[plan.index(g) + 1][0]]) > budget or len(g) == 1
+        assert all(1 <= len(g) <= 2 * bs for g in plan)
+    assert [g.tolist() for g in store.plan(64, True, 0)] == [g.tolist() for g in store.plan(64, True)]
+
+
 def test_fill_matches_a_per_passage_loop():
     lists = [[5, 6, 7], [9], [1, 2, 3, 4, 5, 6], [], [8, 8]]
     store = TokenStore.from_token_lists(lists)
