@@ -54,11 +54,11 @@ def test_token_budget_plan_covers_every_row_once_within_budget():
     for budget, bs in ((4096, 64), (65536, 512), (100, 8)):
         plan = store.plan(bs, True, budget)
         assert sorted(np.concatenate(plan).tolist()) == list(range(5000))
-        for g in plan[:-1]:
+        for gi, g in enumerate(plan[:-1]):
             tok = int(store.lengths[g].sum())
             # a group holds as many passages as fit the budget (or one passage longer than it, or the cap of 2 x batch_size passages)
             assert tok <= budget or len(g) == 1
-            assert len(g) == 2 * bs or tok + int(store.lengths[plan[plan.index(g) + 1][0]]) > budget or len(g) == 1
+            assert len(g) == 2 * bs or tok + int(store.lengths[plan[gi + 1][0]]) > budget or len(g) == 1
         assert all(1 <= len(g) <= 2 * bs for g in plan)
     assert [g.tolist() for g in store.plan(64, True, 0)] == [g.tolist() for g in store.plan(64, True)]
 
