@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_SO = os.environ.get("ATLAS_HIP_SO") or os.path.join(HERE, "lib", "libatlas_hip.so")   # ATLAS_HIP_SO: A/B runs of two builds (dev)
 TUNE_SO = os.path.join(HERE, "lib", "libatlas_hip_tune.so")   # the -DATLAS_TUNING=1 build: lib(tuning=True), tools/ and configuration tests only
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 DT_F16, DT_F32, DT_BF16 = 0, 1, 2
 STATUS_HEADER = 8
 SCAN_TRUST_PMAX = 1          # ATLAS_SCAN_TRUST_PMAX
@@ -26,6 +26,7 @@ SYMBOLS = [
     "atlas_scan_topk_workspace_bytes", "atlas_scan_topk", "atlas_scan_topk_ex", "atlas_scan_topk_flags", "atlas_scan_topk_pack",
     "atlas_exact_topk_workspace_bytes", "atlas_exact_topk",
     "atlas_pack_candidates", "atlas_merge_packed",
+    "atlas_xchg_bytes", "atlas_xchg_create", "atlas_xchg_open", "atlas_xchg_close", "atlas_xchg_destroy", "atlas_xchg_push", "atlas_xchg_merge",
     "atlas_pool_write", "atlas_slab_pmax",
     "atlas_contriever_workspace_bytes", "atlas_contriever_embed", "atlas_contriever_embed_rows",
 ]
@@ -104,6 +105,20 @@ def _bind(path):
     L.atlas_pack_candidates.argtypes = [vp, vp, i64, i64, i64, vp, vp]
     L.atlas_merge_packed.restype = i32
     L.atlas_merge_packed.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.atlas_xchg_bytes.restype = sz
+    L.atlas_xchg_bytes.argtypes = [i32, i64]
+    L.atlas_xchg_create.restype = i32
+    L.atlas_xchg_create.argtypes = [i32, i64, ctypes.POINTER(vp), ctypes.c_char_p]
+    L.atlas_xchg_open.restype = i32
+    L.atlas_xchg_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
+    L.atlas_xchg_close.restype = i32
+    L.atlas_xchg_close.argtypes = [vp]
+    L.atlas_xchg_destroy.restype = i32
+    L.atlas_xchg_destroy.argtypes = [vp]
+    L.atlas_xchg_push.restype = i32
+    L.atlas_xchg_push.argtypes = [vp, i64, ctypes.POINTER(vp), i32, i32, i64, ctypes.c_uint32, vp]
+    L.atlas_xchg_merge.restype = i32
+    L.atlas_xchg_merge.argtypes = [vp, i32, i32, i32, i64, ctypes.c_uint32, i32, vp, vp, vp]
     L.atlas_pool_write.restype = i32
     L.atlas_pool_write.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, vp]
     L.atlas_contriever_workspace_bytes.restype = sz

@@ -21,6 +21,7 @@
 #include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 #ifndef ATLAS_TUNING
@@ -293,6 +294,70 @@ merge_packed_kernel(const uint64_t* __restrict__ gathered, int W, int B, int k, 
     for (int i = threadIdx.x; i < n; i += 256) {
         const uint64_t ki = c[i];
         // strict order with index tie-break so that padded zeros (equal keys) stay distinct
+        uint32_t pos = 0;
+        for (int j = 0; j < n; ++j) pos += (c[j] > ki || (c[j] == ki && j < i)) ? 1u : 0u;
+        if (pos < (uint32_t)k) out[(size_t)q * k + pos] = ki;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Peer exchange (atlas_xchg_*): the one-hop alternative to the all-gather of the packed winners. Every rank owns an exchange buffer that
+// its peers map (hipIpc): [2 sets][XCHG_MAXW flag lines of 128 B] | [2 sets][W slots of slot_entries u64]. A search with tag t uses set
+// t & 1: rank r copies its [B][k] packed winners into slot r of EVERY peer's buffer and then stores t into flag r there (system-scope
+// release); the merge of a rank waits -- bounded -- until all W flags of its own buffer carry t (acquire) and ranks the W * k candidates
+// of a query. Two sets are enough: a rank passes the merge of tag t only when every peer has pushed t, i.e. has finished the merge of
+// t - 1 (stream order), so set (t - 1) & 1 = (t + 1) & 1 is free when this rank pushes t + 1.
+// NOT the default (index.py: exchange="rccl"): never run across two devices -- no multi-GPU box was attached; its logic is tested with two
+// processes on one GPU (tests/test_gpu_peer_exchange.py).
+// ------------------------------------------------------------------------------------------
+#define XCHG_MAXW 64
+#define XCHG_HDR (2 * XCHG_MAXW * 128)
+struct XchgPeers { unsigned char* buf[XCHG_MAXW]; };
+
+__global__ void __launch_bounds__(256)
+xchg_push_kernel(const uint64_t* __restrict__ packed, int64_t n, XchgPeers peers, int rank, int W, int64_t slot_entries, uint32_t tag) {
+    unsigned char* dst = peers.buf[blockIdx.x];
+    const int set = (int)(tag & 1u);
+    uint64_t* slot = (uint64_t*)(dst + XCHG_HDR + ((size_t)set * W + rank) * (size_t)slot_entries * 8);
+    for (int64_t i = threadIdx.x; i < n; i += 256) slot[i] = packed[i];
+    __threadfence_system();                                // this thread's stores are out before ...
+    __syncthreads();
+    if (threadIdx.x == 0)                                  // ... the flag says so
+        __hip_atomic_store((unsigned long long*)(dst + ((size_t)set * XCHG_MAXW + rank) * 128), (unsigned long long)tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// one block per query: wait for the W flags of this call, then rank the W * k candidates (as merge_packed_kernel)
+__global__ void __launch_bounds__(256)
+xchg_merge_kernel(const unsigned char* __restrict__ own, int W, int B, int k, int64_t slot_entries, uint32_t tag, unsigned long long wait_ticks,
+                  uint64_t* __restrict__ out, int32_t* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* c = (uint64_t*)smem;
+    __shared__ int s_late;
+    const int q = blockIdx.x, n = W * k, set = (int)(tag & 1u);
+    if (threadIdx.x == 0) s_late = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < W) {
+        const unsigned long long* f = (const unsigned long long*)(own + ((size_t)set * XCHG_MAXW + threadIdx.x) * 128);
+        const unsigned long long end = wall_clock64() + wait_ticks;
+        while ((uint32_t)__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
+            if (wall_clock64() >= end) { s_late = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    if (s_late) {                                          // a peer did not deliver in time: the caller repeats the exchange another way
+        if (threadIdx.x == 0) atomicOr((uint32_t*)status, 1u);
+        return;
+    }
+    __threadfence_system();                                // acquire for every thread's loads of the slots
+    const uint64_t* slots = (const uint64_t*)(own + XCHG_HDR + (size_t)set * W * (size_t)slot_entries * 8);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int w = i / k, j = i - w * k;
+        c[i] = __hip_atomic_load(slots + (size_t)w * slot_entries + (size_t)q * k + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const uint64_t ki = c[i];
         uint32_t pos = 0;
         for (int j = 0; j < n; ++j) pos += (c[j] > ki || (c[j] == ki && j < i)) ? 1u : 0u;
         if (pos < (uint32_t)k) out[(size_t)q * k + pos] = ki;
@@ -842,6 +907,54 @@ int atlas_merge_packed(const uint64_t* gathered, int W, int B, int k, uint64_t* 
     if ((size_t)W * k > 8192) return ATLAS_E_UNSUPPORTED;
     hipLaunchKernelGGL(merge_packed_kernel, dim3(B), dim3(256), (size_t)W * k * 8, (hipStream_t)stream_, gathered, W,
                        B, k, out_packed);
+    return (int)hipGetLastError();
+}
+
+size_t atlas_xchg_bytes(int W, int64_t slot_entries) {
+    if (W <= 0 || W > XCHG_MAXW || slot_entries <= 0) return 0;
+    return (size_t)XCHG_HDR + (size_t)2 * W * (size_t)slot_entries * 8;
+}
+
+int atlas_xchg_create(int W, int64_t slot_entries, void** buf, unsigned char* handle64) {
+    if (!buf || !handle64 || atlas_xchg_bytes(W, slot_entries) == 0) return ATLAS_E_BADARG;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, atlas_xchg_bytes(W, slot_entries));
+    if (e != hipSuccess) return (int)e;
+    e = hipMemset(p, 0, atlas_xchg_bytes(W, slot_entries));
+    hipIpcMemHandle_t h;
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) { (void)hipFree(p); return (int)e; }
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C-ABI carries IPC handles as 64 bytes");
+    memcpy(handle64, &h, 64);
+    *buf = p;
+    return 0;
+}
+
+int atlas_xchg_open(const unsigned char* handle64, void** peer_buf) {
+    if (!handle64 || !peer_buf) return ATLAS_E_BADARG;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, 64);
+    return (int)hipIpcOpenMemHandle(peer_buf, h, hipIpcMemLazyEnablePeerAccess);
+}
+
+int atlas_xchg_close(void* peer_buf) { return peer_buf ? (int)hipIpcCloseMemHandle(peer_buf) : ATLAS_E_BADARG; }
+int atlas_xchg_destroy(void* buf) { return buf ? (int)hipFree(buf) : ATLAS_E_BADARG; }
+
+int atlas_xchg_push(const uint64_t* packed, int64_t n, void* const* peer_bufs, int W, int rank, int64_t slot_entries, uint32_t tag, void* stream_) {
+    if (!packed || !peer_bufs || W <= 0 || W > XCHG_MAXW || rank < 0 || rank >= W || n < 0 || n > slot_entries || tag == 0) return ATLAS_E_BADARG;
+    XchgPeers pp{};
+    for (int i = 0; i < W; ++i) { if (!peer_bufs[i]) return ATLAS_E_BADARG; pp.buf[i] = (unsigned char*)peer_bufs[i]; }
+    hipLaunchKernelGGL(xchg_push_kernel, dim3(W), dim3(256), 0, (hipStream_t)stream_, packed, n, pp, rank, W, slot_entries, tag);
+    return (int)hipGetLastError();
+}
+
+int atlas_xchg_merge(const void* own_buf, int W, int B, int k, int64_t slot_entries, uint32_t tag, int wait_ms, uint64_t* out_packed,
+                     int32_t* status, void* stream_) {
+    if (!own_buf || !out_packed || !status || W <= 0 || W > XCHG_MAXW || B <= 0 || k <= 0 || (int64_t)B * k > slot_entries || tag == 0 || wait_ms <= 0)
+        return ATLAS_E_BADARG;
+    if ((size_t)W * k > 8192) return ATLAS_E_UNSUPPORTED;
+    hipLaunchKernelGGL(xchg_merge_kernel, dim3(B), dim3(256), (size_t)W * k * 8, (hipStream_t)stream_, (const unsigned char*)own_buf, W, B, k,
+                       slot_entries, tag, (unsigned long long)wait_ms * 100000ull, out_packed, status);
     return (int)hipGetLastError();
 }
 

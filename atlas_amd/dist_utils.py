@@ -13,6 +13,7 @@ process group's backend expects (cuda for nccl, cpu for gloo) — callers pass d
 from typing import List, Tuple
 
 import torch
+from typing import Optional
 import torch.distributed as dist
 
 
@@ -78,6 +79,72 @@ def all_gather_packed(packed: torch.Tensor) -> torch.Tensor:
     out = torch.empty((W * B, k), dtype=packed.dtype, device=packed.device)   # concatenation along dim 0
     dist.all_gather_into_tensor(out, packed.contiguous())
     return out.view(W, B, k)
+
+
+class PeerExchange:
+    """The one-hop alternative to `all_gather_packed` + the W*k -> k merge (C-ABI atlas_xchg_*, include/atlas_hip.h): every rank writes its
+    packed winners straight into a slot of every peer's exchange buffer (mapped through hipIpc handles exchanged once, here) and the merge
+    kernel waits for the W tags. EXPERIMENTAL and off by default (`HipDistributedIndex(exchange="peer")`): it has never run across two
+    devices. Setting it up is collective and fails on every rank or on none; `exchange()` returns None when a peer was late."""
+
+    def __init__(self, slot_entries: int, wait_ms: int = 200):
+        import ctypes
+
+        from . import _lib
+
+        self.L, self.W, self.rank = _lib.lib(), dist.get_world_size(), dist.get_rank()
+        self.slot_entries, self.wait_ms, self.tag = int(slot_entries), int(wait_ms), 0
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        own, handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
+        _lib.check(self.L.atlas_xchg_create(self.W, self.slot_entries, ctypes.byref(own), handle), "atlas_xchg_create")
+        self.own = own.value
+        handles = [None] * self.W
+        dist.all_gather_object(handles, bytes(handle.raw))              # once per index: 64 bytes per rank
+        self.peers = (ctypes.c_void_p * self.W)()
+        self._opened = []
+        failed = None
+        for r, h in enumerate(handles):
+            if r == self.rank:
+                self.peers[r] = self.own
+                continue
+            p = ctypes.c_void_p()
+            rc = self.L.atlas_xchg_open(h, ctypes.byref(p))
+            if rc != 0:
+                failed = f"atlas_xchg_open of rank {r}'s buffer: hipError_t {rc}"
+                break
+            self.peers[r] = p.value
+            self._opened.append(p.value)
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        # every buffer is mapped everywhere before the first push -- or nobody uses the exchange (the verdict is the same on every rank)
+        verdicts = [None] * self.W
+        dist.all_gather_object(verdicts, failed)
+        if any(v is not None for v in verdicts):
+            self.close()
+            raise _lib.AtlasHipError("peer exchange unavailable: " + "; ".join(v for v in verdicts if v is not None))
+
+    def exchange(self, packed: torch.Tensor, k: int) -> Optional[torch.Tensor]:
+        """(B, k) int64 packed winners of this rank (B the same on all ranks) -> (B, k) merged, or None if a peer was late"""
+        from . import _lib
+
+        B = int(packed.shape[0])
+        assert packed.is_cuda and packed.dtype == torch.int64 and B * k <= self.slot_entries
+        self.tag += 1
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        packed = packed.contiguous()
+        out = torch.empty((B, k), dtype=torch.int64, device=self.dev)
+        self.status.zero_()
+        _lib.check(self.L.atlas_xchg_push(packed.data_ptr(), B * k, self.peers, self.W, self.rank, self.slot_entries, self.tag, stream), "atlas_xchg_push")
+        _lib.check(self.L.atlas_xchg_merge(self.own, self.W, B, k, self.slot_entries, self.tag, self.wait_ms, out.data_ptr(), self.status.data_ptr(), stream),
+                   "atlas_xchg_merge")
+        return out if int(self.status.item()) == 0 else None
+
+    def close(self) -> None:
+        for p in self._opened:
+            self.L.atlas_xchg_close(p)
+        self._opened = []
+        if self.own:
+            self.L.atlas_xchg_destroy(self.own)
+            self.own = None
 
 
 def _collective_device() -> torch.device:

@@ -27,6 +27,8 @@ import os
 import pickle
 from typing import List, Optional, Tuple
 
+import warnings
+
 import numpy as np
 import torch
 
@@ -75,11 +77,17 @@ def merge_packed_host(gathered: np.ndarray, k: int) -> np.ndarray:
 
 
 class HipDistributedIndex(object):
-    def __init__(self, certify_every: int = 64):
-        """certify_every: every that-many-th search runs the scan that measures every row's norm itself (the C-ABI's default mode,
+    def __init__(self, certify_every: int = 64, exchange: str = "rccl"):
+        """exchange: how the ranks' packed winners meet in a distributed search_knn: "rccl" = one all_gather_into_tensor + the W*k -> k
+        merge (the default); "peer" = every rank writes them into its peers' hipIpc-mapped exchange buffers and the merge waits for the
+        tags (dist_utils.PeerExchange; experimental: back on "rccl" for good if the buffers cannot be mapped; a late peer raises).
+        certify_every: every that-many-th search runs the scan that measures every row's norm itself (the C-ABI's default mode,
         ~5 % slower) instead of trusting the bound taken when the slab last changed -- the net under writers torch's version counter
         cannot see (`.data`, a numpy / DLPack alias, a raw pointer). 1 = every search certifies, 0 = never (trust the counter alone)."""
         self.certify_every = int(certify_every)
+        assert exchange in ("rccl", "peer"), exchange
+        self.exchange = exchange
+        self._peer_xchg = None
         self._since_certified = 0
         self.embeddings = None          # (d, N) fp16 view of the slab, like the reference
         self.doc_map = dict()
@@ -438,8 +446,10 @@ class HipDistributedIndex(object):
         packed = self._last_packed                                                       # straight from the merge kernel, or ...
         if packed is None:
             packed = self._pack(scores_d, rows_d, scores, rows, id_mul, id_add)         # (B, k) int64, device
-        gathered = dist_utils.all_gather_packed(packed)                                  # (W, B, k): ONE collective
-        merged = self._merge(gathered, topk)                                             # (B, k) numpy, W*k -> k per query
+        merged = self._peer_merge(packed, topk) if self.exchange == "peer" and packed.is_cuda else None
+        if merged is None:
+            gathered = dist_utils.all_gather_packed(packed)                              # (W, B, k): ONE collective
+            merged = self._merge(gathered, topk)                                         # (B, k) numpy, W*k -> k per query
         m_scores, m_gid = unpack_candidates_host(merged)
         lo, hi = int(bounds[rank]), int(bounds[rank + 1])
         if self._passage_store is not None:
@@ -463,6 +473,28 @@ class HipDistributedIndex(object):
         docs = [[table[int(g)] for g in m_gid[b] if g >= 0] for b in range(lo, hi)]
         out_scores = [[float(s) for s, g in zip(m_scores[b], m_gid[b]) if g >= 0] for b in range(lo, hi)]
         return docs, out_scores
+
+    def _peer_merge(self, packed: torch.Tensor, k: int) -> Optional[np.ndarray]:
+        """the "peer" exchange of one search; None = use the collective (the set-up failed -- on every rank alike -- and the index is
+        back on "rccl" for good). A peer that is LATE is an error, not a fallback: agreeing on a fallback would cost the very collective
+        the exchange is there to avoid."""
+        B = int(packed.shape[0])
+        if B == 0:
+            return None
+        if self._peer_xchg is None or self._peer_xchg.slot_entries < B * k:
+            if self._peer_xchg is not None:
+                self._peer_xchg.close()
+                self._peer_xchg = None
+            try:
+                self._peer_xchg = dist_utils.PeerExchange(slot_entries=max(B * k, 64 * 256))
+            except _lib.AtlasHipError as e:
+                warnings.warn(f"{e}; using the collective")
+                self.exchange = "rccl"
+                return None
+        out = self._peer_xchg.exchange(packed, k)
+        if out is None:
+            raise _lib.AtlasHipError(f"peer exchange: a rank did not deliver its candidates within {self._peer_xchg.wait_ms} ms")
+        return out.cpu().numpy()
 
     def _pack(self, scores_d, rows_d, scores_h, rows_h, id_mul, id_add) -> torch.Tensor:
         if scores_d.numel() == 0:                       # every rank's batch is empty: nothing to launch

@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--batch-sweep", type=str, default="64,96,128,192,256,512", help="query-batch sizes timed on the 4M-row prefix (a rank of an N-GPU search scores ALL gathered queries; N=1 only; '' = skip)")
     ap.add_argument("--shard-sweep", type=str, default="1000000,4000000,8000000,16000000",
                     help="prefix sizes of the slab timed like the headline: configs[1] and the per-GPU shards of an 8 / 4 / 2-GPU run (N=1 only; '' = skip)")
+    ap.add_argument("--exchange", choices=("rccl", "peer"), default="rccl",
+                    help="N > 1: how the ranks' packed winners meet -- one RCCL all-gather + merge (default), or the peer-mapped exchange buffers "
+                         "(atlas_xchg_*: push kernel + waiting merge kernel, no collective; experimental, never run across two devices)")
     ap.add_argument("--oracle-query", type=int, default=31, help="query of the batch held to the CPU oracle at full size in the cpu_baseline leg (-1 = skip)")
     args = ap.parse_args()
 
@@ -161,6 +164,12 @@ def main():
         a.record(); b.record()
     torch.cuda.synchronize()
 
+    px = None
+    if world > 1 and args.exchange == "peer" and backend == "nccl":
+        from atlas_amd import dist_utils as du
+        px = du.PeerExchange(slot_entries=B * k, wait_ms=1000)
+        px_bad = torch.zeros(1, dtype=torch.int32, device=dev)
+
     def step(ev=None):
         eb = ev[0].cuda_event if ev else None
         ee = ev[1].cuda_event if ev else None
@@ -172,7 +181,13 @@ def main():
                                     out_i.data_ptr(), out_st.data_ptr(), ws.data_ptr(), ws.numel(), stream, eb, ee, _lib.SCAN_TRUST_PMAX,
                                     world, rank, packed.data_ptr() if world > 1 else None)
         assert rc == 0, rc
-        if world > 1:
+        if world > 1 and px is not None:                                # no collective: push into the peers' buffers, merge waits for the tags
+            px.tag += 1
+            rc = L.atlas_xchg_push(packed.data_ptr(), B * k, px.peers, world, rank, px.slot_entries, px.tag, stream)
+            assert rc == 0, rc
+            rc = L.atlas_xchg_merge(px.own, world, B, k, px.slot_entries, px.tag, px.wait_ms, merged.data_ptr(), px_bad.data_ptr(), stream)
+            assert rc == 0, rc
+        elif world > 1:
             if backend == "nccl":
                 dist.all_gather_into_tensor(gathered, packed)          # ONE collective: 8*B*k bytes per rank
             else:                                                       # gloo logic check: stage through the host
@@ -210,6 +225,9 @@ def main():
     assert int(st[_lib.ST_FLAGS]) == 0, f"status flags {int(st[_lib.ST_FLAGS])} in the timed region"
     assert torch.equal(out_s, s0) and torch.equal(out_i, i0), "timed steps disagree with the checked call"
 
+    if world > 1 and px is not None:
+        assert int(px_bad.item()) == 0, "peer exchange: a rank was late in the timed region"
+        dist.all_gather_into_tensor(gathered, packed)                   # (outside the timed region: what the merge must equal)
     if world > 1:
         from atlas_amd.index import merge_packed_host
         want = merge_packed_host(gathered.view(world, B, k).cpu().numpy(), k)
@@ -534,7 +552,7 @@ def main():
                 "workload": f"{args.passages} passages x d=768 fp16 (round-robin over {world} GPU), "
                             f"{B} queries/step, top-{k}, exact MIPS",
                 "passages_total": args.passages, "passages_per_gpu": rows, "queries": B, "topk": k,
-                "parallelism": f"shard{world}" + ("+rccl-allgather" if world > 1 else ""),
+                "parallelism": f"shard{world}" + (("+peer-exchange" if args.exchange == "peer" and backend == "nccl" else "+rccl-allgather") if world > 1 else ""),
             },
             "roofline": {
                 "kernel": "scan_kernel<16,1,8,64> (the twin that takes pmax as certified: ATLAS_SCAN_TRUST_PMAX, what HipDistributedIndex runs "

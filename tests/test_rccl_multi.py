@@ -37,7 +37,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, W, port, N, batches, k, out_dir):
+def _worker(rank, W, port, N, batches, k, out_dir, exchange="rccl"):
     sys.path.insert(0, HERE)
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -54,12 +54,13 @@ def _worker(rank, W, port, N, batches, k, out_dir):
         lo = sum(batches[:rank])
         Q = torch.from_numpy(Qall[lo: lo + batches[rank]]).to(dev)
         mine = np.arange(rank, N, W)                                     # src/index_io.py:41
-        idx = HipDistributedIndex()
+        idx = HipDistributedIndex(exchange=exchange)
         idx.init_embeddings([{"id": str(int(g)), "text": f"p{g}"} for g in mine])
         idx.embeddings[:, :] = torch.from_numpy(P[mine]).to(dev).T
         for _ in range(2):                                               # a collective: every rank calls it the same number of times
             docs, scores = idx.search_knn(Q, k)
         assert all(d["text"] == f"p{d['id']}" for row in docs for d in row)
+        assert idx.exchange == exchange, "the peer exchange fell back to the collective"      # (reported, so that a silent fallback does not pass for coverage)
         ids = np.array([[int(d["id"]) for d in row] for row in docs], dtype=np.int64).reshape(len(docs), k)
         # device merge == host merge on what was actually gathered
         allq = torch.from_numpy(Qall).to(dev)
@@ -75,14 +76,16 @@ def _worker(rank, W, port, N, batches, k, out_dir):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["rccl", "peer"])
 @pytest.mark.parametrize("W,batches", [(2, (3, 5)), (2, (4, 0)), (4, (2, 0, 5, 1)), (8, (1, 2, 0, 3, 1, 0, 2, 4))])
-def test_search_knn_over_rccl_equals_union(W, batches, tmp_path, oracle_mod):
+def test_search_knn_over_rccl_equals_union(W, batches, exchange, tmp_path, oracle_mod):
+    """both exchange modes: the all-gather of the packed winners, and the peer-mapped exchange buffers (index.py: exchange="peer")"""
     if _n_gpus() < W:
         pytest.skip(f"needs {W} GPUs, this box has {_n_gpus()}")
     import torch.multiprocessing as mp
 
     N, k = 50_003, 12                                                    # not a multiple of W: shards differ by one row
-    mp.spawn(_worker, args=(W, _free_port(), N, batches, k, str(tmp_path)), nprocs=W, join=True)
+    mp.spawn(_worker, args=(W, _free_port(), N, batches, k, str(tmp_path), exchange), nprocs=W, join=True)
     P = synth.passages_f16(N, 768, 61)
     Q = synth.queries_f32(sum(batches), 768, 62)
     s, i = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, k)
