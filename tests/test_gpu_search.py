@@ -74,6 +74,28 @@ def test_batches_above_64_queries_bit_exact_vs_oracle(N, B, k, ps, gpu_index_cls
     parity.assert_identical(s2, i2, es2, ei2, f"duplicated halves, N={N} B={B} k={k}")
 
 
+def test_wide_passes_of_the_certifying_twin(gpu_index_cls, oracle_mod):
+    """batches above 64 queries through the scan that measures every row norm itself (certify_every = 1: the C-ABI's default mode, the
+    96-query instantiation of the certifying twin), incl. a row that violates the hint: one certifying rerun, same canonical result"""
+    N, B, k = 150000, 160, 40
+    P = synth.passages_f16(N, 768, 311)
+    Q = synth.queries_f32(B, 768, 312)
+    idx = gpu_index_cls(certify_every=1)
+    idx.init_embeddings([{"id": str(i)} for i in range(N)], 768)
+    idx.embeddings[:, :] = torch.from_numpy(P).cuda().T
+    es, ei = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, k)
+    for _ in range(2):
+        s, i = _search(idx, Q, k)
+        parity.assert_identical(s, i, es, ei, "certifying, wide passes")
+        assert idx.last_search_stats["pmax_trusted"] is False and idx.last_search_stats["fallback_queries"] == 0
+    P2 = P.copy()
+    P2[77777] = (P2[77777].astype(np.float32) * 9.0).astype(np.float16)
+    idx._slab[77777] = torch.from_numpy(P2[77777]).cuda()            # (a write torch sees: the bound is re-measured before the scan)
+    es2, ei2 = oracle_mod.search(oracle_mod.f32_to_f16(Q), P2, k)
+    s2, i2 = _search(idx, Q, k)
+    parity.assert_identical(s2, i2, es2, ei2, "certifying, wide passes, a 9 x row")
+
+
 @pytest.mark.parametrize("case", ["a10k", "b3k", "c_dups", "d_k128"])
 def test_scan_vs_reference_golden(case, gpu_index_cls, oracle_mod):
     """HIP path vs the outputs of the reference's own DistributedIndex (tie-/1-ulp-aware, see parity.py)."""
