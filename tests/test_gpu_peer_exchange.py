@@ -2,6 +2,7 @@
 buffers through hipIpc handles and exchange packed winners through them -- the logic of the one-hop alternative to the all-gather of
 src/index.py:134-151 (across two devices it has never run: no multi-GPU box). Every wait is bounded: a late peer is a status bit, not a hang."""
 import os
+import socket
 import subprocess
 import sys
 import textwrap
@@ -9,6 +10,14 @@ import textwrap
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port() -> str:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return str(port)
 
 WORKER = textwrap.dedent('''
     import os, sys
@@ -51,7 +60,7 @@ WORKER = textwrap.dedent('''
 def test_two_processes_exchange_packed_winners_through_mapped_buffers(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, ATLAS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, ATLAS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(2)]
     outs = []
@@ -102,7 +111,7 @@ def test_search_knn_with_the_peer_exchange_equals_the_union(tmp_path):
     scores of every rank equal the canonical search over the union of the shards"""
     script = tmp_path / "knn_worker.py"
     script.write_text(KNN_WORKER)
-    env = dict(os.environ, ATLAS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29578", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, ATLAS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(2)]
     outs = []
