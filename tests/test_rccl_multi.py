@@ -76,7 +76,8 @@ def _worker(rank, W, port, N, batches, k, out_dir, exchange="rccl"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["rccl", "peer"])
+@pytest.mark.parametrize("exchange", ["rccl", pytest.param("peer", marks=pytest.mark.xfail(
+    strict=False, reason="experimental exchange: has never run across two devices (its logic is tested with two processes on one GPU)"))])
 @pytest.mark.parametrize("W,batches", [(2, (3, 5)), (2, (4, 0)), (4, (2, 0, 5, 1)), (8, (1, 2, 0, 3, 1, 0, 2, 4))])
 def test_search_knn_over_rccl_equals_union(W, batches, exchange, tmp_path, oracle_mod):
     """both exchange modes: the all-gather of the packed winners, and the peer-mapped exchange buffers (index.py: exchange="peer")"""
