@@ -95,8 +95,18 @@ prep_queries_kernel(const void* __restrict__ q, int q_dtype, int q0, int nq, int
 // ------------------------------------------------------------------------------------------
 template <int NT>
 __global__ void __launch_bounds__(NT)
-merge_rescore_kernel(const MergeParams p) {
+merge_rescore_kernel(const MergeParams pk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    MergeParams p = pk;
+    if (blockIdx.y != 0) {                                 // the second chunk of a paired pass
+        auto st = [&](auto*& ptr) { ptr = (std::remove_reference_t<decltype(ptr)>)((unsigned char*)ptr + pk.pair_state); };
+        auto bk = [&](auto*& ptr) { ptr = (std::remove_reference_t<decltype(ptr)>)((unsigned char*)ptr + pk.pair_bulk); };
+        st(p.epoch); st(p.ticket); st(p.qflag);
+        bk(p.lists); bk(p.list_cnt); bk(p.wg_stat);
+        p.q0 = pk.q0 + pk.nq1;
+        p.qbase = pk.qbase + pk.nq1;
+    }
+    if ((int)blockIdx.x >= (blockIdx.y ? pk.nq2 : pk.nq1)) return;
     merge_rescore_body<NT>(p, (int)blockIdx.x, smem);
 }
 
@@ -478,6 +488,8 @@ const ScanVariant kTrusted = {16, 1, 8, scan_kernel<16, 1, 8, 64>, "scan_kernel<
 const ScanVariant kWide = {16, 1, 8, scan_kernel<16, 1, 8, 0, 6>, "scan_kernel<16,1,8,96q>"};
 const ScanVariant kWideTrusted = {16, 1, 8, scan_kernel<16, 1, 8, 64, 6>, "scan_kernel<16,1,8,96q> (trusted pmax)"};
 constexpr int QWIDE = 96;
+constexpr size_t PAIR_STATE = 1u << 20;
+static_assert(ATLAS_WS_STATE_BYTES >= 2 * PAIR_STATE, "both chunks' state inside the zero-filled head");
 
 constexpr int MERGE_NT = 1024;
 constexpr int SAMPLE_MAX = 16384;
@@ -490,6 +502,8 @@ int g_scan_coop = 1;                         // atlas_tune_set_scan_coop: 0 = sa
 bool scan_coop_enabled() { return g_scan_coop != 0; }
 int g_scan_wide = 1;                         // atlas_tune_set_scan_wide: 0 = batches above 64 queries in 64-query passes only (A/B)
 bool scan_wide_enabled() { return g_scan_wide != 0; }
+int g_scan_pair = 1;                         // atlas_tune_set_scan_pair: 0 = no paired passes (A/B)
+bool scan_pair_enabled() { return g_scan_pair != 0; }
 int g_scan_fused = 0;                        // atlas_tune_set_scan_fused: 1 = the merge inside the scan (experiment, not adopted)
 bool scan_fused_enabled() { return g_scan_fused != 0; }
 #else
@@ -498,6 +512,7 @@ constexpr unsigned long long* g_scan_dbg = nullptr;
 constexpr int scan_variant_index() { return 0; }
 constexpr bool scan_coop_enabled() { return true; }
 constexpr bool scan_wide_enabled() { return true; }
+constexpr bool scan_pair_enabled() { return true; }
 #endif
 // run-time tile pool at the end of the slab: share of a workgroup's tiles that is NOT pre-assigned, and its cap
 #if ATLAS_TUNING
@@ -520,6 +535,7 @@ struct ScanPlan {
     int S; int64_t sample_stride;     // sample pre-pass: S rows (0 = none), tile j starts at j*sample_stride
     int key_cap;
     int total_cap;
+    size_t bulk_begin, bulk_size;
     size_t off_qflag, off_epoch, off_fuse, off_gran, off_gmax, off_q16, off_sample, off_list_cnt, off_wg_stat, off_lists, total;
     size_t scan_lds, merge_lds;
 };
@@ -594,13 +610,18 @@ ScanPlan make_plan(int64_t N, int d, int k, int cus, const ScanVariant& v, int n
     pl.off_fuse = o;   o += 512;                         // fused merge: arrivals, tags, per-query states (scan_kernel.h)
     pl.off_gran = o;   o += 1024;
     pl.off_gmax = o;   o += (size_t)QWIDE * 1024 * 8;
+    // everything above is state (< 1 MiB); the second chunk of a PAIRED pass (ScanParams::nq2) keeps its own copy PAIR_STATE bytes on,
+    // inside the zero-filled head too (ATLAS_WS_STATE_BYTES = 2 MiB). The bulk arrays follow from 2 MiB on, the second chunk's behind
+    // the first's (bulk_size on)
+    pl.bulk_begin = o = PAIR_STATE * 2;
     pl.off_q16 = o;    o += (size_t)QCHUNK * D_FAST * 2;
     pl.off_sample = o; o += (size_t)QCHUNK * SAMPLE_MAX * 4;
     pl.off_list_cnt = o; o += align_up((size_t)pl.G * nqp * 4, 256);     // every scan workgroup overwrites its words: no reset
     pl.off_wg_stat = o;  o += align_up((size_t)pl.G * 2 * 4, 256);
     pl.total_cap = 131072;                // most candidates of one query the merge takes on (beyond: exact path)
     pl.off_lists = o;  o += (size_t)pl.G * nqp * pl.cap * 8;
-    pl.total = align_up(o, 256);
+    pl.bulk_size = align_up(o - pl.bulk_begin, 256);
+    pl.total = pl.bulk_begin + pl.bulk_size;
     pl.scan_lds = (size_t)ScanSmem::buf_off + (size_t)pl.buf_cap * 8 + (ATLAS_TUNING ? 1024 : 0);     // tuning build: + per-tile stamps (its buffer is 128 entries shorter)
     pl.buf_cap_wide = (int)((160 * 1024 - (size_t)ScanSmemT<QWIDE>::buf_off) / 8) - (ATLAS_TUNING ? 128 : 0);
     pl.flush_at_wide = pl.buf_cap_wide * 3 / 4;
@@ -670,6 +691,7 @@ void atlas_tune_set_scan_variant(int v) { g_scan_variant = v; }
 void atlas_tune_set_scan_coop(int c) { g_scan_coop = c; }
 void atlas_tune_set_scan_fused(int f) { g_scan_fused = f; }
 void atlas_tune_set_scan_wide(int f) { g_scan_wide = f; }
+void atlas_tune_set_scan_pair(int f) { g_scan_pair = f; }
 void atlas_tune_set_scan_pool(int permille, int max_per_wg) { g_pool_permille = permille; g_pool_max = max_per_wg; }
 // the launch plan of a scan over N rows on a device with `cus` CUs, for host-side checks of its invariants (no GPU needed):
 // out = {G, rows_per_wg, pool_begin, pool_rows, pool_tiles, tile, pool_tile, supported (the range checks of atlas_scan_topk)}
@@ -706,6 +728,11 @@ size_t atlas_scan_topk_workspace_bytes(int64_t N, int B, int d, int k) {
     for (int v = 0; v < kNumVariants; ++v) {
         const size_t t = make_plan(N, d, k, device_cus(), kVariants[v], B > QCHUNK ? QWIDE : QCHUNK).total;
         mx = t > mx ? t : mx;
+        if (B > QCHUNK) {              // paired passes: two half-chip plans side by side
+            const ScanPlan pp = make_plan(N, d, k, device_cus() / 2, kVariants[v], QWIDE);
+            const size_t t2 = pp.bulk_begin + 2 * pp.bulk_size;
+            mx = t2 > mx ? t2 : mx;
+        }
     }
     return mx;
 }
@@ -753,18 +780,44 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
     if (ws_bytes < pl.total) return ATLAS_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     unsigned char* w = (unsigned char*)ws;
-    std::vector<int> chunk;                     // queries of every pass, in order
-    if (!wide_ok) {
-        for (int r = B; r > 0; r -= QCHUNK) chunk.push_back(r < QCHUNK ? r : QCHUNK);
+    // Passes of the batch, in order. Items: one 64-query pass (cost 1), one 96-query pass (1.11), a PAIR of 64-query passes run concurrently
+    // on half the chip each (1.62 for up to 128 queries: the second reader of a slab row hits the Infinity Cache), a pair of 96-query
+    // passes (1.89 for up to 192); f(n) = min over the items of cost + f(n - size): 128 -> a pair of 64, 192 -> a pair of 96,
+    // 512 -> 2 pairs of 96 + a pair of 64.
+    struct Pass { int nq, nq2; bool wide; };
+    std::vector<Pass> passes;
+    ScanPlan pp = pl;                           // the half-chip plan of paired passes
+    const int half = device_cus() / 2;
+    bool pair_ok = B > QCHUNK && scan_variant_index() == 0 && scan_pair_enabled() && scan_coop_enabled() && half % 8 == 0 && half >= QCHUNK && half <= 256;
+    if (pair_ok) {
+        pp = make_plan(N, d, k, half, var, wide_ok ? QWIDE : QCHUNK);
+        pair_ok = pp.S > 0 && pp.G == half && scan_plan_supported(pp, wide_ok ? 25 : 26) && ws_bytes >= pp.bulk_begin + 2 * pp.bulk_size;
+    }
+    const bool pair_wide_ok = pair_ok && wide_ok && half >= QWIDE;
+    if (B <= QCHUNK || (!wide_ok && !pair_ok)) {
+        for (int r = B; r > 0; r -= QCHUNK) passes.push_back({r < QCHUNK ? r : QCHUNK, 0, false});
     } else {
+        const float cost[4] = {1.0f, 1.11f, 1.62f, 1.89f};                   // (measured at 4M and 32M rows: profiles/r03/batch_paired_pass_ab.txt)
+        const int size[4] = {QCHUNK, QWIDE, 2 * QCHUNK, 2 * QWIDE};
+        const bool ok[4] = {true, wide_ok, pair_ok, pair_wide_ok};
         std::vector<float> f((size_t)B + 1, 0.f);
         std::vector<unsigned char> take((size_t)B + 1, 0);
         for (int n = 1; n <= B; ++n) {
-            const float c64 = 1.0f + f[n > QCHUNK ? n - QCHUNK : 0], c96 = 1.10f + f[n > QWIDE ? n - QWIDE : 0];
-            take[n] = c96 < c64 ? 1 : 0;
-            f[n] = take[n] ? c96 : c64;
+            float best = 1e30f;
+            for (int it = 0; it < 4; ++it) {
+                if (!ok[it]) continue;
+                if (it >= 2 && n <= size[it - 2]) continue;                  // a pair needs more queries than one pass of its kind takes
+                const float c = cost[it] + f[n > size[it] ? n - size[it] : 0];
+                if (c < best) { best = c; take[n] = (unsigned char)it; }
+            }
+            f[n] = best;
         }
-        for (int r = B; r > 0;) { const int c = take[r] ? QWIDE : QCHUNK; chunk.push_back(r < c ? r : c); r -= c; }
+        for (int r = B; r > 0;) {
+            const int it = take[r], m = r < size[it] ? r : size[it];
+            if (it < 2) passes.push_back({m, 0, it == 1});
+            else passes.push_back({(m + 1) / 2, m / 2, it == 3});
+            r -= m;
+        }
     }
     const ScanVariant& wide = trusted ? kWideTrusted : kWide;
 
@@ -775,10 +828,12 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
     allow_lds(sample_scores_kernel);
 
     hipError_t e = hipSuccess;
+    const ScanPlan single = pl;
     int q0 = 0;
-    for (size_t ci = 0; ci < chunk.size(); q0 += chunk[ci], ++ci) {
-        const int nq = chunk[ci];
-        const bool is_wide = nq > QCHUNK;
+    for (size_t ci = 0; ci < passes.size(); q0 += passes[ci].nq + passes[ci].nq2, ++ci) {
+        const int nq = passes[ci].nq, nq2 = passes[ci].nq2;
+        const bool is_wide = passes[ci].wide, paired = nq2 > 0;
+        const ScanPlan& pl = paired ? pp : single;                          // (shadows the whole-chip plan inside the loop)
         // initial thresholds: the scan derives them from the tile maxima of an evenly spread sample; small shards
         // start at -inf. Whoever runs first clears the per-call state (per-query fallback flags, status header).
         // coop scan: the workgroups' first tiles are the sample (one launch less); needs one granule per (query, workgroup) lane slot
@@ -813,6 +868,7 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
         sp.rows_per_wg = pl.rows_per_wg; sp.nq = nq; sp.k = k; sp.cap = pl.cap; sp.keep_max = pl.keep_max;
         sp.buf_cap = is_wide ? pl.buf_cap_wide : pl.buf_cap; sp.flush_at = is_wide ? pl.flush_at_wide : pl.flush_at;
         sp.pmax2_hint = pmax_hint * pmax_hint;
+        sp.nq2 = nq2; sp.pair_state = PAIR_STATE; sp.pair_bulk = pl.bulk_size;
         sp.dbg = g_scan_dbg;
         if (q0 == 0 && ev_scan_begin) (void)hipEventRecord((hipEvent_t)ev_scan_begin, stream);
         MergeParams mp{};
@@ -824,17 +880,19 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
         mp.dbg = g_merge_dbg;
         mp.out_score = (uint16_t*)out_score_f16; mp.out_idx = out_idx; mp.out_status = out_status;
         mp.out_packed = out_packed; mp.id_mul = id_mul; mp.id_add = id_add;
+        mp.nq1 = nq; mp.nq2 = nq2; mp.pair_state = PAIR_STATE; mp.pair_bulk = pl.bulk_size;
 #if ATLAS_TUNING
         // experiment (scan_kernel.h, ScanParams::fused): the merge inside the scan's last nq workgroups
-        const bool fused = !is_wide && coop && var.nw * 64 == MERGE_NT && pl.G >= nq && pl.merge_lds <= pl.scan_lds && scan_fused_enabled();
+        const bool fused = !paired && !is_wide && coop && var.nw * 64 == MERGE_NT && pl.G >= nq && pl.merge_lds <= pl.scan_lds && scan_fused_enabled();
         sp.fused = fused ? 1 : 0; sp.fuse = (uint32_t*)(w + pl.off_fuse); sp.mp = mp;
 #else
         constexpr bool fused = false;
 #endif
-        if (is_wide) hipLaunchKernelGGL(wide.kern, dim3(pl.G), dim3(wide.nw * 64), pl.scan_lds_wide, stream, sp);
-        else hipLaunchKernelGGL(var.kern, dim3(pl.G), dim3(var.nw * 64), pl.scan_lds, stream, sp);
+        const dim3 sgrid(pl.G, paired ? 2 : 1);
+        if (is_wide) hipLaunchKernelGGL(wide.kern, sgrid, dim3(wide.nw * 64), pl.scan_lds_wide, stream, sp);
+        else hipLaunchKernelGGL(var.kern, sgrid, dim3(var.nw * 64), pl.scan_lds, stream, sp);
         if (q0 == 0 && ev_scan_end) (void)hipEventRecord((hipEvent_t)ev_scan_end, stream);
-        if (!fused) hipLaunchKernelGGL(merge, dim3(nq), dim3(MERGE_NT), pl.merge_lds, stream, mp);
+        if (!fused) hipLaunchKernelGGL(merge, dim3(nq, paired ? 2 : 1), dim3(MERGE_NT), pl.merge_lds, stream, mp);
     }
     return (int)hipGetLastError();
 }

@@ -48,6 +48,10 @@ struct MergeParams {
     unsigned long long* dbg;     // optional per-phase cycle stamps of block 0 (tuning only; null in production)
     uint16_t* out_score; int64_t* out_idx; int32_t* out_status;
     uint64_t* out_packed; int64_t id_mul, id_add;   // optional: the winners also leave as cross-shard packed candidates (atlas_scan_topk_pack)
+    // paired passes (ScanParams: grid.y == 2): blocks with blockIdx.y == 1 merge the nq2 queries of the second chunk, whose scan state /
+    // lists live pair_state / pair_bulk bytes behind the first chunk's
+    int nq1, nq2;
+    size_t pair_state, pair_bulk;
 };
 
 // Canonical exact score (common.h exact_dot_f16) computed by ONE WAVE: lane j is chain j and adds the

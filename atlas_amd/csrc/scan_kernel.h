@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "common.h"
 #include "../../include/atlas_hip.h"
 
@@ -242,6 +243,13 @@ struct ScanParams {
     int flush_at;             // buffer fill at which a flush into the global lists is requested
     float pmax2_hint;
     unsigned long long* dbg;  // tuning build only (atlas_tune_set_scan_stamps): 8 wall-clock stamps (100 MHz, common to all XCDs) per workgroup; null in production
+    // PAIRED PASSES (grid.y == 2, round 3): two query chunks of a batch are scanned CONCURRENTLY, each by half of the chip (grid.x = CUs / 2
+    // workgroups per chunk, the same row ranges in both halves). The second reader of a slab row is served by the Infinity Cache / L2
+    // instead of HBM: the two half-chip scans deliver ~7.1 TB/s to the CUs for ~3.5 TB/s of HBM reads, x 1.12-1.17 against the two passes
+    // one after the other (profiles/r03/concurrent_chunks_experiment.txt). Chunk 1 = queries [q0 + nq, q0 + nq + nq2); its per-call state
+    // lives pair_state bytes behind chunk 0's, its lists pair_bulk bytes behind (same layout; atlas_hip.hip: make_plan).
+    int nq2;
+    size_t pair_state, pair_bulk;
 #if ATLAS_TUNING
     // EXPERIMENT, tuning build only (atlas_tune_set_scan_fused; tools/fused_timeline.py): the merge inside the scan -- the LAST nq workgroups
     // to finish their ranges stay and run the merge of one query each once every workgroup has handed over. Measured and NOT adopted:
@@ -277,7 +285,16 @@ typedef ScanSmemT<64> ScanSmem;
 //       buffer (1 480 entries instead of 7 680: a flush per ~1 100 candidates), and candidate entries carry a 7-bit query + 25-bit row)
 template <int NW, int PF, int RING, int AUX = 0, int NQF = 4>
 __global__ void __launch_bounds__(NW * 64)
-scan_kernel(const ScanParams p) {
+scan_kernel(const ScanParams pk) {
+    ScanParams p = pk;
+    if (blockIdx.y != 0) {                                 // the second chunk of a paired pass (uniform)
+        auto st = [&](auto*& ptr) { ptr = (std::remove_reference_t<decltype(ptr)>)((unsigned char*)ptr + pk.pair_state); };
+        auto bk = [&](auto*& ptr) { ptr = (std::remove_reference_t<decltype(ptr)>)((unsigned char*)ptr + pk.pair_bulk); };
+        st(p.theta_gran); st(p.gran_max); st(p.epoch); st(p.qflag); st(p.ticket);
+        bk(p.lists); bk(p.list_cnt); bk(p.wg_stat);
+        p.q0 = pk.q0 + pk.nq;
+        p.nq = pk.nq2;
+    }
     constexpr int NQ = 16 * NQF;                           // queries per pass
     constexpr int QSHIFT = NQ > 64 ? 25 : 26;              // candidate entry: (query << QSHIFT) | virtual row
     constexpr uint32_t ROWMASK = (1u << QSHIFT) - 1u;

@@ -351,16 +351,25 @@ def main():
             del sub
 
     # ---- larger query batches on the 4M-row prefix (the shard of an 8-GPU run): a rank of a distributed search scores ALL gathered
-    # queries (src/index.py:127-131), B_total = W x b_r; the scan takes them in slab passes of 64 or 96 queries (atlas_hip.hip: the
-    # chunk plan; a 96-query pass costs ~1.10 of a 64-query pass)
+    # queries (src/index.py:127-131), B_total = W x b_r; the scan takes them in slab passes of 64 or 96 queries, single or as PAIRS that
+    # scan concurrently on half the chip each and share their slab reads through the cache (atlas_hip.hip: the pass plan; [a, b] = a pair)
     def pass_plan(n):
+        cost, size = (1.0, 1.11, 1.62, 1.89), (64, 96, 128, 192)            # one 64 / 96-query pass, a PAIR of them on half the chip each
         f, take = [0.0] * (n + 1), [0] * (n + 1)
         for m in range(1, n + 1):
-            c64, c96 = 1.0 + f[max(m - 64, 0)], 1.10 + f[max(m - 96, 0)]
-            take[m], f[m] = (96, c96) if c96 < c64 else (64, c64)
+            best = None
+            for it in range(4):
+                if it >= 2 and m <= size[it - 2]:
+                    continue
+                c = cost[it] + f[max(m - size[it], 0)]
+                if best is None or c < best:
+                    best, take[m] = c, it
+            f[m] = best
         out = []
         while n > 0:
-            out.append(min(n, take[n])); n -= take[n]
+            it = take[n]; m = min(n, size[it])
+            out.append(m if it < 2 else [(m + 1) // 2, m // 2])
+            n -= m
         return out
 
     batch_sweep = None
@@ -396,7 +405,7 @@ def main():
             es_b, ei_b = subb._exact_topk(qb[sel_b], k)
             assert torch.equal(o_s[sel_b], es_b) and torch.equal(o_i[sel_b], ei_b), f"B={Bb}: scan disagrees with the exact path"
             plan_b = pass_plan(Bb) if Bb > 64 else [Bb]
-            passes = len(plan_b)
+            passes = len(plan_b)                                         # launches; a paired launch reads the slab from HBM about once
             batch_sweep[str(Bb)] = {"ms_per_step": dtb * 1e3, "queries_per_s": Bb / dtb, "slab_passes": passes, "queries_per_pass": plan_b,
                                     "bytes_read_per_query": passes * n_b * D * 2 / Bb, "step_frac_of_hbm_peak": passes * n_b * D * 2 / dtb / 1e9 / HBM_PEAK_GBS,
                                     "parity_checked": {"rows": n_b, "queries_exact": int(sel_b.numel())}}

@@ -39,7 +39,7 @@ extern "C" {
 
 #define ATLAS_ABI_VERSION 8
 
-#define ATLAS_WS_STATE_BYTES (1u << 20)   /* head of a scan workspace that must be zero before the workspace's first use */
+#define ATLAS_WS_STATE_BYTES (2u << 20)   /* head of a scan workspace that must be zero before the workspace's first use */
 
 /* negative return codes */
 #define ATLAS_E_BADARG     (-1)  /* null pointer, B<=0, k<=0, d unsupported ...        */

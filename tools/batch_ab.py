@@ -1,4 +1,4 @@
-"""Batches above 64 queries: 64-query slab passes only (wide 0) vs the mix of 64- and 96-query passes (wide 1), same process (tuning build).
+"""Batches above 64 queries: 64-query slab passes only vs + 96-query passes vs + PAIRED passes (two chunks concurrently on half the chip each: the product), same process (tuning build).
     python tools/batch_ab.py [rows, default 4000000 and 32000000]"""
 import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
 from _tune import L  # noqa: E402
@@ -22,10 +22,10 @@ for N in sizes:
         out_st = torch.empty(_lib.STATUS_HEADER + B, dtype=torch.int32, device="cuda")
         ws = torch.zeros(L.atlas_scan_topk_workspace_bytes(N, B, D, k), dtype=torch.uint8, device="cuda")
         reps = max(3, int((200 if N <= 4_000_000 else 24) * 64 / B))
-        res, outs = {0: [], 1: []}, {}
+        res, outs = {0: [], 1: [], 2: []}, {}
         for rnd in range(3):
-            for wide in (0, 1):
-                L.atlas_tune_set_scan_wide(wide)
+            for wide in (0, 1, 2):
+                L.atlas_tune_set_scan_wide(1 if wide else 0); L.atlas_tune_set_scan_pair(1 if wide == 2 else 0)
                 def call():
                     rc = L.atlas_scan_topk_flags(q.data_ptr(), _lib.DT_F16, slab.data_ptr(), N, B, D, k, 1.002, out_s.data_ptr(), out_i.data_ptr(), out_st.data_ptr(),
                                                  ws.data_ptr(), ws.numel(), stream, None, None, _lib.SCAN_TRUST_PMAX)
@@ -39,7 +39,7 @@ for N in sizes:
                 cur = (out_s.clone(), out_i.clone())
                 if wide in outs: assert torch.equal(cur[0], outs[wide][0]) and torch.equal(cur[1], outs[wide][1])
                 outs[wide] = cur
-        same = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-        a, b = float(np.median(res[0])), float(np.median(res[1]))
-        print(f"{N:>9d} rows, {B:3d} queries: 64-query passes {a:8.3f} ms = {B / a * 1e3:8.0f} queries/s;  with 96-query passes {b:8.3f} ms = {B / b * 1e3:8.0f} queries/s  (x {a / b:5.3f})  identical results: {same}", flush=True)
-L.atlas_tune_set_scan_wide(1)
+        same = all(torch.equal(outs[0][0], outs[m][0]) and torch.equal(outs[0][1], outs[m][1]) for m in (1, 2))
+        a, b, c = (float(np.median(res[m])) for m in (0, 1, 2))
+        print(f"{N:>9d} rows, {B:3d} queries: 64-query passes {a:8.3f} ms = {B / a * 1e3:8.0f} queries/s;  + 96-query passes {b:8.3f} ms = {B / b * 1e3:8.0f} (x {a / b:5.3f});  + paired passes {c:8.3f} ms = {B / c * 1e3:8.0f} queries/s (x {a / c:5.3f})  identical results: {same}", flush=True)
+L.atlas_tune_set_scan_wide(1); L.atlas_tune_set_scan_pair(1)
