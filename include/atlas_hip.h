@@ -101,9 +101,11 @@ const char* atlas_build_info(void);          /* "gfx950 <compile date> ..." */
  * Fast path requires d == 768 (EMBEDDINGS_DIM, src/retrievers.py:13) and k <= 256;
  * otherwise returns ATLAS_E_UNSUPPORTED (callers then use atlas_exact_topk).
  * Any B >= 1 is accepted: up to 64 queries are one slab pass; a larger batch is a sequence of 64- and 96-query passes chosen by cost
- * (a 96-query pass -- 147 KiB query image, 6 MFMAs per 16-byte slab load -- takes ~1.10 of a 64-query pass: 96 -> one pass, 128 -> 64 + 64,
- * 192 -> 96 + 96, 512 -> 2 x 64 + 4 x 96; shards of fewer than 96 workgroups keep 64-query passes). The workspace size depends on
- * B > 64: a workspace sized for a larger batch serves every smaller one; the state words at its head do not move with B.
+ * (a 96-query pass -- 147 KiB query image, 6 MFMAs per 16-byte slab load -- takes ~1.11 of a 64-query pass), single or PAIRED: two passes
+ * scanning concurrently on half the chip each, the second reader of a slab row served by the cache (a pair of 64-query passes costs 1.62,
+ * a pair of 96-query passes 1.89 of one 64-query pass): 96 -> one pass, 128 -> a pair of 64, 192 -> a pair of 96, 512 -> two pairs of 96 +
+ * a pair of 64; small shards keep 64-query passes. The workspace size depends on B > 64: a workspace sized for a larger batch serves
+ * every smaller one; the state words at its head do not move with B.
  *
  * One 64-query pass is two launches: the scan (which converts the queries itself, takes its initial pruning thresholds
  * from its own first tiles -- the workgroups exchange 8-byte granules inside the kernel; every wait is bounded, a value
