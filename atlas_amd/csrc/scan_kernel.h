@@ -245,7 +245,7 @@ struct ScanParams {
     unsigned long long* dbg;  // tuning build only (atlas_tune_set_scan_stamps): 8 wall-clock stamps (100 MHz, common to all XCDs) per workgroup; null in production
     // PAIRED PASSES (grid.y == 2, round 3): two query chunks of a batch are scanned CONCURRENTLY, each by half of the chip (grid.x = CUs / 2
     // workgroups per chunk, the same row ranges in both halves). The second reader of a slab row is served by the Infinity Cache / L2
-    // instead of HBM: the two half-chip scans deliver ~7.1 TB/s to the CUs for ~3.5 TB/s of HBM reads, x 1.12-1.17 against the two passes
+    // instead of HBM: the two half-chip scans deliver ~7.6 TB/s to the CUs for one slab of HBM reads, x 1.17-1.24 against the two passes
     // one after the other (profiles/r03/concurrent_chunks_experiment.txt). Chunk 1 = queries [q0 + nq, q0 + nq + nq2); its per-call state
     // lives pair_state bytes behind chunk 0's, its lists pair_bulk bytes behind (same layout; atlas_hip.hip: make_plan).
     int nq2;
