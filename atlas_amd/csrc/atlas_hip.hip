@@ -30,6 +30,7 @@
 
 #include "common.h"
 #include "scan_kernel.h"
+#include "gscan_kernel.h"
 #include "../../include/atlas_hip.h"
 
 using namespace atlas;
@@ -506,6 +507,8 @@ int g_scan_pair = 1;                         // atlas_tune_set_scan_pair: 0 = no
 bool scan_pair_enabled() { return g_scan_pair != 0; }
 int g_scan_fused = 0;                        // atlas_tune_set_scan_fused: 1 = the merge inside the scan (experiment, not adopted)
 bool scan_fused_enabled() { return g_scan_fused != 0; }
+int g_scan_gemm = 1;                         // atlas_tune_set_scan_gemm: 0 = no GEMM-shaped passes for big batches (A/B)
+bool scan_gemm_enabled() { return g_scan_gemm != 0; }
 #else
 constexpr unsigned long long* g_merge_dbg = nullptr;
 constexpr unsigned long long* g_scan_dbg = nullptr;
@@ -513,6 +516,7 @@ constexpr int scan_variant_index() { return 0; }
 constexpr bool scan_coop_enabled() { return true; }
 constexpr bool scan_wide_enabled() { return true; }
 constexpr bool scan_pair_enabled() { return true; }
+constexpr bool scan_gemm_enabled() { return true; }
 #endif
 // run-time tile pool at the end of the slab: share of a workgroup's tiles that is NOT pre-assigned, and its cap
 #if ATLAS_TUNING
@@ -654,6 +658,48 @@ ExactPlan make_exact_plan(int64_t N, int d, int k, int B) {
     return e;
 }
 
+// The GEMM-shaped pass of big batches (gscan_kernel.h). One pass takes up to GS_MAXQ queries as ncol = 1, 2 or 4 column tiles of 256.
+constexpr int GS_MAXQ = 1024;
+constexpr size_t GS_OFF_QFLAG = 800u << 10;     // its per-query fallback flags: state words (zero between calls) behind the coop scan's granules
+static_assert(GS_OFF_QFLAG >= 512 + 256 + 512 + 1024 + (size_t)QWIDE * 1024 * 8 && GS_OFF_QFLAG + GS_MAXQ * 4 <= PAIR_STATE, "inside the first chunk's state");
+struct GPlan {
+    bool ok;
+    int G, ncol, ldq;
+    int64_t rows_per_range;
+    int s_tiles, nmax; int64_t s_stride;
+    int gcap;
+    size_t off_q16, off_theta, off_gcnt, off_wgstat, off_smax, off_lists, total;
+};
+GPlan make_gplan(int64_t N, int nq, int cus) {
+    GPlan g{};
+    int ncol = 1;
+    while (ncol * GS_TILE < nq) ncol *= 2;
+    g.ncol = ncol; g.ldq = ncol * GS_TILE;
+    g.G = cus / (8 * ncol) * (8 * ncol);
+    const int64_t full_tiles = N / GS_TILE, tiles = (N + GS_TILE - 1) / GS_TILE;
+    g.ok = nq >= 1 && nq <= GS_MAXQ && g.G >= 8 * ncol && g.G <= 1024 && full_tiles >= 256;
+    if (!g.ok) return g;
+    const int nranges = g.G / ncol;
+    g.rows_per_range = (tiles + nranges - 1) / nranges * GS_TILE;
+    if (g.rows_per_range >= (1 << 24)) { g.ok = false; return g; }      // candidate entries carry a 24-bit row relative to the range
+    // the sample: ~1/64 of the slab in whole tiles, evenly spread (at least 128 tiles = 2 048 fragment maxima per query, at most 2 048 =
+    // 32 768 maxima: what gtheta_kernel keeps in LDS)
+    int64_t st = full_tiles / 64;
+    st = st < 128 ? 128 : (st > 2048 ? 2048 : st);
+    g.s_tiles = (int)st; g.nmax = g.s_tiles * GS_FRAG_PER_TILE;
+    g.s_stride = full_tiles / st * GS_TILE;
+    g.gcap = 32768;                                                      // = 1024 virtual segments of 32 entries for the merge
+    size_t o = PAIR_STATE * 2;
+    g.off_q16 = o;    o += align_up((size_t)g.ldq * D_FAST * 2, 256);
+    g.off_theta = o;  o += align_up((size_t)g.ldq * 4, 256);
+    g.off_gcnt = o;   o += align_up((size_t)g.ldq * 4, 256);
+    g.off_wgstat = o; o += align_up((size_t)g.G * 8, 256);
+    g.off_smax = o;   o += align_up((size_t)g.nmax * g.ldq * 4, 256);
+    g.off_lists = o;  o += (size_t)g.ldq * g.gcap * 8;
+    g.total = o;
+    return g;
+}
+
 template <typename KernelT>
 void allow_lds(KernelT kern) {   // opt in to the full 160 KiB of LDS (idempotent)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -692,6 +738,7 @@ void atlas_tune_set_scan_coop(int c) { g_scan_coop = c; }
 void atlas_tune_set_scan_fused(int f) { g_scan_fused = f; }
 void atlas_tune_set_scan_wide(int f) { g_scan_wide = f; }
 void atlas_tune_set_scan_pair(int f) { g_scan_pair = f; }
+void atlas_tune_set_scan_gemm(int f) { g_scan_gemm = f; }
 void atlas_tune_set_scan_pool(int permille, int max_per_wg) { g_pool_permille = permille; g_pool_max = max_per_wg; }
 // the launch plan of a scan over N rows on a device with `cus` CUs, for host-side checks of its invariants (no GPU needed):
 // out = {G, rows_per_wg, pool_begin, pool_rows, pool_tiles, tile, pool_tile, supported (the range checks of atlas_scan_topk)}
@@ -733,6 +780,10 @@ size_t atlas_scan_topk_workspace_bytes(int64_t N, int B, int d, int k) {
             const size_t t2 = pp.bulk_begin + 2 * pp.bulk_size;
             mx = t2 > mx ? t2 : mx;
         }
+    }
+    if (B > QWIDE) {                   // GEMM-shaped passes (gscan_kernel.h)
+        const GPlan g = make_gplan(N, B < GS_MAXQ ? B : GS_MAXQ, device_cus());
+        if (g.ok && g.total > mx) mx = g.total;
     }
     return mx;
 }
@@ -784,7 +835,9 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
     // on half the chip each (1.62 for up to 128 queries: the second reader of a slab row hits the Infinity Cache), a pair of 96-query
     // passes (1.89 for up to 192); f(n) = min over the items of cost + f(n - size): 128 -> a pair of 64, 192 -> a pair of 96,
     // 512 -> 2 pairs of 96 + a pair of 64.
-    struct Pass { int nq, nq2; bool wide; };
+    // ... and, for batches above 96 queries whose pmax is certified, GEMM-shaped passes (gscan_kernel.h) of up to 256 / 512 / 1024 queries: MFMA-bound
+    // instead of LDS-fed, one slab read from HBM per pass whatever its width.
+    struct Pass { int nq, nq2; bool wide; bool gemm; };
     std::vector<Pass> passes;
     ScanPlan pp = pl;                           // the half-chip plan of paired passes
     const int half = device_cus() / 2;
@@ -794,19 +847,29 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
         pair_ok = pp.S > 0 && pp.G == half && scan_plan_supported(pp, wide_ok ? 25 : 26) && ws_bytes >= pp.bulk_begin + 2 * pp.bulk_size;
     }
     const bool pair_wide_ok = pair_ok && wide_ok && half >= QWIDE;
-    if (B <= QCHUNK || (!wide_ok && !pair_ok)) {
-        for (int r = B; r > 0; r -= QCHUNK) passes.push_back({r < QCHUNK ? r : QCHUNK, 0, false});
+    bool gemm_ok[3] = {false, false, false};
+    if (B > QWIDE && trusted && scan_gemm_enabled()) {
+        for (int i = 0; i < 3; ++i) {
+            const GPlan g = make_gplan(N, GS_TILE << i, device_cus());
+            gemm_ok[i] = g.ok && ws_bytes >= g.total;
+        }
+    }
+    if (B <= QCHUNK || (!wide_ok && !pair_ok && !gemm_ok[0])) {
+        for (int r = B; r > 0; r -= QCHUNK) passes.push_back({r < QCHUNK ? r : QCHUNK, 0, false, false});
     } else {
-        const float cost[4] = {1.0f, 1.11f, 1.62f, 1.89f};                   // (measured at 4M and 32M rows: profiles/r03/batch_paired_pass_ab.txt)
-        const int size[4] = {QCHUNK, QWIDE, 2 * QCHUNK, 2 * QWIDE};
-        const bool ok[4] = {true, wide_ok, pair_ok, pair_wide_ok};
+        // costs in units of one 64-query pass (measured at 4M and 32M rows: profiles/r03/batch_paired_pass_ab.txt, profiles/r04/batch_gemm_pass_ab.txt)
+        constexpr int NI = 7;
+        const float cost[NI] = {1.0f, 1.11f, 1.62f, 1.89f, 1.30f, 2.45f, 4.8f};
+        const int size[NI] = {QCHUNK, QWIDE, 2 * QCHUNK, 2 * QWIDE, GS_TILE, 2 * GS_TILE, 4 * GS_TILE};
+        const bool ok[NI] = {true, wide_ok, pair_ok, pair_wide_ok, gemm_ok[0], gemm_ok[1], gemm_ok[2]};
         std::vector<float> f((size_t)B + 1, 0.f);
         std::vector<unsigned char> take((size_t)B + 1, 0);
         for (int n = 1; n <= B; ++n) {
             float best = 1e30f;
-            for (int it = 0; it < 4; ++it) {
+            for (int it = 0; it < NI; ++it) {
                 if (!ok[it]) continue;
-                if (it >= 2 && n <= size[it - 2]) continue;                  // a pair needs more queries than one pass of its kind takes
+                if ((it == 2 || it == 3) && n <= size[it - 2]) continue;     // a pair needs more queries than one pass of its kind takes
+                if (it >= 5 && n <= size[it - 1]) continue;                  // a column tile more than the queries fill
                 const float c = cost[it] + f[n > size[it] ? n - size[it] : 0];
                 if (c < best) { best = c; take[n] = (unsigned char)it; }
             }
@@ -814,8 +877,9 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
         }
         for (int r = B; r > 0;) {
             const int it = take[r], m = r < size[it] ? r : size[it];
-            if (it < 2) passes.push_back({m, 0, it == 1});
-            else passes.push_back({(m + 1) / 2, m / 2, it == 3});
+            if (it < 2) passes.push_back({m, 0, it == 1, false});
+            else if (it < 4) passes.push_back({(m + 1) / 2, m / 2, it == 3, false});
+            else passes.push_back({m, 0, false, true});
             r -= m;
         }
     }
@@ -833,6 +897,40 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
     for (size_t ci = 0; ci < passes.size(); q0 += passes[ci].nq + passes[ci].nq2, ++ci) {
         const int nq = passes[ci].nq, nq2 = passes[ci].nq2;
         const bool is_wide = passes[ci].wide, paired = nq2 > 0;
+        if (passes[ci].gemm) {
+            // GEMM-shaped pass: queries -> fp16 rows, sample launch -> fragment maxima, thresholds, scan launch, merge (flat lists)
+            const GPlan g = make_gplan(N, nq, device_cus());
+            auto gsample = gscan_kernel<1>;
+            auto gscan = gscan_kernel<0>;
+            allow_lds(gsample); allow_lds(gscan); allow_lds(gtheta_kernel);
+            uint16_t* q16 = (uint16_t*)(w + g.off_q16);
+            uint32_t* gcnt = (uint32_t*)(w + g.off_gcnt);
+            hipLaunchKernelGGL(gprep_kernel, dim3(nq), dim3(96), 0, stream, q, q_dtype, q0, (uint4*)q16, gcnt, out_status);
+            GScanParams gs{};
+            gs.slab = (const uint16_t*)slab_f16; gs.N = N; gs.q16 = q16; gs.nq = nq; gs.ncol = g.ncol; gs.rows_per_range = g.rows_per_range;
+            gs.s_tiles = g.s_tiles; gs.s_stride = g.s_stride; gs.theta = (const float*)(w + g.off_theta); gs.smax = (float*)(w + g.off_smax);
+            gs.lists = (uint2*)(w + g.off_lists); gs.gcnt = gcnt; gs.qflag = (uint32_t*)(w + GS_OFF_QFLAG); gs.gcap = g.gcap;
+            gs.wg_stat = (uint32_t*)(w + g.off_wgstat);
+            hipLaunchKernelGGL(gsample, dim3(g.G), dim3(512), GS_LDS_BYTES, stream, gs);
+            hipLaunchKernelGGL(gtheta_kernel, dim3(g.ldq), dim3(256), GTHETA_LDS(g.nmax), stream, (const float*)gs.smax, g.nmax, g.ldq, (const uint16_t*)q16, nq,
+                               pmax_hint, k, (float*)(w + g.off_theta));
+            if (q0 == 0 && ev_scan_begin) (void)hipEventRecord((hipEvent_t)ev_scan_begin, stream);
+            hipLaunchKernelGGL(gscan, dim3(g.G), dim3(512), GS_LDS_BYTES, stream, gs);
+            if (q0 == 0 && ev_scan_end) (void)hipEventRecord((hipEvent_t)ev_scan_end, stream);
+            MergeParams mp{};
+            mp.slab = (const uint16_t*)slab_f16; mp.N = N; mp.d = d;
+            mp.q = q16; mp.q_dtype = ATLAS_DT_F16; mp.qbase = 0; mp.pmax = pmax_hint; mp.pmax_trusted = 1;
+            mp.lists = gs.lists; mp.list_cnt = nullptr; mp.wg_stat = gs.wg_stat; mp.G = 1024; mp.cap = g.gcap / 1024;
+            mp.flat_cnt = gcnt; mp.nstat = g.G;
+            mp.total_cap = g.gcap; mp.epoch = (uint32_t*)(w + single.off_epoch); mp.ticket = (uint32_t*)(w + single.off_epoch + 128);
+            mp.qflag = gs.qflag; mp.k = k; mp.q0 = q0; mp.key_cap = single.key_cap;
+            mp.dbg = g_merge_dbg;
+            mp.out_score = (uint16_t*)out_score_f16; mp.out_idx = out_idx; mp.out_status = out_status;
+            mp.out_packed = out_packed; mp.id_mul = id_mul; mp.id_add = id_add;
+            mp.nq1 = nq; mp.nq2 = 0; mp.pair_state = PAIR_STATE; mp.pair_bulk = 0;
+            hipLaunchKernelGGL(merge, dim3(nq, 1), dim3(MERGE_NT), single.merge_lds, stream, mp);
+            continue;
+        }
         const ScanPlan& pl = paired ? pp : single;                          // (shadows the whole-chip plan inside the loop)
         // initial thresholds: the scan derives them from the tile maxima of an evenly spread sample; small shards
         // start at -inf. Whoever runs first clears the per-call state (per-query fallback flags, status header).

@@ -1,0 +1,364 @@
+// gscan_kernel.h -- the slab scan for BIG query batches (a rank of an N-GPU search scores ALL gathered queries, src/index.py:127-131:
+// 512 per call at W = 8 x 64), shaped like a GEMM: scores[256 slab rows x 256 queries] per workgroup tile, both operands staged through LDS
+// by LDS-DMA, accumulators in registers for the whole k = 768, and the threshold filter of scan_kernel.h as the epilogue. Scores never
+// reach HBM here either.
+//
+// Why a second kernel: scan_kernel.h streams -- one 16-row fragment per wave, the query operand re-read from an LDS image for every MFMA
+// (one ds_read_b128 per MFMA) -- which is right while the slab bytes are the bound (<= 96 queries per pass: 64-96 flop per byte against a
+// ridge of ~312), and wrong above it: 512 queries on a 4M-row shard ran at 0.216 of the f16 MFMA peak. Here a wave owns a
+// 128-row x 64-query block: 24 ds_read_b128 feed 64 MFMAs per 64-wide k-tile.
+//
+// Decomposition. One workgroup per CU (all 160 KiB of LDS), 8 waves as 2 (slab rows) x 4 (queries); the two waves of a SIMD run in
+// opposite phases (one reads its fragments and issues LDS-DMA while the other multiplies: the ping-pong schedule of encoder.hip's bulk
+// GEMM). Workgroup g: XCD x = g & 7, slot s = g >> 3; query column tile c = s % ncol (256 queries each), row range (x, s / ncol): a
+// contiguous, tile-aligned share of the slab. The ncol workgroups that score the same rows against different query tiles sit on the SAME
+// XCD in neighbouring slots and walk their range in step, so every slab tile comes from HBM once and from that XCD's L2 (or the
+// Infinity Cache) the other ncol - 1 times: HBM traffic is one slab read per launch whatever the batch.
+//
+// Thresholds. A first launch of the same kernel in SAMPLE mode scores s_tiles evenly spread tiles and leaves, per query, the maximum of
+// every 16-row fragment; gtheta_kernel takes the k-th largest of those maxima (scores of DISTINCT rows -> prune_threshold gives a
+// certified threshold) -- the sample grows with the shard (about 1/64 of it), so a query brings ~70 k candidates per
+// million... no: ~64 k x 1.1 candidates to the merge whatever the shard's size. The SCAN launch then keeps what passes, per wave: a
+// wave appends to its own LDS buffer (slots from ballots: no atomics, no barrier) and empties it into the per-query global lists when it
+// is full (one returning atomic per entry on gcnt[query], all lanes at once) -- a few times per millisecond.
+// The merge is merge_rescore_kernel in FLAT mode (merge_kernel.h): one contiguous list per query, cut into 1024 virtual segments.
+#pragma once
+#include "scan_kernel.h"
+
+namespace atlas {
+
+#define GS_TILE 256               // slab rows per workgroup tile, and queries per column tile
+#define GS_NK (D_FAST / 64)       // 12 k-tiles of 64 halfs (128 bytes of every row)
+#define GS_STG (256 * 128)        // bytes of one operand stage
+#define GS_WBUF_ENTRIES 448       // candidate entries of one wave's LDS buffer (8 x 3.5 KiB behind the four stages)
+#define GS_LDS_BYTES (4 * GS_STG + 8 * GS_WBUF_ENTRIES * 8)     // 159 744
+#define GTHETA_LDS(nmax) (64 + 4096 + (size_t)(nmax) * 4)
+#define GS_FRAG_PER_TILE 16       // 16-row fragments of a tile: the sample keeps one maximum per fragment and query
+
+struct GScanParams {
+    const uint16_t* slab;     // [N][768] fp16
+    int64_t N;
+    const uint16_t* q16;      // [nq][768] the queries of this pass as fp16 rows (gprep_kernel)
+    int nq, ncol;             // queries of the pass, column tiles of 256 (ncol divides gridDim.x / 8)
+    int64_t rows_per_range;   // SCAN: rows of every row range (a multiple of 256)
+    int s_tiles;              // SAMPLE: tiles of the sample; tile t = rows [t * s_stride, + 256), all inside the slab
+    int64_t s_stride;
+    const float* theta;       // SCAN: [ncol * 256] pruning thresholds (+inf for the padding queries)
+    float* smax;              // SAMPLE: [s_tiles * 16][ncol * 256] fragment maxima
+    uint2* lists;             // SCAN: [nq][gcap] {f32 bits of the approximate score, shard-local row}
+    uint32_t* gcnt;           // SCAN: [nq] entries appended to lists[q] (may exceed gcap: the query is then flagged)
+    uint32_t* qflag;          // SCAN: [nq] fallback flags (plain idempotent stores)
+    int gcap;
+    uint32_t* wg_stat;        // SCAN: [gridDim.x][2] {largest row norm^2 seen (0: this kernel does not measure), ATLAS_F_* flags}
+};
+
+typedef unsigned int gs_u4 __attribute__((ext_vector_type(4)));
+
+// MODE 0 = scan (filter epilogue), 1 = sample (fragment maxima)
+template <int MODE>
+__global__ void __launch_bounds__(512)
+gscan_kernel(const GScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // S0 | S1 | Q0 | Q1 (32 KiB each) | 8 wave buffers
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 2, wj = wave & 3;
+    const bool grpB = wave >= 4;
+    const int lr = lane & 15, lg = lane >> 4;
+    constexpr int ROWB = D_FAST * 2;
+
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int col = slot % p.ncol;
+    const int per_xcd = nslots / p.ncol;
+    const int range = xcd * per_xcd + slot / p.ncol, nranges = 8 * per_xcd;
+    int64_t begin = 0, end = 0;
+    int ntl;
+    if (MODE == 0) {
+        begin = (int64_t)range * p.rows_per_range;
+        end = begin + p.rows_per_range;
+        if (end > p.N) end = p.N;
+        ntl = end > begin ? (int)((end - begin + GS_TILE - 1) / GS_TILE) : 0;
+    } else {
+        ntl = range < p.s_tiles ? (p.s_tiles - range + nranges - 1) / nranges : 0;
+    }
+    auto tile_row0 = [&](const int ti) -> int64_t {
+        return MODE == 0 ? begin + (int64_t)ti * GS_TILE : (int64_t)(range + ti * nranges) * p.s_stride;
+    };
+    if (MODE == 0 && tid == 0) { p.wg_stat[(size_t)blockIdx.x * 2] = 0u; p.wg_stat[(size_t)blockIdx.x * 2 + 1] = 0u; }
+    if (ntl == 0) return;
+    const int total_it = ntl * GS_NK;
+
+    // LDS-DMA: one wave instruction writes 8 LDS rows x 128 B, lane-linear; wave w stages LDS rows 32 w + 8 i + (lane >> 3), i = 0..3, of
+    // both operands. LDS[row][16-byte position p] holds source chunk p ^ (row & 7) (the swizzle sits on the SOURCE address), which makes the
+    // fragment reads below conflict-free. Everything that selects a ROW is in the bounds-checked voffset: rows past the end of the range /
+    // of the queries are not fetched (zeros land in LDS); the k-tile rides in the scalar offset.
+    const uint32_t chb = (uint32_t)(((lane & 7) ^ (lane >> 3)) * 16);
+    const uint32_t vrow = (uint32_t)(wave * 32 + (lane >> 3)) * ROWB + chb;
+    int qrows = p.nq - col * GS_TILE;
+    qrows = __builtin_amdgcn_readfirstlane(qrows < 0 ? 0 : (qrows > GS_TILE ? GS_TILE : qrows));     // (hipcc clamps with v_med3: back to an SGPR, or the descriptor lives in VGPRs)
+    auto stage = [&](const int buf, const int it) {
+        // (both descriptors are formed HERE, SGPR arithmetic: a descriptor carried across the k-loop ends up in VGPRs and every DMA in a
+        //  readfirstlane loop)
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(p.q16 + (size_t)col * GS_TILE * D_FAST), 0, qrows * ROWB, 0x00020000);
+        const int ti = it / GS_NK, kt = it - ti * GS_NK;
+        const int64_t r0 = tile_row0(ti);
+        int64_t rem = (MODE == 0 ? end : p.N) - r0;
+        if (rem > GS_TILE) rem = GS_TILE;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.slab + (size_t)r0 * D_FAST), 0, (int)rem * ROWB, 0x00020000);
+        const int kb = kt * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(smem + buf * GS_STG + (wave * 32 + i * 8) * 128), 16, (int)(vrow + (uint32_t)(i * 8 * ROWB)), kb, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_ptr)(smem + 2 * GS_STG + buf * GS_STG + (wave * 32 + i * 8) * 128), 16, (int)(vrow + (uint32_t)(i * 8 * ROWB)), kb, 0, 0);
+    };
+
+    // the lane's fragment chunks: slab rows wi * 128 + 16 a + lr (MFMA A operand), query rows wj * 64 + 16 b + lr (B operand); k-step 0 of a
+    // k-tile = chunks 0..3 (chunk lg of the lane), k-step 1 = chunks 4..7
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const uint32_t as0 = lds0 + (wi * 128 + lr) * 128 + ((0 + lg) ^ (lr & 7)) * 16;
+    const uint32_t as1 = lds0 + (wi * 128 + lr) * 128 + ((4 + lg) ^ (lr & 7)) * 16;
+    const uint32_t aq0 = lds0 + 2 * GS_STG + (wj * 64 + lr) * 128 + ((0 + lg) ^ (lr & 7)) * 16;
+    const uint32_t aq1 = lds0 + 2 * GS_STG + (wj * 64 + lr) * 128 + ((4 + lg) ^ (lr & 7)) * 16;
+
+    // C layout of v_mfma_f32_16x16x32_f16: lane l holds query column l & 15 and slab rows 4 (l >> 4) + r of the 16 x 16 block: the lane
+    // OWNS its queries, the thresholds are four per-lane scalars for the whole kernel
+    float th[4];
+    if (MODE == 0) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) th[b] = p.theta[col * GS_TILE + wj * 64 + b * 16 + lr];
+    }
+    uint2* wbuf = (uint2*)(smem + 4 * GS_STG) + wave * GS_WBUF_ENTRIES;
+    uint32_t cnt = 0;                                   // entries in this wave's buffer (wave-uniform)
+    auto flush = [&]() {
+        for (uint32_t i = (uint32_t)lane_now(); i < cnt; i += 64) {
+            const uint2 e = wbuf[i];
+            const uint32_t qq = (uint32_t)(col * GS_TILE) + (e.y >> 24);
+            const uint32_t gs = atomicAdd(&p.gcnt[qq], 1u);
+            if (gs < (uint32_t)p.gcap) p.lists[(size_t)qq * p.gcap + gs] = make_uint2(e.x, (uint32_t)begin + (e.y & 0xffffffu));
+            else p.qflag[qq] = 1u;                      // the list is full (mass ties, no usable threshold): exact path
+        }
+        cnt = 0;
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto epilogue = [&](const int ti) {
+        if (MODE == 0) {
+            const int64_t r0 = tile_row0(ti);
+            const int valid = (int)(end - r0 > GS_TILE ? GS_TILE : end - r0);
+            // (everything lane-derived is formed HERE from a lane id hipcc cannot trace back: hoisted over the k-loop -- which runs at the
+            //  register cap: 128 accumulators + 96 fragment registers -- it would push fragments into scratch)
+            const int ln = lane_now(), lr_e = ln & 15, lg_e = ln >> 4;
+            const uint32_t rel0 = (uint32_t)(ti * GS_TILE + wi * 128 + lg_e * 4);     // row of acc[0][.][0], relative to `begin` (< 2^24)
+            const uint32_t qtag = (uint32_t)(wj * 64 + lr_e) << 24;
+            const int rin0 = wi * 128 + lg_e * 4;                                      // row of acc[0][.][0] inside the tile
+            if (cnt > GS_WBUF_ENTRIES / 2) flush();
+            // Passing scores take the buffer slots cnt, cnt + 1, ... in walk order (ballot prefix counts: no atomics, no barrier). A handful
+            // pass per tile and wave; the buffer has room for at least GS_WBUF_ENTRIES / 2 more. What does not fit (no usable threshold,
+            // mass ties: adversarial data) sends its query to the exact path, as a full list does.
+            uint32_t lost = 0;                          // bit b: an entry of query column b of this lane found no slot
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const f32x4 v = acc[a][b];
+                    const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                    if (__builtin_amdgcn_ballot_w64(m > th[b]) == 0ull) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool pass = v[r] > th[b] && rin0 + a * 16 + r < valid;
+                        const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
+                        const uint32_t idx = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                        if (pass) {
+                            if (idx < GS_WBUF_ENTRIES)
+                                wbuf[idx] = make_uint2(f32_bits(v[r]), (qtag + ((uint32_t)(b * 16) << 24)) | (rel0 + (uint32_t)(a * 16 + r)));
+                            else lost |= 1u << b;
+                        }
+                        cnt += (uint32_t)__popcll(mask);
+                    }
+                }
+            if (cnt > GS_WBUF_ENTRIES) {
+                cnt = GS_WBUF_ENTRIES;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (lost & (1u << b)) p.qflag[col * GS_TILE + wj * 64 + b * 16 + lr_e] = 1u;
+            }
+        } else {
+            const int ts = range + ti * nranges;
+            const size_t ldq = (size_t)p.ncol * GS_TILE;
+            const int ln = lane_now(), lr_e = ln & 15, lg_e = ln >> 4;
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const f32x4 v = acc[a][b];
+                    float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                    m = fmaxf(m, __shfl_xor(m, 16));
+                    m = fmaxf(m, __shfl_xor(m, 32));
+                    if (lg_e == 0) p.smax[((size_t)ts * GS_FRAG_PER_TILE + wi * 8 + a) * ldq + (size_t)(col * GS_TILE + wj * 64 + b * 16 + lr_e)] = m;
+                }
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+
+    // Phases are separated by s_barrier (all 8 waves); group A = waves 0-3, group B = waves 4-7 (wave w and w + 4 share a SIMD):
+    //     phase 2i     : A reads k-tile i (+ issues the DMA of i + 1)      | B multiplies k-tile i - 1 (+ issues the DMA of i + 1 first)
+    //     phase 2i + 1 : A multiplies k-tile i                             | B reads k-tile i
+    // One flat loop over the k-tiles of ALL tiles of the workgroup: the staging runs straight through the tile boundaries. The epilogue of a
+    // tile needs no barrier and no stage buffer: a group runs it behind the barrier that ends its tile's last multiply phase, while the
+    // other group is still multiplying or already reading.
+    stage(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's pieces of k-tile 0 have landed
+    __builtin_amdgcn_s_barrier();
+    if (grpB) {                                        // B's phase 0: nothing to multiply yet
+        if (total_it > 1) stage(1, 1);
+        __builtin_amdgcn_s_barrier();
+    }
+    int kt = 0, ti = 0;
+#pragma unroll 1
+    for (int it = 0; it < total_it; ++it) {
+        const int buf = it & 1;
+        gs_u4 fs0[8], fq0[4], fs1[8], fq1[4];
+        {
+            // (inline asm: hipcc's wait insertion would drain vmcnt(0) in front of any ds_read it sees behind an LDS-DMA it cannot prove disjoint)
+            const uint32_t s0 = as0 + buf * GS_STG, s1 = as1 + buf * GS_STG, q0 = aq0 + buf * GS_STG, q1 = aq1 + buf * GS_STG;
+            asm volatile(
+                "ds_read_b128 %0, %24\n ds_read_b128 %1, %24 offset:2048\n ds_read_b128 %2, %24 offset:4096\n ds_read_b128 %3, %24 offset:6144\n"
+                "ds_read_b128 %4, %24 offset:8192\n ds_read_b128 %5, %24 offset:10240\n ds_read_b128 %6, %24 offset:12288\n ds_read_b128 %7, %24 offset:14336\n"
+                "ds_read_b128 %8, %25\n ds_read_b128 %9, %25 offset:2048\n ds_read_b128 %10, %25 offset:4096\n ds_read_b128 %11, %25 offset:6144\n"
+                "ds_read_b128 %12, %26\n ds_read_b128 %13, %26 offset:2048\n ds_read_b128 %14, %26 offset:4096\n ds_read_b128 %15, %26 offset:6144\n"
+                "ds_read_b128 %16, %26 offset:8192\n ds_read_b128 %17, %26 offset:10240\n ds_read_b128 %18, %26 offset:12288\n ds_read_b128 %19, %26 offset:14336\n"
+                "ds_read_b128 %20, %27\n ds_read_b128 %21, %27 offset:2048\n ds_read_b128 %22, %27 offset:4096\n ds_read_b128 %23, %27 offset:6144\n"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(fs0[0]), "=&v"(fs0[1]), "=&v"(fs0[2]), "=&v"(fs0[3]), "=&v"(fs0[4]), "=&v"(fs0[5]), "=&v"(fs0[6]), "=&v"(fs0[7]),
+                  "=&v"(fq0[0]), "=&v"(fq0[1]), "=&v"(fq0[2]), "=&v"(fq0[3]),
+                  "=&v"(fs1[0]), "=&v"(fs1[1]), "=&v"(fs1[2]), "=&v"(fs1[3]), "=&v"(fs1[4]), "=&v"(fs1[5]), "=&v"(fs1[6]), "=&v"(fs1[7]),
+                  "=&v"(fq1[0]), "=&v"(fq1[1]), "=&v"(fq1[2]), "=&v"(fq1[3])
+                : "v"(s0), "v"(q0), "v"(s1), "v"(q1)
+                : "memory");
+        }
+        if (!grpB) { if (it + 1 < total_it) stage(buf ^ 1, it + 1); }     // after the reads: issued first, the DMA competes with them
+        else __builtin_amdgcn_s_waitcnt(0x0F70);       // B: its pieces of k-tile it + 1 (issued a phase ago) have landed
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (grpB && it + 2 < total_it) stage(buf, it + 2);                 // into the buffer both groups have finished reading
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fs0[a]), __builtin_bit_cast(f16x8, fq0[b]), acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fs1[a]), __builtin_bit_cast(f16x8, fq1[b]), acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!grpB) __builtin_amdgcn_s_waitcnt(0x0F70); // A: its pieces of k-tile it + 1 have landed
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (++kt == GS_NK) {
+            epilogue(ti);
+            kt = 0;
+            ++ti;
+        }
+    }
+    if (!grpB) __builtin_amdgcn_s_barrier();           // A matches B's extra barrier
+    if (MODE == 0) flush();
+}
+
+// ------------------------------------------------------------------------------------------
+// gprep_kernel: queries of a pass -> fp16 rows (RNE = `.half()`, src/index.py:117) in the workspace (the LDS-DMA of gscan_kernel copies
+// bytes), and the per-pass state: list lengths to zero, status header (first pass of a call). One block of 96 threads per query.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(96)
+gprep_kernel(const void* __restrict__ q, const int q_dtype, const int q0, uint4* __restrict__ q16, uint32_t* __restrict__ gcnt,
+             int32_t* __restrict__ out_status) {
+    const int j = blockIdx.x, t = threadIdx.x;
+    q16[(size_t)j * (D_FAST / 8) + t] = q8_to_f16(load_q8(q, q_dtype, (size_t)(q0 + j) * D_FAST + (size_t)t * 8), q_dtype);
+    if (t == 0) gcnt[j] = 0u;
+    if (q0 == 0 && j == 0 && t < ATLAS_STATUS_HEADER) out_status[t] = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// gtheta_kernel: the certified initial threshold of every query of a pass from the sample's fragment maxima. One block per query slot
+// (ldq = ncol * 256 of them; slots >= nq get +inf: they never collect anything). A lower bound T of the k-th largest of the nmax maxima
+// from one 1024-bin histogram over [min, max] (any T with count(maxima >= T) >= k is valid: k DISTINCT rows score >= T - eps), then
+// prune_threshold(T, eps) (common.h). Fewer than k maxima: -inf.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+gtheta_kernel(const float* __restrict__ smax, const int nmax, const int ldq, const uint16_t* __restrict__ q16, const int nq, const float pmax,
+              const int k, float* __restrict__ theta) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // (all LDS is dynamic, GTHETA_LDS(nmax) bytes: the launch may ask for up to 133 KiB)
+    double* s_ss = (double*)smem;                      // [4]
+    uint32_t* s_mm = (uint32_t*)(smem + 32);           // [2]; [2] = the bin edge
+    uint32_t& s_bin = s_mm[2];
+    uint32_t* hist = (uint32_t*)(smem + 64);           // [1024]
+    uint32_t* keys = hist + 1024;                      // [nmax]
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (q >= nq) { if (tid == 0) theta[q] = pos_inf(); return; }
+    double ss = 0.0;
+    for (int i = tid; i < D_FAST; i += 256) { const double v = (double)(float)__builtin_bit_cast(_Float16, q16[(size_t)q * D_FAST + i]); ss += v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) s_ss[wave] = ss;
+    if (tid == 0) { s_mm[0] = 0xffffffffu; s_mm[1] = 0u; s_bin = 0u; }
+    for (int i = tid; i < 1024; i += 256) hist[i] = 0u;
+    __syncthreads();
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
+    for (int i = tid; i < nmax; i += 256) {
+        const uint32_t key = f32_order_key(smax[(size_t)i * ldq + q]);
+        keys[i] = key;
+        kmin = key < kmin ? key : kmin;
+        kmax = key > kmax ? key : kmax;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = __shfl_xor(kmin, o), b = __shfl_xor(kmax, o);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    if (lane == 0) { atomicMin(&s_mm[0], kmin); atomicMax(&s_mm[1], kmax); }
+    __syncthreads();
+    kmin = s_mm[0]; kmax = s_mm[1];
+    const float eps = query_eps((float)(s_ss[0] + s_ss[1] + s_ss[2] + s_ss[3]) * 1.000001f, pmax);
+    if (nmax < k) { if (tid == 0) theta[q] = neg_inf(); return; }
+    const uint32_t span = kmax - kmin;
+    const int shift = span >= 1024u ? (32 - __builtin_clz(span)) - 10 : 0;      // (key - kmin) >> shift < 1024
+    for (int i = tid; i < nmax; i += 256) atomicAdd(&hist[(keys[i] - kmin) >> shift], 1u);
+    __syncthreads();
+    if (tid < 64) {                                    // lane l owns bins [16 l, 16 l + 16): suffix sums find the lane, then the bin
+        uint32_t own = 0;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) own += hist[tid * 16 + b];
+        uint32_t suf = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_down(suf, o);
+            if (tid + o < 64) suf += y;
+        }
+        const uint32_t above = suf - own;
+        if (above < (uint32_t)k && suf >= (uint32_t)k) {
+            uint32_t acc = above; int bin = tid * 16;
+            for (int b = 15; b >= 0; --b) {
+                acc += hist[tid * 16 + b];
+                if (acc >= (uint32_t)k) { bin = tid * 16 + b; break; }
+            }
+            s_bin = kmin + ((uint32_t)bin << shift);  // lower edge of the bin that holds rank k
+        }
+    }
+    __syncthreads();
+    if (tid == 0) theta[q] = prune_threshold(f32_from_order_key(s_bin), eps);
+}
+
+}  // namespace atlas

@@ -52,6 +52,11 @@ struct MergeParams {
     // lists live pair_state / pair_bulk bytes behind the first chunk's
     int nq1, nq2;
     size_t pair_state, pair_bulk;
+    // FLAT mode (gscan_kernel.h): the candidates of query q are ONE contiguous list, lists[q * G * cap ...], of flat_cnt[q] entries (clipped
+    // to G * cap); it is cut into G virtual segments of cap entries so that the gather below works on it unchanged. nstat = entries of
+    // wg_stat (the scan's workgroups); 0 = G.
+    const uint32_t* flat_cnt;
+    int nstat;
 };
 
 // Canonical exact score (common.h exact_dot_f16) computed by ONE WAVE: lane j is chain j and adds the
@@ -119,8 +124,16 @@ static __device__ __forceinline__ void merge_rescore_body(const MergeParams& p, 
     // norm / flag word (the scan's certification state is reduced here, the scan kernel itself ends without a single global atomic)
     static_assert(NT >= MERGE_GMAX, "one thread per scan workgroup");
     uint32_t cg = 0, pmb = 0, flg = 0;
+    const int nstat = p.nstat > 0 ? p.nstat : p.G;
     if (tid < p.G) {
-        cg = p.list_cnt[(size_t)q * p.G + tid];
+        if (p.flat_cnt != nullptr) {
+            const uint32_t n = p.flat_cnt[q], lo = (uint32_t)tid * (uint32_t)p.cap;
+            cg = n > lo ? (n - lo < (uint32_t)p.cap ? n - lo : (uint32_t)p.cap) : 0u;
+        } else {
+            cg = p.list_cnt[(size_t)q * p.G + tid];
+        }
+    }
+    if (tid < nstat) {
         pmb = p.wg_stat[(size_t)tid * 2 + 0];                         // non-negative floats order like their bits
         flg = p.wg_stat[(size_t)tid * 2 + 1];
     }
@@ -168,7 +181,7 @@ static __device__ __forceinline__ void merge_rescore_body(const MergeParams& p, 
         pmb = a > pmb ? a : pmb;
         flg |= shfl_xor_n(flg, o);
     }
-    if (lane == 0 && wave * 64 < p.G) { atomicMax(&misc[7], pmb); if (flg) atomicOr(&misc[6], flg); }
+    if (lane == 0 && wave * 64 < nstat) { atomicMax(&misc[7], pmb); if (flg) atomicOr(&misc[6], flg); }
     uint32_t inc = cg;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
