@@ -859,7 +859,7 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
     } else {
         // costs in units of one 64-query pass (measured at 4M and 32M rows: profiles/r03/batch_paired_pass_ab.txt, profiles/r04/batch_gemm_pass_ab.txt)
         constexpr int NI = 7;
-        const float cost[NI] = {1.0f, 1.11f, 1.62f, 1.89f, 1.30f, 2.45f, 4.8f};
+        const float cost[NI] = {1.0f, 1.11f, 1.62f, 1.89f, 1.56f, 2.86f, 5.40f};
         const int size[NI] = {QCHUNK, QWIDE, 2 * QCHUNK, 2 * QWIDE, GS_TILE, 2 * GS_TILE, 4 * GS_TILE};
         const bool ok[NI] = {true, wide_ok, pair_ok, pair_wide_ok, gemm_ok[0], gemm_ok[1], gemm_ok[2]};
         std::vector<float> f((size_t)B + 1, 0.f);
@@ -911,11 +911,24 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
             gs.s_tiles = g.s_tiles; gs.s_stride = g.s_stride; gs.theta = (const float*)(w + g.off_theta); gs.smax = (float*)(w + g.off_smax);
             gs.lists = (uint2*)(w + g.off_lists); gs.gcnt = gcnt; gs.qflag = (uint32_t*)(w + GS_OFF_QFLAG); gs.gcap = g.gcap;
             gs.wg_stat = (uint32_t*)(w + g.off_wgstat);
+            gs.dbg = g_scan_dbg;
             hipLaunchKernelGGL(gsample, dim3(g.G), dim3(512), GS_LDS_BYTES, stream, gs);
             hipLaunchKernelGGL(gtheta_kernel, dim3(g.ldq), dim3(256), GTHETA_LDS(g.nmax), stream, (const float*)gs.smax, g.nmax, g.ldq, (const uint16_t*)q16, nq,
-                               pmax_hint, k, (float*)(w + g.off_theta));
+                               pmax_hint, k, (float*)(w + g.off_theta), (const uint2*)nullptr, (const uint32_t*)nullptr, 0);
+            // the scan, in two launches: the first eighth of every row range with the sample's thresholds, then -- thresholds tightened by what
+            // that found (the k-th best of N / 8 rows instead of the k-th best of the N / 64 sampled ones) -- the rest: ~4 x fewer candidates
+            // per query, and the filter epilogue of most tiles finds nothing to do
+            const int tiles_per_range = (int)(g.rows_per_range / GS_TILE);
+            const int t1 = tiles_per_range >= 16 ? (tiles_per_range + 7) / 8 : tiles_per_range;
             if (q0 == 0 && ev_scan_begin) (void)hipEventRecord((hipEvent_t)ev_scan_begin, stream);
+            gs.tile_begin = 0; gs.tile_end = t1;
             hipLaunchKernelGGL(gscan, dim3(g.G), dim3(512), GS_LDS_BYTES, stream, gs);
+            if (t1 < tiles_per_range) {
+                hipLaunchKernelGGL(gtheta_kernel, dim3(g.ldq), dim3(256), GTHETA_LDS(GTHETA_MAXKEYS), stream, (const float*)gs.smax, g.nmax, g.ldq, (const uint16_t*)q16, nq,
+                                   pmax_hint, k, (float*)(w + g.off_theta), (const uint2*)gs.lists, (const uint32_t*)gcnt, g.gcap);
+                gs.tile_begin = t1; gs.tile_end = tiles_per_range;
+                hipLaunchKernelGGL(gscan, dim3(g.G), dim3(512), GS_LDS_BYTES, stream, gs);
+            }
             if (q0 == 0 && ev_scan_end) (void)hipEventRecord((hipEvent_t)ev_scan_end, stream);
             MergeParams mp{};
             mp.slab = (const uint16_t*)slab_f16; mp.N = N; mp.d = d;

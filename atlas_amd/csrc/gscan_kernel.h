@@ -30,9 +30,12 @@ namespace atlas {
 #define GS_TILE 256               // slab rows per workgroup tile, and queries per column tile
 #define GS_NK (D_FAST / 64)       // 12 k-tiles of 64 halfs (128 bytes of every row)
 #define GS_STG (256 * 128)        // bytes of one operand stage
-#define GS_WBUF_ENTRIES 448       // candidate entries of one wave's LDS buffer (8 x 3.5 KiB behind the four stages)
+#define GS_WBUF_ENTRIES 448       // entries of one wave's LDS buffer (8 x 3.5 KiB behind the four stages): GS_WBUF_REAL candidates + one dummy slot per lane
+#define GS_WBUF_REAL (GS_WBUF_ENTRIES - 64)
 #define GS_LDS_BYTES (4 * GS_STG + 8 * GS_WBUF_ENTRIES * 8)     // 159 744
 #define GTHETA_LDS(nmax) (64 + 4096 + (size_t)(nmax) * 4)
+#define GTHETA_MAXKEYS 32768
+#define GS_PIECES_A 11            // LDS-DMA pieces per k-tile of a wave of group A (of 16 per pair of waves; see `stage`)
 #define GS_FRAG_PER_TILE 16       // 16-row fragments of a tile: the sample keeps one maximum per fragment and query
 
 struct GScanParams {
@@ -41,6 +44,8 @@ struct GScanParams {
     const uint16_t* q16;      // [nq][768] the queries of this pass as fp16 rows (gprep_kernel)
     int nq, ncol;             // queries of the pass, column tiles of 256 (ncol divides gridDim.x / 8)
     int64_t rows_per_range;   // SCAN: rows of every row range (a multiple of 256)
+    int tile_begin, tile_end; // SCAN: this launch takes tiles [tile_begin, tile_end) of every range (two launches per pass: the second one runs with
+                              // thresholds tightened by what the first one found, gtheta_kernel)
     int s_tiles;              // SAMPLE: tiles of the sample; tile t = rows [t * s_stride, + 256), all inside the slab
     int64_t s_stride;
     const float* theta;       // SCAN: [ncol * 256] pruning thresholds (+inf for the padding queries)
@@ -50,7 +55,20 @@ struct GScanParams {
     uint32_t* qflag;          // SCAN: [nq] fallback flags (plain idempotent stores)
     int gcap;
     uint32_t* wg_stat;        // SCAN: [gridDim.x][2] {largest row norm^2 seen (0: this kernel does not measure), ATLAS_F_* flags}
+    unsigned long long* dbg;  // tuning build only (atlas_tune_set_scan_stamps): shader-clock stamps of workgroup 0, [8 waves][GS_STAMP_ITERS][8]; null in production
 };
+#define GS_STAMP_FIRST 24         // the stamped iterations: k-tiles 24 .. 55 of the workgroup (its third to fifth tile)
+#define GS_STAMP_ITERS 32
+#if ATLAS_TUNING
+#define GS_STAMP(i) do { if (MODE == 0 && p.dbg != nullptr && blockIdx.x == 0 && it >= GS_STAMP_FIRST && it < GS_STAMP_FIRST + GS_STAMP_ITERS && lane_now() == 0) \
+        p.dbg[((size_t)wave * GS_STAMP_ITERS + (it - GS_STAMP_FIRST)) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+// epilogue stamps: [8 waves][8 tiles][4] behind the k-loop stamps
+#define GS_ESTAMP(i) do { if (MODE == 0 && p.dbg != nullptr && blockIdx.x == 0 && ti < 8 && lane_now() == 0) \
+        p.dbg[(size_t)8 * GS_STAMP_ITERS * 8 + ((size_t)wave * 8 + ti) * 4 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GS_STAMP(i) do { } while (0)
+#define GS_ESTAMP(i) do { } while (0)
+#endif
 
 typedef unsigned int gs_u4 __attribute__((ext_vector_type(4)));
 
@@ -78,11 +96,13 @@ gscan_kernel(const GScanParams p) {
         end = begin + p.rows_per_range;
         if (end > p.N) end = p.N;
         ntl = end > begin ? (int)((end - begin + GS_TILE - 1) / GS_TILE) : 0;
+        ntl = (ntl < p.tile_end ? ntl : p.tile_end) - p.tile_begin;
+        if (ntl < 0) ntl = 0;
     } else {
         ntl = range < p.s_tiles ? (p.s_tiles - range + nranges - 1) / nranges : 0;
     }
     auto tile_row0 = [&](const int ti) -> int64_t {
-        return MODE == 0 ? begin + (int64_t)ti * GS_TILE : (int64_t)(range + ti * nranges) * p.s_stride;
+        return MODE == 0 ? begin + (int64_t)(p.tile_begin + ti) * GS_TILE : (int64_t)(range + ti * nranges) * p.s_stride;
     };
     if (MODE == 0 && tid == 0) { p.wg_stat[(size_t)blockIdx.x * 2] = 0u; p.wg_stat[(size_t)blockIdx.x * 2 + 1] = 0u; }
     if (ntl == 0) return;
@@ -93,10 +113,14 @@ gscan_kernel(const GScanParams p) {
     // fragment reads below conflict-free. Everything that selects a ROW is in the bounds-checked voffset: rows past the end of the range /
     // of the queries are not fetched (zeros land in LDS); the k-tile rides in the scalar offset.
     const uint32_t chb = (uint32_t)(((lane & 7) ^ (lane >> 3)) * 16);
-    const uint32_t vrow = (uint32_t)(wave * 32 + (lane >> 3)) * ROWB + chb;
+    const uint32_t vbase = (uint32_t)(lane >> 3) * ROWB + chb;
     int qrows = p.nq - col * GS_TILE;
     qrows = __builtin_amdgcn_readfirstlane(qrows < 0 ? 0 : (qrows > GS_TILE ? GS_TILE : qrows));     // (hipcc clamps with v_med3: back to an SGPR, or the descriptor lives in VGPRs)
-    auto stage = [&](const int buf, const int it) {
+    // A k-tile is 64 pieces of 8 rows x 128 B (32 of the slab, 32 of the queries), one wave instruction each. They are NOT split evenly: group
+    // A issues its pieces in its read phase, beside the partner's MFMAs (~95 cycles of the wave's time per piece, hidden), group B in front of
+    // its own MFMAs, where every piece is ~90 cycles of an idle matrix pipe -- so an A wave takes GS_PIECES_A = 11 (8 of the slab + 3 of the
+    // queries), a B wave 5 (queries): measured k-tile period 8 + 8: ... 11 + 5: ... (profiles/r04/gscan_phases.txt)
+    auto stage = [&](const int buf, const int it) __attribute__((always_inline)) {
         // (both descriptors are formed HERE, SGPR arithmetic: a descriptor carried across the k-loop ends up in VGPRs and every DMA in a
         //  readfirstlane loop)
         const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(p.q16 + (size_t)col * GS_TILE * D_FAST), 0, qrows * ROWB, 0x00020000);
@@ -106,12 +130,19 @@ gscan_kernel(const GScanParams p) {
         if (rem > GS_TILE) rem = GS_TILE;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.slab + (size_t)r0 * D_FAST), 0, (int)rem * ROWB, 0x00020000);
         const int kb = kt * 128;
+        const int w4 = wave & 3;
+        auto piece = [&](const __amdgpu_buffer_rsrc_t& rsrc, const int op, const int rg) __attribute__((always_inline)) {      // rows [8 rg, 8 rg + 8) of operand op
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(smem + op * 2 * GS_STG + buf * GS_STG + rg * 1024), 16, (int)(vbase + (uint32_t)(rg * 8 * ROWB)), kb, 0, 0);
+        };
+        if (!grpB) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(smem + buf * GS_STG + (wave * 32 + i * 8) * 128), 16, (int)(vrow + (uint32_t)(i * 8 * ROWB)), kb, 0, 0);
+            for (int j = 0; j < 8; ++j) piece(rs, 0, w4 + 4 * j);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_ptr)(smem + 2 * GS_STG + buf * GS_STG + (wave * 32 + i * 8) * 128), 16, (int)(vrow + (uint32_t)(i * 8 * ROWB)), kb, 0, 0);
+            for (int j = 0; j < GS_PIECES_A - 8; ++j) piece(rq, 1, w4 + 4 * j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16 - GS_PIECES_A; ++j) piece(rq, 1, 4 * (GS_PIECES_A - 8) + w4 + 4 * j);
+        }
     };
 
     // the lane's fragment chunks: slab rows wi * 128 + 16 a + lr (MFMA A operand), query rows wj * 64 + 16 b + lr (B operand); k-step 0 of a
@@ -131,9 +162,12 @@ gscan_kernel(const GScanParams p) {
     }
     uint2* wbuf = (uint2*)(smem + 4 * GS_STG) + wave * GS_WBUF_ENTRIES;
     uint32_t cnt = 0;                                   // entries in this wave's buffer (wave-uniform)
-    auto flush = [&]() {
+    auto flush = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the epilogue's ds_write_b64 are inline asm
+        const uint32_t nrows = (uint32_t)(end - begin);
         for (uint32_t i = (uint32_t)lane_now(); i < cnt; i += 64) {
             const uint2 e = wbuf[i];
+            if ((e.y & 0xffffffu) >= nrows) continue;           // a row past the end of the range (zeros of a partial last tile)
             const uint32_t qq = (uint32_t)(col * GS_TILE) + (e.y >> 24);
             const uint32_t gs = atomicAdd(&p.gcnt[qq], 1u);
             if (gs < (uint32_t)p.gcap) p.lists[(size_t)qq * p.gcap + gs] = make_uint2(e.x, (uint32_t)begin + (e.y & 0xffffffu));
@@ -148,47 +182,73 @@ gscan_kernel(const GScanParams p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto epilogue = [&](const int ti) {
+    auto epilogue = [&](const int ti) __attribute__((always_inline)) {
         if (MODE == 0) {
-            const int64_t r0 = tile_row0(ti);
-            const int valid = (int)(end - r0 > GS_TILE ? GS_TILE : end - r0);
-            // (everything lane-derived is formed HERE from a lane id hipcc cannot trace back: hoisted over the k-loop -- which runs at the
-            //  register cap: 128 accumulators + 96 fragment registers -- it would push fragments into scratch)
-            const int ln = lane_now(), lr_e = ln & 15, lg_e = ln >> 4;
-            const uint32_t rel0 = (uint32_t)(ti * GS_TILE + wi * 128 + lg_e * 4);     // row of acc[0][.][0], relative to `begin` (< 2^24)
-            const uint32_t qtag = (uint32_t)(wj * 64 + lr_e) << 24;
-            const int rin0 = wi * 128 + lg_e * 4;                                      // row of acc[0][.][0] inside the tile
-            if (cnt > GS_WBUF_ENTRIES / 2) flush();
-            // Passing scores take the buffer slots cnt, cnt + 1, ... in walk order (ballot prefix counts: no atomics, no barrier). A handful
-            // pass per tile and wave; the buffer has room for at least GS_WBUF_ENTRIES / 2 more. What does not fit (no usable threshold,
-            // mass ties: adversarial data) sends its query to the exact path, as a full list does.
-            uint32_t lost = 0;                          // bit b: an entry of query column b of this lane found no slot
+            // (1) which of the 32 fragments hold a passing score: 32 independent chains of two VALU + two compares that end in scalar bit
+            // arithmetic -- no branch (a chain that ends in a branch costs its whole latency, ~70 cycles per fragment, 32 times per tile)
+            uint32_t hit = 0;
+            GS_ESTAMP(0);
 #pragma unroll
             for (int a = 0; a < 8; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const f32x4 v = acc[a][b];
-                    const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                    if (__builtin_amdgcn_ballot_w64(m > th[b]) == 0ull) continue;
+                    float m;
+                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(v[0]), "v"(v[1]), "v"(v[2]));      // (fmaxf: two canonicalising v_max more)
+                    const uint64_t any = __builtin_amdgcn_ballot_w64(m > th[b]) | __builtin_amdgcn_ballot_w64(v[3] > th[b]);
+                    hit |= (any != 0ull ? 1u : 0u) << (a * 4 + b);
+                }
+            GS_ESTAMP(1);
+            if (hit != 0u) {
+                // (everything lane-derived is formed HERE from a lane id hipcc cannot trace back: hoisted over the k-loop -- which runs at the
+                //  register cap: 128 accumulators + 96 fragment registers -- it would push fragments into scratch)
+                const int ln = lane_now(), lr_e = ln & 15, lg_e = ln >> 4;
+                const uint32_t tag0 = ((uint32_t)(wj * 64 + lr_e) << 24) | (uint32_t)((p.tile_begin + ti) * GS_TILE + wi * 128 + lg_e * 4);   // (query << 24) | row relative to `begin` (< 2^24) of acc[0][0][0]
+                const uint32_t wb = lds0 + 4 * GS_STG + (uint32_t)wave * (GS_WBUF_ENTRIES * 8);
+                if (cnt > GS_WBUF_REAL / 2) flush();
+                // (2) passing scores take the buffer slots cnt, cnt + 1, ... in walk order (ballot prefix counts: no atomics, no barrier). A
+                // handful pass per tile and wave and the buffer has room for at least GS_WBUF_REAL / 2 more; slots are CLAMPED to the buffer,
+                // and a tile that brings more than fit (no usable threshold, mass ties: adversarial data) sends the wave's 64 queries to the
+                // exact path, as a full list does. Rows past the end of the range (zeros in a partial last tile) are dropped by the flush.
+                // The body is kept SMALL (the 32 copies are ~10 KB of code that stays in the instruction cache: a first version with per-entry
+                // capacity checks and out-of-line bodies took ~1 000 cycles per candidate, mostly instruction fetch).
+                // TAKEN BRANCHES are what this walk costs (~80 cycles each beside a partner wave that streams MFMAs; measured: 2.5k cycles for
+                // 32 skipped fragments, + 310 per hit fragment whose four `if (pass)` regions each ended in an execz branch): so one test per
+                // group of four fragments, then one per fragment, and NO branch inside a hit fragment -- every lane stores, the lanes
+                // without a passing score into a dummy slot of their own behind the real ones.
+                const uint32_t dummy = wb + (uint32_t)(GS_WBUF_REAL + ln) * 8u;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool pass = v[r] > th[b] && rin0 + a * 16 + r < valid;
-                        const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
-                        const uint32_t idx = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                        if (pass) {
-                            if (idx < GS_WBUF_ENTRIES)
-                                wbuf[idx] = make_uint2(f32_bits(v[r]), (qtag + ((uint32_t)(b * 16) << 24)) | (rel0 + (uint32_t)(a * 16 + r)));
-                            else lost |= 1u << b;
+                for (int a = 0; a < 8; ++a) {
+                    if ((hit & (0xfu << (a * 4))) == 0u) continue;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        if ((hit & (1u << (a * 4 + b))) == 0u) continue;
+                        const f32x4 v = acc[a][b];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool pass = v[r] > th[b];
+                            const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
+                            uint32_t idx = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                            idx = idx < GS_WBUF_REAL - 1 ? idx : GS_WBUF_REAL - 1;
+                            const unsigned long long e = (unsigned long long)f32_bits(v[r]) |
+                                                         ((unsigned long long)(tag0 + (((uint32_t)(b * 16) << 24) | (uint32_t)(a * 16 + r))) << 32);
+                            // (asm: behind an LDS-DMA it cannot prove disjoint hipcc puts s_waitcnt vmcnt(0) in front of every LDS store)
+                            asm volatile("ds_write_b64 %0, %1" :: "v"(pass ? wb + idx * 8u : dummy), "v"(e) : "memory");
+                            cnt += (uint32_t)__popcll(mask);
                         }
-                        cnt += (uint32_t)__popcll(mask);
                     }
                 }
-            if (cnt > GS_WBUF_ENTRIES) {
-                cnt = GS_WBUF_ENTRIES;
+                if (cnt > GS_WBUF_REAL) {               // entries were lost
+                    cnt = GS_WBUF_REAL;
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    if (lost & (1u << b)) p.qflag[col * GS_TILE + wj * 64 + b * 16 + lr_e] = 1u;
+                    for (int b = 0; b < 4; ++b) p.qflag[col * GS_TILE + wj * 64 + b * 16 + lr_e] = 1u;
+                }
             }
+            GS_ESTAMP(2);
+#if ATLAS_TUNING
+            if (p.dbg != nullptr && blockIdx.x == 0 && ti < 8 && lane_now() == 0)
+                p.dbg[(size_t)8 * GS_STAMP_ITERS * 8 + ((size_t)wave * 8 + ti) * 4 + 3] = ((unsigned long long)__popc(hit) << 32) | cnt;
+#endif
         } else {
             const int ts = range + ti * nranges;
             const size_t ldq = (size_t)p.ncol * GS_TILE;
@@ -204,10 +264,6 @@ gscan_kernel(const GScanParams p) {
                     if (lg_e == 0) p.smax[((size_t)ts * GS_FRAG_PER_TILE + wi * 8 + a) * ldq + (size_t)(col * GS_TILE + wj * 64 + b * 16 + lr_e)] = m;
                 }
         }
-#pragma unroll
-        for (int a = 0; a < 8; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     };
 
     // Phases are separated by s_barrier (all 8 waves); group A = waves 0-3, group B = waves 4-7 (wave w and w + 4 share a SIMD):
@@ -224,9 +280,17 @@ gscan_kernel(const GScanParams p) {
         __builtin_amdgcn_s_barrier();
     }
     int kt = 0, ti = 0;
+    bool skip_b1 = false;
+    // (measured and not kept: group B's DMA pieces issued BETWEEN its MFMAs, one per eight, in a group-specialised copy of the loop -- the
+    //  ~700 cycles they cost in a block in front of the MFMAs only moved into the MFMA block: 1 950 cycles either way)
 #pragma unroll 1
     for (int it = 0; it < total_it; ++it) {
         const int buf = it & 1;
+        GS_STAMP(0);
+        // A's pieces of k-tile it + 1 go out FIRST, in front of its reads: they come from HBM (~2k cycles to land) and A waits for them at the end
+        // of its multiply phase
+        if (!grpB && it + 1 < total_it) stage(buf ^ 1, it + 1);
+        __builtin_amdgcn_sched_barrier(0);
         gs_u4 fs0[8], fq0[4], fs1[8], fq1[4];
         {
             // (inline asm: hipcc's wait insertion would drain vmcnt(0) in front of any ds_read it sees behind an LDS-DMA it cannot prove disjoint)
@@ -246,33 +310,54 @@ gscan_kernel(const GScanParams p) {
                 : "v"(s0), "v"(q0), "v"(s1), "v"(q1)
                 : "memory");
         }
-        if (!grpB) { if (it + 1 < total_it) stage(buf ^ 1, it + 1); }     // after the reads: issued first, the DMA competes with them
-        else __builtin_amdgcn_s_waitcnt(0x0F70);       // B: its pieces of k-tile it + 1 (issued a phase ago) have landed
+        GS_STAMP(1);
+        if (grpB) __builtin_amdgcn_s_waitcnt(0x0F70);  // B: its pieces of k-tile it + 1 (issued a phase ago) have landed
+        GS_STAMP(2);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if (!skip_b1) __builtin_amdgcn_s_barrier();    // (group A took a tile's first barrier ahead of its epilogue: below)
+        skip_b1 = false;
         __builtin_amdgcn_sched_barrier(0);
+        GS_STAMP(3);
         if (grpB && it + 2 < total_it) stage(buf, it + 2);                 // into the buffer both groups have finished reading
+        GS_STAMP(4);
+        if (kt == 0) {                                 // a tile's first k-tile starts from C = 0 (an inline constant: no 128 v_mov per tile)
 #pragma unroll
-        for (int a = 0; a < 8; ++a)
+            for (int a = 0; a < 8; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fs0[a]), __builtin_bit_cast(f16x8, fq0[b]), acc[a][b], 0, 0, 0);
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fs0[a]), __builtin_bit_cast(f16x8, fq0[b]), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fs0[a]), __builtin_bit_cast(f16x8, fq0[b]), acc[a][b], 0, 0, 0);
+        }
 #pragma unroll
         for (int a = 0; a < 8; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b)
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fs1[a]), __builtin_bit_cast(f16x8, fq1[b]), acc[a][b], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        GS_STAMP(5);
         if (!grpB) __builtin_amdgcn_s_waitcnt(0x0F70); // A: its pieces of k-tile it + 1 have landed
+        GS_STAMP(6);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        GS_STAMP(7);
         if (++kt == GS_NK) {
+            // The epilogues of BOTH groups side by side: an epilogue is chains of dependent VALU / scalar work that one wave per SIMD runs at
+            // 10+ cycles per instruction; two waves per SIMD fill each other's gaps. No LDS hazard hangs on the barrier between a group's reads
+            // and its MFMAs (every buffer hand-over goes through the OTHER barrier, see above): it only keeps the groups in opposite phases. So
+            // group A takes the next tile's first one HERE, ahead of its epilogue -- it meets group B coming out of the tile's last MFMAs --
+            // and skips it in the next iteration; after the last tile it is the barrier that group B's phase 0 is owed.
+            if (!grpB) { __builtin_amdgcn_s_barrier(); skip_b1 = true; }
+            __builtin_amdgcn_sched_barrier(0);
             epilogue(ti);
             kt = 0;
             ++ti;
         }
     }
-    if (!grpB) __builtin_amdgcn_s_barrier();           // A matches B's extra barrier
     if (MODE == 0) flush();
 }
 
@@ -295,9 +380,12 @@ gprep_kernel(const void* __restrict__ q, const int q_dtype, const int q0, uint4*
 // from one 1024-bin histogram over [min, max] (any T with count(maxima >= T) >= k is valid: k DISTINCT rows score >= T - eps), then
 // prune_threshold(T, eps) (common.h). Fewer than k maxima: -inf.
 // ------------------------------------------------------------------------------------------
+// LIST mode (lists != nullptr, between the two scan launches of a pass): the same from the approximate scores of the candidates the first
+// launch left in lists[q] (all written: a kernel boundary lies in between) -- the k-th best of the first eighth of the slab prunes the rest
+// ~8 x harder than the sample's threshold; theta[q] = max(old, new), both are certified.
 __global__ void __launch_bounds__(256)
-gtheta_kernel(const float* __restrict__ smax, const int nmax, const int ldq, const uint16_t* __restrict__ q16, const int nq, const float pmax,
-              const int k, float* __restrict__ theta) {
+gtheta_kernel(const float* __restrict__ smax, int nmax, const int ldq, const uint16_t* __restrict__ q16, const int nq, const float pmax,
+              const int k, float* __restrict__ theta, const uint2* __restrict__ lists, const uint32_t* __restrict__ gcnt, const int gcap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // (all LDS is dynamic, GTHETA_LDS(nmax) bytes: the launch may ask for up to 133 KiB)
     double* s_ss = (double*)smem;                      // [4]
@@ -307,6 +395,12 @@ gtheta_kernel(const float* __restrict__ smax, const int nmax, const int ldq, con
     uint32_t* keys = hist + 1024;                      // [nmax]
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (q >= nq) { if (tid == 0) theta[q] = pos_inf(); return; }
+    const bool from_list = lists != nullptr;
+    if (from_list) {
+        const uint32_t n = gcnt[q];
+        nmax = (int)(n < (uint32_t)gcap ? n : (uint32_t)gcap);
+        if (nmax > GTHETA_MAXKEYS) nmax = GTHETA_MAXKEYS;       // (any subset of the candidates gives a valid threshold)
+    }
     double ss = 0.0;
     for (int i = tid; i < D_FAST; i += 256) { const double v = (double)(float)__builtin_bit_cast(_Float16, q16[(size_t)q * D_FAST + i]); ss += v * v; }
 #pragma unroll
@@ -317,7 +411,7 @@ gtheta_kernel(const float* __restrict__ smax, const int nmax, const int ldq, con
     __syncthreads();
     uint32_t kmin = 0xffffffffu, kmax = 0u;
     for (int i = tid; i < nmax; i += 256) {
-        const uint32_t key = f32_order_key(smax[(size_t)i * ldq + q]);
+        const uint32_t key = f32_order_key(from_list ? bits_f32(lists[(size_t)q * gcap + i].x) : smax[(size_t)i * ldq + q]);
         keys[i] = key;
         kmin = key < kmin ? key : kmin;
         kmax = key > kmax ? key : kmax;
@@ -332,7 +426,7 @@ gtheta_kernel(const float* __restrict__ smax, const int nmax, const int ldq, con
     __syncthreads();
     kmin = s_mm[0]; kmax = s_mm[1];
     const float eps = query_eps((float)(s_ss[0] + s_ss[1] + s_ss[2] + s_ss[3]) * 1.000001f, pmax);
-    if (nmax < k) { if (tid == 0) theta[q] = neg_inf(); return; }
+    if (nmax < k) { if (tid == 0 && !from_list) theta[q] = neg_inf(); return; }
     const uint32_t span = kmax - kmin;
     const int shift = span >= 1024u ? (32 - __builtin_clz(span)) - 10 : 0;      // (key - kmin) >> shift < 1024
     for (int i = tid; i < nmax; i += 256) atomicAdd(&hist[(keys[i] - kmin) >> shift], 1u);
@@ -358,7 +452,10 @@ gtheta_kernel(const float* __restrict__ smax, const int nmax, const int ldq, con
         }
     }
     __syncthreads();
-    if (tid == 0) theta[q] = prune_threshold(f32_from_order_key(s_bin), eps);
+    if (tid == 0) {
+        const float th = prune_threshold(f32_from_order_key(s_bin), eps);
+        theta[q] = from_list ? fmaxf(theta[q], th) : th;
+    }
 }
 
 }  // namespace atlas
