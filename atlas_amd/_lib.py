@@ -12,11 +12,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_SO = os.environ.get("ATLAS_HIP_SO") or os.path.join(HERE, "lib", "libatlas_hip.so")   # ATLAS_HIP_SO: A/B runs of two builds (dev)
 TUNE_SO = os.path.join(HERE, "lib", "libatlas_hip_tune.so")   # the -DATLAS_TUNING=1 build: lib(tuning=True), tools/ and configuration tests only
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 DT_F16, DT_F32, DT_BF16 = 0, 1, 2
 STATUS_HEADER = 8
 SCAN_TRUST_PMAX = 1          # ATLAS_SCAN_TRUST_PMAX
-ST_FLAGS, ST_PMAX_BITS, ST_N_FALLBACK, ST_N_CANDIDATES, ST_N_RESCORED, ST_MAXERR_BITS = 0, 1, 2, 3, 4, 5
+ST_FLAGS, ST_PMAX_BITS, ST_N_FALLBACK, ST_N_CANDIDATES, ST_N_RESCORED, ST_MAXERR_BITS, ST_PLAN = 0, 1, 2, 3, 4, 5, 6
+
+
+def decode_plan(word: int) -> dict:
+    """ATLAS_ST_PLAN -> the slab passes a search was made of (include/atlas_hip.h)"""
+    word = int(word) & 0xFFFFFFFF
+    return {"passes_64": word & 0xFF, "passes_96": (word >> 8) & 0xFF, "pairs_64": (word >> 16) & 0xF, "pairs_96": (word >> 20) & 0xF,
+            "gemm_passes": (word >> 24) & 0xFF}
 F_PMAX_VIOLATION, F_FALLBACK, F_EPS_VIOLATION = 1, 2, 4
 E_BADARG, E_WORKSPACE, E_UNSUPPORTED = -1, -2, -3
 D_FAST, K_FAST_MAX, K_EXACT_MAX = 768, 256, 2048

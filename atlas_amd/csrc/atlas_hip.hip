@@ -693,7 +693,7 @@ GPlan make_gplan(int64_t N, int nq, int cus) {
     g.off_q16 = o;    o += align_up((size_t)g.ldq * D_FAST * 2, 256);
     g.off_theta = o;  o += align_up((size_t)g.ldq * 4, 256);
     g.off_gcnt = o;   o += align_up((size_t)g.ldq * 4, 256);
-    g.off_wgstat = o; o += align_up((size_t)g.G * 8, 256);
+    g.off_wgstat = o; o += align_up((size_t)g.G * 8 * 2, 256);        // two scan launches per pass
     g.off_smax = o;   o += align_up((size_t)g.nmax * g.ldq * 4, 256);
     g.off_lists = o;  o += (size_t)g.ldq * g.gcap * 8;
     g.total = o;
@@ -848,7 +848,7 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
     }
     const bool pair_wide_ok = pair_ok && wide_ok && half >= QWIDE;
     bool gemm_ok[3] = {false, false, false};
-    if (B > QWIDE && trusted && scan_gemm_enabled()) {
+    if (B > QWIDE && scan_variant_index() == 0 && scan_gemm_enabled()) {
         for (int i = 0; i < 3; ++i) {
             const GPlan g = make_gplan(N, GS_TILE << i, device_cus());
             gemm_ok[i] = g.ok && ws_bytes >= g.total;
@@ -884,6 +884,9 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
         }
     }
     const ScanVariant& wide = trusted ? kWideTrusted : kWide;
+    int plan_word = 0;
+    for (const Pass& ps : passes)
+        plan_word += ps.gemm ? (1 << 24) : ps.nq2 > 0 ? (ps.wide ? (1 << 20) : (1 << 16)) : (ps.wide ? (1 << 8) : 1);
 
     auto merge = merge_rescore_kernel<MERGE_NT>;
     allow_lds(var.kern);
@@ -901,7 +904,7 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
             // GEMM-shaped pass: queries -> fp16 rows, sample launch -> fragment maxima, thresholds, scan launch, merge (flat lists)
             const GPlan g = make_gplan(N, nq, device_cus());
             auto gsample = gscan_kernel<1>;
-            auto gscan = gscan_kernel<0>;
+            auto gscan = trusted ? gscan_kernel<0> : gscan_kernel<2>;          // <2>: the twin that measures every row norm
             allow_lds(gsample); allow_lds(gscan); allow_lds(gtheta_kernel);
             uint16_t* q16 = (uint16_t*)(w + g.off_q16);
             uint32_t* gcnt = (uint32_t*)(w + g.off_gcnt);
@@ -910,7 +913,7 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
             gs.slab = (const uint16_t*)slab_f16; gs.N = N; gs.q16 = q16; gs.nq = nq; gs.ncol = g.ncol; gs.rows_per_range = g.rows_per_range;
             gs.s_tiles = g.s_tiles; gs.s_stride = g.s_stride; gs.theta = (const float*)(w + g.off_theta); gs.smax = (float*)(w + g.off_smax);
             gs.lists = (uint2*)(w + g.off_lists); gs.gcnt = gcnt; gs.qflag = (uint32_t*)(w + GS_OFF_QFLAG); gs.gcap = g.gcap;
-            gs.wg_stat = (uint32_t*)(w + g.off_wgstat);
+            gs.wg_stat = (uint32_t*)(w + g.off_wgstat); gs.pmax2_hint = pmax_hint * pmax_hint;
             gs.dbg = g_scan_dbg;
             hipLaunchKernelGGL(gsample, dim3(g.G), dim3(512), GS_LDS_BYTES, stream, gs);
             hipLaunchKernelGGL(gtheta_kernel, dim3(g.ldq), dim3(256), GTHETA_LDS(g.nmax), stream, (const float*)gs.smax, g.nmax, g.ldq, (const uint16_t*)q16, nq,
@@ -926,21 +929,21 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
             if (t1 < tiles_per_range) {
                 hipLaunchKernelGGL(gtheta_kernel, dim3(g.ldq), dim3(256), GTHETA_LDS(GTHETA_MAXKEYS), stream, (const float*)gs.smax, g.nmax, g.ldq, (const uint16_t*)q16, nq,
                                    pmax_hint, k, (float*)(w + g.off_theta), (const uint2*)gs.lists, (const uint32_t*)gcnt, g.gcap);
-                gs.tile_begin = t1; gs.tile_end = tiles_per_range;
+                gs.tile_begin = t1; gs.tile_end = tiles_per_range; gs.wg_stat += (size_t)g.G * 2;      // (one word pair per workgroup and launch)
                 hipLaunchKernelGGL(gscan, dim3(g.G), dim3(512), GS_LDS_BYTES, stream, gs);
             }
             if (q0 == 0 && ev_scan_end) (void)hipEventRecord((hipEvent_t)ev_scan_end, stream);
             MergeParams mp{};
             mp.slab = (const uint16_t*)slab_f16; mp.N = N; mp.d = d;
-            mp.q = q16; mp.q_dtype = ATLAS_DT_F16; mp.qbase = 0; mp.pmax = pmax_hint; mp.pmax_trusted = 1;
-            mp.lists = gs.lists; mp.list_cnt = nullptr; mp.wg_stat = gs.wg_stat; mp.G = 1024; mp.cap = g.gcap / 1024;
-            mp.flat_cnt = gcnt; mp.nstat = g.G;
+            mp.q = q16; mp.q_dtype = ATLAS_DT_F16; mp.qbase = 0; mp.pmax = pmax_hint; mp.pmax_trusted = trusted ? 1 : 0;
+            mp.lists = gs.lists; mp.list_cnt = nullptr; mp.wg_stat = (uint32_t*)(w + g.off_wgstat); mp.G = 1024; mp.cap = g.gcap / 1024;
+            mp.flat_cnt = gcnt; mp.nstat = (t1 < tiles_per_range ? 2 : 1) * g.G;
             mp.total_cap = g.gcap; mp.epoch = (uint32_t*)(w + single.off_epoch); mp.ticket = (uint32_t*)(w + single.off_epoch + 128);
             mp.qflag = gs.qflag; mp.k = k; mp.q0 = q0; mp.key_cap = single.key_cap;
             mp.dbg = g_merge_dbg;
             mp.out_score = (uint16_t*)out_score_f16; mp.out_idx = out_idx; mp.out_status = out_status;
             mp.out_packed = out_packed; mp.id_mul = id_mul; mp.id_add = id_add;
-            mp.nq1 = nq; mp.nq2 = 0; mp.pair_state = PAIR_STATE; mp.pair_bulk = 0;
+            mp.nq1 = nq; mp.nq2 = 0; mp.pair_state = PAIR_STATE; mp.pair_bulk = 0; mp.plan_word = plan_word;
             hipLaunchKernelGGL(merge, dim3(nq, 1), dim3(MERGE_NT), single.merge_lds, stream, mp);
             continue;
         }
@@ -991,7 +994,7 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
         mp.dbg = g_merge_dbg;
         mp.out_score = (uint16_t*)out_score_f16; mp.out_idx = out_idx; mp.out_status = out_status;
         mp.out_packed = out_packed; mp.id_mul = id_mul; mp.id_add = id_add;
-        mp.nq1 = nq; mp.nq2 = nq2; mp.pair_state = PAIR_STATE; mp.pair_bulk = pl.bulk_size;
+        mp.nq1 = nq; mp.nq2 = nq2; mp.pair_state = PAIR_STATE; mp.pair_bulk = pl.bulk_size; mp.plan_word = plan_word;
 #if ATLAS_TUNING
         // experiment (scan_kernel.h, ScanParams::fused): the merge inside the scan's last nq workgroups
         const bool fused = !paired && !is_wide && coop && var.nw * 64 == MERGE_NT && pl.G >= nq && pl.merge_lds <= pl.scan_lds && scan_fused_enabled();

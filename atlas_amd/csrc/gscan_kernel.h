@@ -54,16 +54,17 @@ struct GScanParams {
     uint32_t* gcnt;           // SCAN: [nq] entries appended to lists[q] (may exceed gcap: the query is then flagged)
     uint32_t* qflag;          // SCAN: [nq] fallback flags (plain idempotent stores)
     int gcap;
-    uint32_t* wg_stat;        // SCAN: [gridDim.x][2] {largest row norm^2 seen (0: this kernel does not measure), ATLAS_F_* flags}
+    uint32_t* wg_stat;        // SCAN: [gridDim.x][2] {largest row norm^2 seen (MODE 2; 0 otherwise), ATLAS_F_* flags} of THIS launch
+    float pmax2_hint;         // MODE 2: the square of the caller's pmax hint
     unsigned long long* dbg;  // tuning build only (atlas_tune_set_scan_stamps): shader-clock stamps of workgroup 0, [8 waves][GS_STAMP_ITERS][8]; null in production
 };
 #define GS_STAMP_FIRST 24         // the stamped iterations: k-tiles 24 .. 55 of the workgroup (its third to fifth tile)
 #define GS_STAMP_ITERS 32
 #if ATLAS_TUNING
-#define GS_STAMP(i) do { if (MODE == 0 && p.dbg != nullptr && blockIdx.x == 0 && it >= GS_STAMP_FIRST && it < GS_STAMP_FIRST + GS_STAMP_ITERS && lane_now() == 0) \
+#define GS_STAMP(i) do { if (MODE != 1 && p.dbg != nullptr && blockIdx.x == 0 && it >= GS_STAMP_FIRST && it < GS_STAMP_FIRST + GS_STAMP_ITERS && lane_now() == 0) \
         p.dbg[((size_t)wave * GS_STAMP_ITERS + (it - GS_STAMP_FIRST)) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 // epilogue stamps: [8 waves][8 tiles][4] behind the k-loop stamps
-#define GS_ESTAMP(i) do { if (MODE == 0 && p.dbg != nullptr && blockIdx.x == 0 && ti < 8 && lane_now() == 0) \
+#define GS_ESTAMP(i) do { if (MODE != 1 && p.dbg != nullptr && blockIdx.x == 0 && ti < 8 && lane_now() == 0) \
         p.dbg[(size_t)8 * GS_STAMP_ITERS * 8 + ((size_t)wave * 8 + ti) * 4 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define GS_STAMP(i) do { } while (0)
@@ -72,7 +73,9 @@ struct GScanParams {
 
 typedef unsigned int gs_u4 __attribute__((ext_vector_type(4)));
 
-// MODE 0 = scan (filter epilogue), 1 = sample (fragment maxima)
+// MODE 0 = scan (filter epilogue), 1 = sample (fragment maxima), 2 = scan that also MEASURES every row's norm (the certifying twin: the caller's
+// pmax is a hint, atlas_scan_topk's default contract). The four waves that share a slab fragment row split its eight fragments: 16 v_dot2
+// per k-tile and wave beside its 64 MFMAs.
 template <int MODE>
 __global__ void __launch_bounds__(512)
 gscan_kernel(const GScanParams p) {
@@ -84,6 +87,7 @@ gscan_kernel(const GScanParams p) {
     const bool grpB = wave >= 4;
     const int lr = lane & 15, lg = lane >> 4;
     constexpr int ROWB = D_FAST * 2;
+    constexpr bool SCAN = MODE != 1, CERT = MODE == 2;
 
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
     const int col = slot % p.ncol;
@@ -91,7 +95,7 @@ gscan_kernel(const GScanParams p) {
     const int range = xcd * per_xcd + slot / p.ncol, nranges = 8 * per_xcd;
     int64_t begin = 0, end = 0;
     int ntl;
-    if (MODE == 0) {
+    if (SCAN) {
         begin = (int64_t)range * p.rows_per_range;
         end = begin + p.rows_per_range;
         if (end > p.N) end = p.N;
@@ -102,9 +106,9 @@ gscan_kernel(const GScanParams p) {
         ntl = range < p.s_tiles ? (p.s_tiles - range + nranges - 1) / nranges : 0;
     }
     auto tile_row0 = [&](const int ti) -> int64_t {
-        return MODE == 0 ? begin + (int64_t)(p.tile_begin + ti) * GS_TILE : (int64_t)(range + ti * nranges) * p.s_stride;
+        return SCAN ? begin + (int64_t)(p.tile_begin + ti) * GS_TILE : (int64_t)(range + ti * nranges) * p.s_stride;
     };
-    if (MODE == 0 && tid == 0) { p.wg_stat[(size_t)blockIdx.x * 2] = 0u; p.wg_stat[(size_t)blockIdx.x * 2 + 1] = 0u; }
+    if (SCAN && tid == 0) { p.wg_stat[(size_t)blockIdx.x * 2] = 0u; p.wg_stat[(size_t)blockIdx.x * 2 + 1] = 0u; }
     if (ntl == 0) return;
     const int total_it = ntl * GS_NK;
 
@@ -126,7 +130,7 @@ gscan_kernel(const GScanParams p) {
         const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(p.q16 + (size_t)col * GS_TILE * D_FAST), 0, qrows * ROWB, 0x00020000);
         const int ti = it / GS_NK, kt = it - ti * GS_NK;
         const int64_t r0 = tile_row0(ti);
-        int64_t rem = (MODE == 0 ? end : p.N) - r0;
+        int64_t rem = (SCAN ? end : p.N) - r0;
         if (rem > GS_TILE) rem = GS_TILE;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.slab + (size_t)r0 * D_FAST), 0, (int)rem * ROWB, 0x00020000);
         const int kb = kt * 128;
@@ -156,7 +160,7 @@ gscan_kernel(const GScanParams p) {
     // C layout of v_mfma_f32_16x16x32_f16: lane l holds query column l & 15 and slab rows 4 (l >> 4) + r of the 16 x 16 block: the lane
     // OWNS its queries, the thresholds are four per-lane scalars for the whole kernel
     float th[4];
-    if (MODE == 0) {
+    if (SCAN) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) th[b] = p.theta[col * GS_TILE + wj * 64 + b * 16 + lr];
     }
@@ -183,7 +187,7 @@ gscan_kernel(const GScanParams p) {
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto epilogue = [&](const int ti) __attribute__((always_inline)) {
-        if (MODE == 0) {
+        if (SCAN) {
             // (1) which of the 32 fragments hold a passing score: 32 independent chains of two VALU + two compares that end in scalar bit
             // arithmetic -- no branch (a chain that ends in a branch costs its whole latency, ~70 cycles per fragment, 32 times per tile)
             uint32_t hit = 0;
@@ -281,6 +285,7 @@ gscan_kernel(const GScanParams p) {
     }
     int kt = 0, ti = 0;
     bool skip_b1 = false;
+    float nrm0 = 0.f, nrm1 = 0.f, pm = 0.f;          // MODE 2: running sums of squares of two slab rows' elements, largest row sum seen
     // (measured and not kept: group B's DMA pieces issued BETWEEN its MFMAs, one per eight, in a group-specialised copy of the loop -- the
     //  ~700 cycles they cost in a block in front of the MFMAs only moved into the MFMA block: 1 950 cycles either way)
 #pragma unroll 1
@@ -338,6 +343,19 @@ gscan_kernel(const GScanParams p) {
 #pragma unroll
             for (int b = 0; b < 4; ++b)
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fs1[a]), __builtin_bit_cast(f16x8, fq1[b]), acc[a][b], 0, 0, 0);
+        if (CERT) {
+            // row sums of squares: this wave's two of the eight fragments of its slab rows (the lane holds 8 + 8 of a row's 64 elements of this k-tile)
+            auto sq = [](const gs_u4& f, float acc2) {
+                const uint32_t w[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const f16x2 h = __builtin_bit_cast(f16x2, w[i]); acc2 = __builtin_amdgcn_fdot2(h, h, acc2, false); }
+                return acc2;
+            };
+            if (wj == 0) { nrm0 = sq(fs1[0], sq(fs0[0], nrm0)); nrm1 = sq(fs1[1], sq(fs0[1], nrm1)); }
+            else if (wj == 1) { nrm0 = sq(fs1[2], sq(fs0[2], nrm0)); nrm1 = sq(fs1[3], sq(fs0[3], nrm1)); }
+            else if (wj == 2) { nrm0 = sq(fs1[4], sq(fs0[4], nrm0)); nrm1 = sq(fs1[5], sq(fs0[5], nrm1)); }
+            else { nrm0 = sq(fs1[6], sq(fs0[6], nrm0)); nrm1 = sq(fs1[7], sq(fs0[7], nrm1)); }
+        }
         __builtin_amdgcn_sched_barrier(0);
         GS_STAMP(5);
         if (!grpB) __builtin_amdgcn_s_waitcnt(0x0F70); // A: its pieces of k-tile it + 1 have landed
@@ -353,12 +371,35 @@ gscan_kernel(const GScanParams p) {
             // and skips it in the next iteration; after the last tile it is the barrier that group B's phase 0 is owed.
             if (!grpB) { __builtin_amdgcn_s_barrier(); skip_b1 = true; }
             __builtin_amdgcn_sched_barrier(0);
+            if (CERT) {                                // full row norms: the 4 lanes {l, l + 16, l + 32, l + 48} hold the 4 chunks of row l & 15
+                float x = nrm0, y = nrm1;
+                x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
+                y += __shfl_xor(y, 16); y += __shfl_xor(y, 32);
+                pm = fmaxf(pm, fmaxf(x, y));
+                nrm0 = 0.f; nrm1 = 0.f;
+            }
             epilogue(ti);
             kt = 0;
             ++ti;
         }
     }
-    if (MODE == 0) flush();
+    if (SCAN) flush();
+    if (CERT) {
+        // largest row norm^2 of the workgroup (x 1.001: v_dot2 accumulates in fp32): waves -> LDS -> one word pair, as scan_kernel.h leaves it
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pm = fmaxf(pm, __shfl_xor(pm, o));
+        float* s_pm = (float*)(smem + 4 * GS_STG);      // (the wave buffers are empty now)
+        __syncthreads();
+        if (lane == 0) s_pm[wave] = pm;
+        __syncthreads();
+        if (tid == 0) {
+            float m = 0.f;
+            for (int w = 0; w < 8; ++w) m = fmaxf(m, s_pm[w]);
+            m *= 1.001f;
+            p.wg_stat[(size_t)blockIdx.x * 2 + 0] = f32_bits(m);
+            p.wg_stat[(size_t)blockIdx.x * 2 + 1] = (m > p.pmax2_hint) ? (uint32_t)ATLAS_F_PMAX_VIOLATION : 0u;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -57,6 +57,7 @@ struct MergeParams {
     // wg_stat (the scan's workgroups); 0 = G.
     const uint32_t* flat_cnt;
     int nstat;
+    int plan_word;               // ATLAS_ST_PLAN of the call (the same in every pass), written by block 0
 };
 
 // Canonical exact score (common.h exact_dot_f16) computed by ONE WAVE: lane j is chain j and adds the
@@ -166,7 +167,7 @@ static __device__ __forceinline__ void merge_rescore_body(const MergeParams& p, 
     if (tid == 0) {                      // per-call state kept in the workspace is put back for the next call here: this block is the only
         flagged = p.qflag[q];            // reader of its query's flag, and every scan workgroup has finished
         p.qflag[q] = 0u;
-        if (q == 0) { *p.epoch = *p.epoch + 1u; *p.ticket = 0u; }
+        if (q == 0) { *p.epoch = *p.epoch + 1u; *p.ticket = 0u; p.out_status[ATLAS_ST_PLAN] = p.plan_word; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += shfl_xor_n(ss, o);

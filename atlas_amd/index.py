@@ -410,6 +410,7 @@ class HipDistributedIndex(object):
             "path": "scan", "reruns": reruns, "fallback_queries": n_fb, "pmax": self._pmax, "pmax_trusted": bool(call_flags & _lib.SCAN_TRUST_PMAX),
             "candidates": int(st[_lib.ST_N_CANDIDATES]), "rescored": int(st[_lib.ST_N_RESCORED]),
             "max_err_over_eps": float(st[_lib.ST_MAXERR_BITS : _lib.ST_MAXERR_BITS + 1].view(np.float32)[0]),
+            "plan": _lib.decode_plan(st[_lib.ST_PLAN]),
         }
         return scores, rows, h_scores, h_rows
 

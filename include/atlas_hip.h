@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ATLAS_ABI_VERSION 8
+#define ATLAS_ABI_VERSION 9
 
 #define ATLAS_WS_STATE_BYTES (2u << 20)   /* head of a scan workspace that must be zero before the workspace's first use */
 
@@ -60,6 +60,9 @@ extern "C" {
 #define ATLAS_ST_N_CANDIDATES    3   /* total candidates that reached the merge (diagnostic)    */
 #define ATLAS_ST_N_RESCORED      4   /* total exact rescorings done in the merge (diagnostic)   */
 #define ATLAS_ST_MAXERR_BITS     5   /* float bits: max |approx-exact| / eps over rescored rows */
+#define ATLAS_ST_PLAN            6   /* the slab passes the call was made of (diagnostic): bits 0-7 single 64-query passes, 8-15 single
+                                        96-query passes, 16-19 pairs of 64-query passes, 20-23 pairs of 96-query passes, 24-31 GEMM-shaped
+                                        passes (<= 256 / 512 / 1024 queries each; batches above 96 queries) */
 /* flags */
 #define ATLAS_F_PMAX_VIOLATION   1   /* a row norm exceeded pmax_hint: results NOT certified;
                                         re-run with pmax_hint >= out_status[ATLAS_ST_PMAX_BITS] */
@@ -100,12 +103,16 @@ const char* atlas_build_info(void);          /* "gfx950 <compile date> ..." */
  *
  * Fast path requires d == 768 (EMBEDDINGS_DIM, src/retrievers.py:13) and k <= 256;
  * otherwise returns ATLAS_E_UNSUPPORTED (callers then use atlas_exact_topk).
- * Any B >= 1 is accepted: up to 64 queries are one slab pass; a larger batch is a sequence of 64- and 96-query passes chosen by cost
- * (a 96-query pass -- 147 KiB query image, 6 MFMAs per 16-byte slab load -- takes ~1.11 of a 64-query pass), single or PAIRED: two passes
- * scanning concurrently on half the chip each, the second reader of a slab row served by the cache (a pair of 64-query passes costs 1.62,
- * a pair of 96-query passes 1.89 of one 64-query pass): 96 -> one pass, 128 -> a pair of 64, 192 -> a pair of 96, 512 -> two pairs of 96 +
- * a pair of 64; small shards keep 64-query passes. The workspace size depends on B > 64: a workspace sized for a larger batch serves
- * every smaller one; the state words at its head do not move with B.
+ * Any B >= 1 is accepted: up to 64 queries are one slab pass; a larger batch is a sequence of passes chosen by measured cost
+ * (ATLAS_ST_PLAN reports it). Up to 96 queries the slab BYTES are the bound and the passes stream (a 96-query pass -- 147 KiB query image,
+ * 6 MFMAs per 16-byte slab load -- takes ~1.11 of a 64-query pass). Above 96 queries the matrix pipe is the bound and the passes are
+ * GEMM-shaped (csrc/gscan_kernel.h; shards of >= 65 536 rows): 256 slab rows x 256 queries per workgroup tile, both operands staged through
+ * LDS, up to 256 / 512 / 1024 queries per pass for ONE slab read from HBM (the workgroups that score the same rows against different query
+ * tiles share them through the L2); a sample launch gives every query its first threshold, a second launch runs with thresholds tightened
+ * by the candidates of the first eighth of the slab. Costs in units of a 64-query pass: 1.56 (<= 256 queries), 2.86 (<= 512), 5.4
+ * (<= 1024); 512 queries on a 4M-row shard: 3.0 ms against 5.7 ms for round 3's streaming passes (paired 64- / 96-query passes, which
+ * remain for small shards). The workspace size depends on B: a workspace sized for a larger batch serves every smaller one; the state
+ * words at its head do not move with B.
  *
  * One 64-query pass is two launches: the scan (which converts the queries itself, takes its initial pruning thresholds
  * from its own first tiles -- the workgroups exchange 8-byte granules inside the kernel; every wait is bounded, a value

@@ -32,7 +32,7 @@ def test_header_symbols_exported(so):
 def test_abi_version_and_bad_args(so):
     L = ctypes.CDLL(so)
     L.atlas_abi_version.restype = ctypes.c_int
-    assert L.atlas_abi_version() == 8
+    assert L.atlas_abi_version() == 9
     L.atlas_build_info.restype = ctypes.c_char_p
     assert b"gfx950" in L.atlas_build_info()
     # argument validation happens before any HIP call

@@ -54,8 +54,9 @@ def test_scan_bit_exact_vs_oracle(N, B, k, ps, gpu_index_cls, oracle_mod):
 @pytest.mark.parametrize("N,B,k,ps", [(100000, 96, 40, 301), (100000, 97, 40, 302), (100000, 160, 40, 303), (120000, 192, 40, 304),
                                      (100000, 200, 100, 305), (70000, 512, 40, 306), (70000, 80, 256, 307), (40000, 300, 40, 308)])
 def test_batches_above_64_queries_bit_exact_vs_oracle(N, B, k, ps, gpu_index_cls, oracle_mod):
-    """a rank of an N-GPU search scores ALL gathered queries (index.py:127-131): batches above 64 run as a mix of 64- and 96-query slab
-    passes (96 + 1, 64 + 96, 96 + 96, 96 + 96 + 8, 5 x 96 + 32, one pass of 80; the 40k-row shard is too small for the wide pass)"""
+    """a rank of an N-GPU search scores ALL gathered queries (index.py:127-131): one 96-query pass up to 96 queries, GEMM-shaped passes
+    (csrc/gscan_kernel.h) above that on shards of >= 65 536 rows (97 -> one 256-query tile, 512 -> two column tiles, ...), round 3's 64- /
+    96-query passes on the 40k-row shard"""
     P = synth.passages_f16(N, 768, ps)
     Q = synth.queries_f32(B, 768, ps + 1)
     idx = _index(gpu_index_cls, P)
@@ -72,6 +73,45 @@ def test_batches_above_64_queries_bit_exact_vs_oracle(N, B, k, ps, gpu_index_cls
     s2, i2 = _search(idx2, Q[:B], k)
     es2, ei2 = oracle_mod.search(oracle_mod.f32_to_f16(Q), P2, k)
     parity.assert_identical(s2, i2, es2, ei2, f"duplicated halves, N={N} B={B} k={k}")
+
+
+@pytest.mark.parametrize("N,B,k,ps,certify", [(150000, 128, 40, 321, 0), (100000, 256, 100, 322, 0), (70000, 512, 256, 323, 0), (66000, 300, 40, 324, 0),
+                                             (150000, 128, 100, 325, 1), (100000, 384, 40, 326, 1), (70000, 512, 256, 327, 1)])
+def test_gemm_shaped_passes_bit_exact_vs_oracle(N, B, k, ps, certify, gpu_index_cls, oracle_mod):
+    """batches above 96 queries on the GEMM-shaped passes (one / two column tiles of 256 queries, partial tiles, the tail range shorter than
+    the others, k = 40 / 100 / 256), the twin that trusts pmax and the one that measures every row norm (certify_every = 1: the C-ABI's
+    default mode) -- and the same shard with duplicated halves (every score twice: twice the candidates, ties across the cut)"""
+    P = synth.passages_f16(N, 768, ps)
+    Q = synth.queries_f32(B, 768, ps + 1)
+    for dup in (False, True):
+        Pd = np.concatenate([P[: N // 2], P[: N // 2]]) if dup else P
+        idx = gpu_index_cls(certify_every=1) if certify else gpu_index_cls()
+        idx.init_embeddings([{"id": str(i)} for i in range(N)], 768)
+        idx.embeddings[:, :] = torch.from_numpy(Pd).cuda().T
+        s, i = _search(idx, Q, k)
+        es, ei = oracle_mod.search(oracle_mod.f32_to_f16(Q), Pd, k)
+        parity.assert_identical(s, i, es, ei, f"N={N} B={B} k={k} certify={certify} dup={dup}")
+        st = idx.last_search_stats
+        assert st["path"] == "scan" and st["plan"]["gemm_passes"] >= 1 and st["pmax_trusted"] is (not certify), st
+        assert st["max_err_over_eps"] < 0.25 and (k > 128 or st["fallback_queries"] == 0), st
+
+
+def test_gemm_shaped_pass_finds_a_row_that_violates_the_hint(gpu_index_cls, oracle_mod):
+    """the certifying twin of the GEMM-shaped pass measures every row: a 9 x row raises ATLAS_F_PMAX_VIOLATION, the search is repeated
+    with the measured bound (the C-ABI contract of atlas_scan_topk), same canonical result"""
+    N, B, k = 120000, 200, 40
+    P = synth.passages_f16(N, 768, 331)
+    Q = synth.queries_f32(B, 768, 332)
+    P[100001] = (P[100001].astype(np.float32) * 9.0).astype(np.float16)
+    idx = gpu_index_cls(certify_every=1)
+    idx.init_embeddings([{"id": str(i)} for i in range(N)], 768)
+    idx.embeddings[:, :] = torch.from_numpy(P).cuda().T
+    idx._pmax, idx._pmax_version = 1.002, idx._slab_version()        # a stale hint: what a caller of the C-ABI without a certificate passes
+    s, i = _search(idx, Q, k)
+    es, ei = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, k)
+    parity.assert_identical(s, i, es, ei, "a 9 x row, GEMM-shaped certifying pass")
+    st = idx.last_search_stats
+    assert st["reruns"] == 1 and st["plan"]["gemm_passes"] >= 1 and st["pmax"] > 8.0, st
 
 
 def test_wide_passes_of_the_certifying_twin(gpu_index_cls, oracle_mod):
