@@ -34,6 +34,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); measured-achievable copy rate is 6290
+MFMA_PEAK_TFLOPS = 2500.0  # dense f16 MFMA peak (same guide)
 D = 768
 
 
@@ -100,9 +101,14 @@ def main():
     ap.add_argument("--refresh-batches", type=int, default=30, help="timed 512-passage encoder batches for the index-refresh leg (0 = skip)")
     ap.add_argument("--refresh-len", type=int, default=128, help="tokens per passage in the refresh leg")
     ap.add_argument("--refresh-stream-seconds", type=float, default=15.0, help="sustained streamed-refresh leg from the token store, with rocm-smi power / clock samples (0 = skip)")
-    ap.add_argument("--batch-sweep", type=str, default="64,96,128,192,256,512", help="query-batch sizes timed on the 4M-row prefix (a rank of an N-GPU search scores ALL gathered queries; N=1 only; '' = skip)")
+    ap.add_argument("--batch-sweep", type=str, default="64,96,128,192,256,384,512,1024", help="query-batch sizes timed on the 4M-row prefix (a rank of an N-GPU search scores ALL gathered queries; N=1 only; '' = skip)")
     ap.add_argument("--shard-sweep", type=str, default="1000000,4000000,8000000,16000000",
                     help="prefix sizes of the slab timed like the headline: configs[1] and the per-GPU shards of an 8 / 4 / 2-GPU run (N=1 only; '' = skip)")
+    ap.add_argument("--api-rows-max", type=int, default=4_000_000, help="shard_sweep entries up to this size also time the synchronous product calls "
+                                                                        "(search_knn through a real dict doc_map of that many passages)")
+    ap.add_argument("--distinct-queries", action="store_true",
+                    help="N > 1: every rank brings its OWN --queries queries (the reference's distributed search_knn, src/index.py:127-151): the step is "
+                         "all-gather of the queries -> scan of the shard for all N x B of them -> all-gather of the packed winners -> W x k -> k merge")
     ap.add_argument("--exchange", choices=("rccl", "peer"), default="rccl",
                     help="N > 1: how the ranks' packed winners meet -- one RCCL all-gather + merge (default), or the peer-mapped exchange buffers "
                          "(atlas_xchg_*: push kernel + waiting merge kernel, no collective; experimental, never run across two devices)")
@@ -129,10 +135,24 @@ def main():
     from atlas_amd import HipDistributedIndex, _lib
 
     L = _lib.lib()
-    B, k = args.queries, args.topk
+    k = args.topk
+    distinct = bool(args.distinct_queries) and world > 1
+    Bq = args.queries                                          # queries a rank brings
+    B = Bq * world if distinct else Bq                         # queries a rank SCORES per step (the reference scores all gathered ones)
     rows = len(range(rank, args.passages, world))            # round-robin shard (src/index_io.py:41)
     slab = make_shard(rows, 1234 + rank, dev)
-    q = torch.randn((B, D), generator=torch.Generator(device=dev).manual_seed(99), device=dev)   # same on every rank
+    if distinct:                                               # rank r's own queries; the step gathers them (fp16: what the scan scores, index.py:117)
+        q_own = torch.randn((Bq, D), generator=torch.Generator(device=dev).manual_seed(99 + rank), device=dev).half()
+        q = torch.empty((B, D), dtype=torch.float16, device=dev)
+        if backend == "nccl":
+            dist.all_gather_into_tensor(q, q_own)
+        else:
+            hq = torch.empty((B, D), dtype=torch.float16)
+            dist.all_gather_into_tensor(hq, q_own.cpu())
+            q.copy_(hq)
+    else:
+        q = torch.randn((B, D), generator=torch.Generator(device=dev).manual_seed(99), device=dev)   # same on every rank
+    q_code = _lib.torch_dtype_code(q.dtype)
     index = HipDistributedIndex()
     index._set_slab(slab)
 
@@ -177,7 +197,14 @@ def main():
         # written to the slab since, so the scan takes it as certified (ATLAS_SCAN_TRUST_PMAX) instead of re-measuring every row's norm
         # (N > 1: the merge kernel emits the packed (score, global id) pairs itself -- global id = row * world + rank -- so the scan is followed
         #  by the all-gather directly)
-        rc = L.atlas_scan_topk_pack(q.data_ptr(), _lib.DT_F32, slab.data_ptr(), rows, B, D, k, pmax, out_s.data_ptr(),
+        if distinct:                                                    # the query all-gather of src/index.py:127 (Bq x 1536 B per rank)
+            if backend == "nccl":
+                dist.all_gather_into_tensor(q, q_own)
+            else:
+                hq_ = torch.empty((B, D), dtype=torch.float16)
+                dist.all_gather_into_tensor(hq_, q_own.cpu())
+                q.copy_(hq_)
+        rc = L.atlas_scan_topk_pack(q.data_ptr(), q_code, slab.data_ptr(), rows, B, D, k, pmax, out_s.data_ptr(),
                                     out_i.data_ptr(), out_st.data_ptr(), ws.data_ptr(), ws.numel(), stream, eb, ee, _lib.SCAN_TRUST_PMAX,
                                     world, rank, packed.data_ptr() if world > 1 else None)
         assert rc == 0, rc
@@ -233,6 +260,31 @@ def main():
         want = merge_packed_host(gathered.view(world, B, k).cpu().numpy(), k)
         assert np.array_equal(merged.cpu().numpy(), want), "device W*k merge disagrees with the host merge"
 
+    # N > 1: where a step's time goes, hop by hop (hipEvents on the launch stream, a separate pass of the same steps): the scan + merge on this
+    # rank's shard, the all-gather of the packed winners, the W x k -> k merge. The all-gather + merge budget that keeps an 8-GPU step at
+    # >= 0.70 of the HBM roofline is ~38 us.
+    hops = None
+    if world > 1 and px is None and backend == "nccl":
+        he = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(min(args.steps, 20))]
+        for e4 in he:
+            if distinct:
+                dist.all_gather_into_tensor(q, q_own)
+            e4[0].record()
+            rc = L.atlas_scan_topk_pack(q.data_ptr(), q_code, slab.data_ptr(), rows, B, D, k, pmax, out_s.data_ptr(), out_i.data_ptr(), out_st.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), stream, None, None, _lib.SCAN_TRUST_PMAX, world, rank, packed.data_ptr())
+            assert rc == 0, rc
+            e4[1].record()
+            dist.all_gather_into_tensor(gathered, packed)
+            e4[2].record()
+            rc = L.atlas_merge_packed(gathered.data_ptr(), world, B, k, merged.data_ptr(), stream)
+            assert rc == 0, rc
+            e4[3].record()
+        fence()
+        hops = {"scan_and_local_merge_ms": reduce_max(float(np.mean([e[0].elapsed_time(e[1]) for e in he]))),
+                "all_gather_packed_ms": reduce_max(float(np.mean([e[1].elapsed_time(e[2]) for e in he]))),
+                "merge_packed_ms": reduce_max(float(np.mean([e[2].elapsed_time(e[3]) for e in he]))),
+                "bytes_per_rank_all_gather": B * k * 8, "steps": len(he), "how": "hipEvents around each hop, max over ranks of the per-rank means"}
+
     scan_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     scan_ms_min = float(np.min([a.elapsed_time(b) for a, b in evs]))
     if world > 1:   # slowest rank's kernel
@@ -272,24 +324,21 @@ def main():
     #  slab passes, then one all-gather of the packed winners, the W x k -> k merge and the personalised text exchange)
     knn_ms, knn_err = None, None
     if world == 1 or backend == "nccl":            # (the gloo logic check keeps device tensors off the collectives)
+        # (a failure here fails the run loudly on every N: swallowed on one rank it would leave the others inside a collective)
         index.doc_map = _Docs()
-        try:
-            index.search_knn(q, k)
-            fence()
-            t1 = time.perf_counter()
-            for _ in range(5):
-                docs_, scores_ = index.search_knn(q, k)
-            fence()
-            knn_ms = (time.perf_counter() - t1) / 5 * 1e3
-            if world > 1:
-                knn_ms = reduce_max(knn_ms)
-            assert len(docs_) == B and len(docs_[0]) == k
-            if world == 1:
-                assert docs_[0][0]["id"] == int(i0[0, 0])
-        except Exception as e:                      # (N > 1 only: a leg beside the metric must not cost the line; N = 1 fails loudly)
-            if world == 1:
-                raise
-            knn_ms, knn_err = None, repr(e)[:300]
+        q_knn = q_own if distinct else q
+        index.search_knn(q_knn, k)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            docs_, scores_ = index.search_knn(q_knn, k)
+        fence()
+        knn_ms = (time.perf_counter() - t1) / 5 * 1e3
+        if world > 1:
+            knn_ms = reduce_max(knn_ms)
+        assert len(docs_) == q_knn.shape[0] and len(docs_[0]) == k
+        if world == 1:
+            assert docs_[0][0]["id"] == int(i0[0, 0])
 
     # ---- parity at the size the number is quoted on (outside every timed region): the timed results s0 / i0 against the MFMA-free
     # exact path for 8 queries spread over the batch -- ids and score bits
@@ -348,30 +397,30 @@ def main():
                                        "step_frac": nbytes / dts / 1e9 / HBM_PEAK_GBS, "kernel_frac": nbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                        "steps": steps_s, "timing": "step: K launches without events; kernel: hipEvents in a second pass of K",
                                        "parity_checked": {"rows": n_sub, "queries_exact": int(sel_s.numel())}}
+            # what a caller of the reference API sees on this shard: the synchronous product calls (host sync, one pinned D2H, status check,
+            # and for search_knn the passages through a REAL dict doc_map and python lists), against the device step above
+            if n_sub <= args.api_rows_max:
+                sub.doc_map = {i: {"id": i} for i in range(n_sub)}
+                for _ in range(3):
+                    sub.search_knn(q, k)
+                fence()
+                ta = time.perf_counter()
+                for _ in range(steps_s):
+                    sub._compute_scores_and_indices(q, k)
+                t_sync = (time.perf_counter() - ta) / steps_s
+                ta = time.perf_counter()
+                for _ in range(steps_s):
+                    docs_s, scores_s = sub.search_knn(q, k)
+                t_knn = (time.perf_counter() - ta) / steps_s
+                assert docs_s[0][0] is sub.doc_map[int(out_i[0, 0])] and len(docs_s) == B and len(scores_s[0]) == k
+                shard_sweep[str(n_sub)].update({"sync_call_ms": t_sync * 1e3, "search_knn_ms": t_knn * 1e3,
+                                                "search_knn_minus_step_ms": (t_knn - dts) * 1e3, "search_knn_step_frac": nbytes / t_knn / 1e9 / HBM_PEAK_GBS,
+                                                "doc_map": "dict of %d passages" % n_sub})
             del sub
 
     # ---- larger query batches on the 4M-row prefix (the shard of an 8-GPU run): a rank of a distributed search scores ALL gathered
-    # queries (src/index.py:127-131), B_total = W x b_r; the scan takes them in slab passes of 64 or 96 queries, single or as PAIRS that
-    # scan concurrently on half the chip each and share their slab reads through the cache (atlas_hip.hip: the pass plan; [a, b] = a pair)
-    def pass_plan(n):
-        cost, size = (1.0, 1.11, 1.62, 1.89), (64, 96, 128, 192)            # one 64 / 96-query pass, a PAIR of them on half the chip each
-        f, take = [0.0] * (n + 1), [0] * (n + 1)
-        for m in range(1, n + 1):
-            best = None
-            for it in range(4):
-                if it >= 2 and m <= size[it - 2]:
-                    continue
-                c = cost[it] + f[max(m - size[it], 0)]
-                if best is None or c < best:
-                    best, take[m] = c, it
-            f[m] = best
-        out = []
-        while n > 0:
-            it = take[n]; m = min(n, size[it])
-            out.append(m if it < 2 else [(m + 1) // 2, m // 2])
-            n -= m
-        return out
-
+    # queries (src/index.py:127-131), B_total = W x b_r: up to 96 in one streaming pass, above that in GEMM-shaped passes of up to 256 / 512 /
+    # 1024 queries (csrc/gscan_kernel.h), where the matrix pipe is the bound: `frac_of_mfma_peak`
     batch_sweep = None
     if world == 1 and args.batch_sweep and rows >= 4_000_000:
         batch_sweep = {}
@@ -404,10 +453,17 @@ def main():
             sel_b = torch.tensor(sorted({min(Bb - 1, j * (Bb // 8) + 3) for j in range(8)}), device=dev)
             es_b, ei_b = subb._exact_topk(qb[sel_b], k)
             assert torch.equal(o_s[sel_b], es_b) and torch.equal(o_i[sel_b], ei_b), f"B={Bb}: scan disagrees with the exact path"
-            plan_b = pass_plan(Bb) if Bb > 64 else [Bb]
-            passes = len(plan_b)                                         # launches; a paired launch reads the slab from HBM about once
-            batch_sweep[str(Bb)] = {"ms_per_step": dtb * 1e3, "queries_per_s": Bb / dtb, "slab_passes": passes, "queries_per_pass": plan_b,
-                                    "bytes_read_per_query": passes * n_b * D * 2 / Bb, "step_frac_of_hbm_peak": passes * n_b * D * 2 / dtb / 1e9 / HBM_PEAK_GBS,
+            # the passes the library made of this batch, as IT reports them (ATLAS_ST_PLAN); every launch -- a single pass, a pair, a
+            # GEMM-shaped pass of up to 1024 queries -- reads the slab from HBM about once (an estimate for pairs / column tiles: the second
+            # reader of a row is served by the L2 / Infinity Cache, not measured here)
+            plan_b = _lib.decode_plan(int(o_st.cpu()[_lib.ST_PLAN]))
+            launches = sum(plan_b.values())
+            flops = 2.0 * Bb * n_b * D
+            batch_sweep[str(Bb)] = {"ms_per_step": dtb * 1e3, "queries_per_s": Bb / dtb, "plan": plan_b, "slab_reads_estimated": launches,
+                                    "bytes_read_per_query_estimated": launches * n_b * D * 2 / Bb,
+                                    "step_frac_of_hbm_peak_estimated": launches * n_b * D * 2 / dtb / 1e9 / HBM_PEAK_GBS,
+                                    "tflops": flops / dtb / 1e12, "frac_of_mfma_peak": flops / dtb / 1e12 / MFMA_PEAK_TFLOPS,
+                                    "bound": "mfma" if Bb > 312 else "hbm",      # arithmetic intensity B flop/B against the ridge ~312
                                     "parity_checked": {"rows": n_b, "queries_exact": int(sel_b.numel())}}
         del subb
 
@@ -417,6 +473,11 @@ def main():
 
         n = min(args.cpu_sample, rows)
         cpu = ref_port.time_reference_flat(slab[:n].cpu(), q.cpu(), k, args.cpu_seconds, workload_rows=args.passages)
+        # BASELINE configs[1] (1M rows) timed as it is, no extrapolation, next to shard_sweep["1000000"]
+        if rows >= 1_000_000 and args.cpu_seconds >= 20:
+            at = ref_port.time_reference_flat(slab[:1_000_000].cpu(), q.cpu(), k, 0.0, workload_rows=1_000_000, min_rows=1_000_000)
+            cpu["at_1m"] = {"rows": 1_000_000, "kind": at["kind"], "seconds": at["seconds_per_batch_on_sample"], "queries_per_s": at["value"],
+                            "gpu_step_queries_per_s": (shard_sweep or {}).get("1000000", {}).get("queries_per_s")}
         # the same leg holds ONE query of the timed batch to the CPU oracle at the full size: the slab is streamed through the
         # oracle's canonical score in 1M-row chunks (all `rows` scores of that query), then its canonical top-k
         if args.oracle_query >= 0 and parity_checked is not None:
@@ -564,18 +625,25 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.passages} passages x d=768 fp16 (round-robin over {world} GPU), "
-                            f"{B} queries/step, top-{k}, exact MIPS",
-                "passages_total": args.passages, "passages_per_gpu": rows, "queries": B, "topk": k,
+                            f"{B} queries/step" + (f" ({Bq} distinct queries per rank, gathered)" if distinct else "") + f", top-{k}, exact MIPS",
+                "passages_total": args.passages, "passages_per_gpu": rows, "queries": B, "queries_per_rank": Bq, "distinct_queries": distinct, "topk": k,
                 "parallelism": f"shard{world}" + (("+peer-exchange" if args.exchange == "peer" and backend == "nccl" else "+rccl-allgather") if world > 1 else ""),
             },
-            "roofline": {
+            "roofline": ({
                 "kernel": "scan_kernel<16,1,8,64> (the twin that takes pmax as certified: ATLAS_SCAN_TRUST_PMAX, what HipDistributedIndex runs "
                           "between certifying searches)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch (PMC FETCH_SIZE, calibrated; from the committed pass of these sources, profiles/pmc_traffic.json)",
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_mean": scan_ms, "kernel_ms_min": scan_ms_min,
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
                 "certifying": certifying,
-            },
+            } if not (stats0.get("plan") or {}).get("gemm_passes") else {
+                # more than 96 queries per step (--distinct-queries at N > 1, or --queries): the GEMM-shaped pass, bounded by the matrix pipe
+                "kernel": "gscan_kernel<0> (two launches + the threshold update between them: the hipEvents bracket all three)", "bound": "mfma",
+                "achieved": 2.0 * B * rows * D / (scan_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": 2.0 * B * rows * D / (scan_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
+                "algorithmic_flops_per_launch": 2.0 * B * rows * D, "kernel_ms_mean": scan_ms, "kernel_ms_min": scan_ms_min,
+                "hbm_frac_of_one_slab_read": achieved / HBM_PEAK_GBS, "certifying": certifying,
+            }),
             "cpu_baseline": cpu,
             "refresh": refresh,
             "shard_sweep": shard_sweep,
@@ -583,8 +651,9 @@ def main():
             "detail": {
                 "parity_checked": parity_checked,
                 "sync_call_latency_ms": lat_ms, "search_knn_ms_per_batch": knn_ms, "search_knn_error": knn_err,
-                "search_knn_queries_per_s": (world * B / (knn_ms * 1e-3)) if knn_ms else None,
+                "search_knn_queries_per_s": (world * Bq / (knn_ms * 1e-3)) if knn_ms else None,
                 "search_knn_note": "synchronous product call incl. host lists; at N > 1 every rank submits its own 64 queries (N x 64 per call)", "candidates_per_search": stats0.get("candidates"),
+                "hops": hops, "plan": stats0.get("plan"),
                 "rescored_per_search": stats0.get("rescored"), "max_err_over_eps": stats0.get("max_err_over_eps"),
                 "build": L.atlas_build_info().decode(),
                 "pmax": {"value": pmax, "how": "atlas_slab_pmax once per state of the slab (torch version counter); the timed scans take it as certified "

@@ -18,10 +18,7 @@ for N in [int(a) for a in sys.argv[1:]] or [1_000_000]:
     q = torch.randn((B, D), generator=g, device="cuda")
     idx = HipDistributedIndex(); idx._set_slab(slab)
 
-    class _Docs:
-        def __getitem__(self, i): return {"id": i}
-        def __len__(self): return N
-    idx.doc_map = _Docs()
+    idx.doc_map = {i: {"id": i} for i in range(N)}        # a real dict, as the reference builds it (index.py:47)
     for _ in range(5): idx.search_knn(q, k)
     torch.cuda.synchronize()
     reps = 200
