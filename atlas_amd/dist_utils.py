@@ -34,7 +34,12 @@ def barrier() -> None:
         dist.barrier()
 
 
-_QUERY_CAP = 64          # rows per rank of the fixed-size query collective; grows (on every rank alike) when a batch exceeds it
+# rows per rank of the fixed-size query collective, PER PROCESS GROUP: {group key: [cap, consecutive calls that would have fitted 64 rows]}.
+# It grows (on every rank alike: same gathered headers) when a batch exceeds it and falls back to 64 after _CAP_DECAY_CALLS small calls in a row,
+# so that one large evaluation batch does not make every later 1-query search gather W x (cap + 1) x 768 halfs for good.
+_QUERY_CAP_MIN = 64
+_CAP_DECAY_CALLS = 16
+_query_caps = {}
 
 
 @torch.no_grad()
@@ -47,14 +52,14 @@ def all_gather_queries(queries: torch.Tensor) -> Tuple[torch.Tensor, List[int]]:
     of them repeat the call once with the larger block. fp16 on the wire: the scan casts with `.half()` anyway (src/index.py:117), so
     gathering the fp32 originals moves twice the bytes for the same result.
     """
-    global _QUERY_CAP
     q16 = queries.to(torch.float16)
     if not is_initialized():
         return q16, [q16.shape[0]]
     W = dist.get_world_size()
     b, d = q16.shape
+    state = _query_caps.setdefault((id(dist.group.WORLD), W), [_QUERY_CAP_MIN, 0])
     while True:
-        cap = _QUERY_CAP
+        cap = state[0]
         block = torch.zeros((cap + 1, d), dtype=torch.float16, device=q16.device)
         block[0].view(torch.int32)[0] = b
         block[1 : 1 + min(b, cap)] = q16[:cap]
@@ -64,7 +69,12 @@ def all_gather_queries(queries: torch.Tensor) -> Tuple[torch.Tensor, List[int]]:
         sizes = out[:, 0].contiguous().view(torch.int32)[:, 0].tolist()          # the one host sync
         if max(sizes) <= cap:
             break
-        _QUERY_CAP = (max(sizes) + 63) // 64 * 64                                    # same decision on every rank: same headers
+        state[0], state[1] = (max(sizes) + 63) // 64 * 64, 0                         # same decision on every rank: same headers
+    # decay (every rank sees the same sizes, so every rank shrinks at the same call)
+    if cap > _QUERY_CAP_MIN:
+        state[1] = state[1] + 1 if max(sizes) <= _QUERY_CAP_MIN else 0
+        if state[1] >= _CAP_DECAY_CALLS:
+            state[0], state[1] = _QUERY_CAP_MIN, 0
     allq = torch.cat([out[r, 1 : 1 + n] for r, n in enumerate(sizes)], dim=0)
     return allq, [int(n) for n in sizes]
 
@@ -85,9 +95,12 @@ class PeerExchange:
     """The one-hop alternative to `all_gather_packed` + the W*k -> k merge (C-ABI atlas_xchg_*, include/atlas_hip.h): every rank writes its
     packed winners straight into a slot of every peer's exchange buffer (mapped through hipIpc handles exchanged once, here) and the merge
     kernel waits for the W tags. EXPERIMENTAL and off by default (`HipDistributedIndex(exchange="peer")`): it has never run across two
-    devices. Setting it up is collective and fails on every rank or on none; `exchange()` returns None when a peer was late."""
+    devices. Setting it up is collective and fails on every rank or on none: a rank whose own buffer could not be created still takes part in
+    both set-up collectives (with an empty handle) and the verdict is formed from what all ranks report. `exchange()` returns None when a peer
+    was late -- `wait_ms` is therefore generous (a rank that re-ran its scan or took the exact path is seconds late, not dead): the caller
+    treats a late peer as an error of the job, there is no per-rank fallback that would not desynchronise the collectives."""
 
-    def __init__(self, slot_entries: int, wait_ms: int = 200):
+    def __init__(self, slot_entries: int, wait_ms: int = 10000):
         import ctypes
 
         from . import _lib
@@ -96,21 +109,27 @@ class PeerExchange:
         self.slot_entries, self.wait_ms, self.tag = int(slot_entries), int(wait_ms), 0
         self.dev = torch.device("cuda", torch.cuda.current_device())
         own, handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
-        _lib.check(self.L.atlas_xchg_create(self.W, self.slot_entries, ctypes.byref(own), handle), "atlas_xchg_create")
-        self.own = own.value
+        self.own, self._opened, failed = None, [], None
+        rc = self.L.atlas_xchg_create(self.W, self.slot_entries, ctypes.byref(own), handle)
+        if rc != 0:                                                     # (no raise here: the other ranks are about to enter the collectives below)
+            failed = f"atlas_xchg_create on rank {self.rank}: {'ATLAS_E_' + str(rc) if rc < 0 else 'hipError_t ' + str(rc)}"
+        else:
+            self.own = own.value
         handles = [None] * self.W
-        dist.all_gather_object(handles, bytes(handle.raw))              # once per index: 64 bytes per rank
+        dist.all_gather_object(handles, bytes(handle.raw) if failed is None else b"")      # once per index: 64 bytes per rank
         self.peers = (ctypes.c_void_p * self.W)()
-        self._opened = []
-        failed = None
+        if failed is None and any(len(h) != 64 for h in handles):
+            failed = f"rank {self.rank}: a peer has no exchange buffer"
         for r, h in enumerate(handles):
+            if failed is not None:
+                break
             if r == self.rank:
                 self.peers[r] = self.own
                 continue
             p = ctypes.c_void_p()
             rc = self.L.atlas_xchg_open(h, ctypes.byref(p))
             if rc != 0:
-                failed = f"atlas_xchg_open of rank {r}'s buffer: hipError_t {rc}"
+                failed = f"atlas_xchg_open of rank {r}'s buffer on rank {self.rank}: hipError_t {rc}"
                 break
             self.peers[r] = p.value
             self._opened.append(p.value)

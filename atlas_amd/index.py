@@ -533,6 +533,8 @@ class HipDistributedIndex(object):
                 return None
         out = self._peer_xchg.exchange(packed, k)
         if out is None:
+            # (deliberately not a per-rank fallback: the peers that were served would go on to the NEXT collective while this rank repeated
+            #  this one -- the job would hang instead of failing; wait_ms is seconds, a peer that late is gone)
             raise _lib.AtlasHipError(f"peer exchange: a rank did not deliver its candidates within {self._peer_xchg.wait_ms} ms")
         return out.cpu().numpy()
 

@@ -136,12 +136,21 @@ class IndexRefresher:
 
 
 def _passages_fingerprint(passages) -> int:
-    """a cheap content fingerprint of a passage list: ids, titles and texts of a few spread entries (first, last, and up to 62 between)"""
+    """a content fingerprint of a passage list: EVERY passage's id and text length (one cheap pass) plus ids, titles and texts of a few spread
+    entries (first, last, and up to 62 between). A HEURISTIC all the same: an in-place edit that keeps a passage's id and the length of its
+    text goes unnoticed unless it hits a sampled entry -- a caller that edits passages in place calls `invalidate_refresh_state(index)`."""
     n = len(passages)
     if n == 0:
         return 0
     picks = sorted({0, n - 1, *range(0, n, max(1, n // 62))})
-    return hash(tuple((passages[i].get("id"), passages[i].get("title"), passages[i].get("text")) for i in picks))
+    sample = tuple((passages[i].get("id"), passages[i].get("title"), passages[i].get("text")) for i in picks)
+    every = hash(tuple((p.get("id"), len(p.get("text") or "")) for p in passages))
+    return hash((sample, every))
+
+
+def invalidate_refresh_state(index) -> None:
+    """forget the token store / fp16 mirror `build_index_streamed` keeps on `index`: the next refresh tokenises the passages again"""
+    index.__dict__.get("_refresh_state", {}).clear()
 
 
 @torch.no_grad()

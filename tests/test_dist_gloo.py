@@ -108,3 +108,35 @@ def test_distributed_search_equals_union(W, batches, mode, tmp_path, oracle_mod)
         else:
             assert got["ids"].size == 0
         lo += n
+
+
+def _cap_worker(rank, W, port):
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    import atlas_amd.dist_utils as du
+
+    def cap():
+        return next(iter(du._query_caps.values()))[0]
+
+    g = torch.Generator().manual_seed(5 + rank)
+    big = torch.randn((130 if rank == 1 else 3, 768), generator=g)
+    allq, sizes = du.all_gather_queries(big)                       # one rank beyond the block: every rank repeats the call once
+    assert sizes == [3, 130] and tuple(allq.shape) == (133, 768) and cap() == 192
+    assert torch.equal(allq[3:], big.half()) if rank == 1 else torch.equal(allq[:3], big.half())
+    for i in range(du._CAP_DECAY_CALLS):                           # small batches: the block shrinks back after _CAP_DECAY_CALLS of them
+        assert cap() == 192
+        small = torch.randn((1 + rank, 768), generator=g)
+        allq, sizes = du.all_gather_queries(small)
+        assert sizes == [1, 2] and tuple(allq.shape) == (3, 768)
+    assert cap() == du._QUERY_CAP_MIN
+    allq, sizes = du.all_gather_queries(torch.randn((2, 768), generator=g))
+    assert sizes == [2, 2] and cap() == du._QUERY_CAP_MIN
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_query_block_grows_and_decays_on_every_rank_alike():
+    """the fixed-size query collective's block grows for a large batch and falls back to 64 rows after a run of small ones -- decided
+    from the gathered headers, so every rank takes the same decision at the same call"""
+    mp.spawn(_cap_worker, args=(2, 29871), nprocs=2, join=True)

@@ -76,8 +76,9 @@ def _worker(rank, W, port, N, batches, k, out_dir, exchange="rccl"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["rccl", pytest.param("peer", marks=pytest.mark.xfail(
-    strict=False, reason="experimental exchange: has never run across two devices (its logic is tested with two processes on one GPU)"))])
+# (both modes are plain tests: the peer exchange has never run across two devices -- its logic is tested with two processes on one GPU -- and the
+#  day a node appears a failure there must turn the suite red, not pass as an expected one)
+@pytest.mark.parametrize("exchange", ["rccl", "peer"])
 @pytest.mark.parametrize("W,batches", [(2, (3, 5)), (2, (4, 0)), (4, (2, 0, 5, 1)), (8, (1, 2, 0, 3, 1, 0, 2, 4))])
 def test_search_knn_over_rccl_equals_union(W, batches, exchange, tmp_path, oracle_mod):
     """both exchange modes: the all-gather of the packed winners, and the peer-mapped exchange buffers (index.py: exchange="peer")"""
@@ -110,10 +111,16 @@ def test_bench_runs_under_torchrun(W):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={W}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(W), "--steps", "5", "--warmup", "2",
            "--passages", "1000003", "--refresh-batches", "0", "--cpu-seconds", "0"]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert p.returncode == 0, p.stderr[-2000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]                             # rank 0 prints ONE line
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == W and d["config"]["passages_total"] == 1000003 and d["value"] > 0
-    assert d["config"]["passages_per_gpu"] == len(range(0, 1000003, W))
+    for extra in ([], ["--distinct-queries"]):                           # the metric step (replicated queries) and the API step (every rank its own 64)
+        p = subprocess.run(cmd + extra, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]                         # rank 0 prints ONE line
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == W and d["config"]["passages_total"] == 1000003 and d["value"] > 0
+        assert d["config"]["passages_per_gpu"] == len(range(0, 1000003, W))
+        assert d["config"]["distinct_queries"] is bool(extra) and d["config"]["queries"] == (64 * W if extra else 64)
+        h = d["detail"]["hops"]
+        assert h["all_gather_packed_ms"] > 0 and h["merge_packed_ms"] > 0 and h["bytes_per_rank_all_gather"] == d["config"]["queries"] * 40 * 8
+        if extra:
+            assert d["roofline"]["bound"] == ("mfma" if 64 * W > 96 else "hbm")
