@@ -123,7 +123,11 @@ gscan_kernel(const GScanParams p) {
     // A k-tile is 64 pieces of 8 rows x 128 B (32 of the slab, 32 of the queries), one wave instruction each. They are NOT split evenly: group
     // A issues its pieces in its read phase, beside the partner's MFMAs (~95 cycles of the wave's time per piece, hidden), group B in front of
     // its own MFMAs, where every piece is ~90 cycles of an idle matrix pipe -- so an A wave takes GS_PIECES_A = 11 (8 of the slab + 3 of the
-    // queries), a B wave 5 (queries): measured k-tile period 8 + 8: ... 11 + 5: ... (profiles/r04/gscan_phases.txt)
+    // queries), a B wave 5 (queries): measured k-tile period (stamps on) 8 + 8: 4.7k cycles, 11 + 5 with A's pieces in front of its reads: 4.3k.
+    // (Measured and not kept: group B refilling A's slab rows in its own READ phase -- A's half of a buffer is free a phase early -- with only
+    // two query pieces left in front of B's MFMAs: the ~500 cycles in front of the MFMAs shrink neither with the piece count nor with the
+    // descriptor arithmetic moved in front of the barrier (the first DMA issue behind a barrier is what costs); 2.5 % slower:
+    // profiles/r04/gscan_phases_512_phase_aware_pieces.txt)
     auto stage = [&](const int buf, const int it) __attribute__((always_inline)) {
         // (both descriptors are formed HERE, SGPR arithmetic: a descriptor carried across the k-loop ends up in VGPRs and every DMA in a
         //  readfirstlane loop)
@@ -136,7 +140,9 @@ gscan_kernel(const GScanParams p) {
         const int kb = kt * 128;
         const int w4 = wave & 3;
         auto piece = [&](const __amdgpu_buffer_rsrc_t& rsrc, const int op, const int rg) __attribute__((always_inline)) {      // rows [8 rg, 8 rg + 8) of operand op
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(smem + op * 2 * GS_STG + buf * GS_STG + rg * 1024), 16, (int)(vbase + (uint32_t)(rg * 8 * ROWB)), kb, 0, 0);
+            uint32_t vo = vbase;                       // (formed here from a copy hipcc cannot hoist: hoisted, the row offsets of all pieces live across the k-loop)
+            asm volatile("" : "+v"(vo));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(smem + op * 2 * GS_STG + buf * GS_STG + rg * 1024), 16, (int)(vo + (uint32_t)(rg * 8 * ROWB)), kb, 0, 0);
         };
         if (!grpB) {
 #pragma unroll

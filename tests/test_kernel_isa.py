@@ -68,13 +68,13 @@ def test_scan_has_no_scratch_and_a_clean_loop():
 
 def test_gemm_shaped_scan_has_a_clean_k_loop():
     """gscan_kernel (batches above 96 queries): at the 256-register cap of its 8-wave workgroup (128 accumulators + 96 fragment registers); the
-    scan and sample instantiations carry no private segment, the certifying twin at most its one spill slot OUTSIDE the k-loop; the 64 MFMAs of
+    three instantiations carry no private segment; the 64 MFMAs of
     a k-tile are free of vector-memory waits and every LDS-DMA descriptor lives in SGPRs (no readfirstlane loop around a DMA)"""
     fns = {k: v for k, v in _functions(_asm("atlas_hip")).items() if "gscan_kernelILi" in k}
     assert len(fns) == 3, sorted(fns)                        # scan, sample, certifying scan
     for name, body in fns.items():
         cert = "ILi2E" in name
-        assert _scratch_bytes(body) <= (8 if cert else 0), (name, _scratch_bytes(body))
+        assert _scratch_bytes(body) == 0 and "scratch_" not in body, (name, _scratch_bytes(body))
         lines = [l.strip() for l in body.split("\n")]
         mf = [i for i, l in enumerate(lines) if l.startswith("v_mfma")]
         assert len(mf) == 96, (name, len(mf))                # the k-step of a tile's first k-tile (C = 0) and the two of every k-tile
