@@ -1553,14 +1553,23 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
         }
         return;
     }
-    if (cfg == 4 && EPI == 1 && sizeof(typename T::elem) == 2) cfg = 6;     // FFN-1: the two-workgroup kernel is 4 % faster there
+    // The PRODUCT library reaches cfg 9 (16-bit bulk), 4 (fp32 bulk, from 9), 0 and 3 only: everything else -- and the 16-bit instantiations of
+    // gemm_pp_kernel -- exists in the tuning build alone (A/B references, the bit-equality test), so that libatlas_hip.so carries no kernel
+    // its dispatch cannot launch
+    constexpr bool TUNE = ATLAS_TUNING != 0;
+    constexpr bool IS16 = sizeof(typename T::elem) == 2;
+    if (cfg == 4 && EPI == 1 && IS16) cfg = 6;                              // FFN-1: the two-workgroup kernel is 4 % faster there
     if (cfg == 7) cfg = 4;                                                  // 7 = gemm_pp_kernel for every GEMM (A/B)
+    if (!TUNE && (cfg == 2 || cfg == 5 || cfg == 6 || cfg == 8 || (cfg == 4 && IS16))) cfg = 0;      // (unreachable: g_gemm_cfg is -1 there)
     if (cfg == 4) {
-        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        const unsigned mtiles = (unsigned)((Mmax + 255) / 256);
-        hipLaunchKernelGGL((gemm_pp_kernel<T, EPI>), dim3((mtiles + 7) / 8 * 8 * (N / 256)), dim3(512), 128 * 1024 + 512, stream, A, W, bias, R, C,
-                           VT, cu, n, tokinfo, N, K, Lp, g_gemm_dbg, g_gemm_diag);
+        if constexpr (TUNE || !IS16) {
+            (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            const unsigned mtiles = (unsigned)((Mmax + 255) / 256);
+            hipLaunchKernelGGL((gemm_pp_kernel<T, EPI>), dim3((mtiles + 7) / 8 * 8 * (N / 256)), dim3(512), 128 * 1024 + 512, stream, A, W, bias, R, C,
+                               VT, cu, n, tokinfo, N, K, Lp, g_gemm_dbg, g_gemm_diag);
+        }
     }
+#if ATLAS_TUNING
     else if (cfg == 6) {
         if constexpr (sizeof(typename T::elem) == 2) {
             (void)hipFuncSetAttribute((const void*)gemm_co_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1569,7 +1578,6 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
                                VT, cu, n, tokinfo, N, K, Lp, g_gemm_diag);
         } else go(gemm_bt_kernel<T, EPI, 256, 256, 2, 4>, 256, 256, 512);
     }
-#if ATLAS_TUNING
     else if (cfg == 8) {                               // weights in registers, activations through four LDS stages
         if constexpr (sizeof(typename T::elem) == 2) {
             (void)hipFuncSetAttribute((const void*)gemm_wr_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1578,8 +1586,9 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
                                VT, cu, n, tokinfo, N, K, Lp, g_gemm_diag);
         } else go(gemm_bt_kernel<T, EPI, 256, 256, 2, 4>, 256, 256, 512);
     }
-#endif
     else if (cfg == 2) go(gemm_bt_kernel<T, EPI, 256, 256, 2, 4>, 256, 256, 512);
+    else if (cfg == 5) go(gemm_bt_kernel<T, EPI, 64, 64, 2, 2>, 64, 64, 256);
+#endif
     else if (cfg == 3) {
         constexpr int ST = (sizeof(typename T::elem) == 2) ? 3 : 4;   // measured: 3 x 16 KiB (3 workgroups / CU) best for 16-bit
         (void)hipFuncSetAttribute((const void*)gemm_ms_kernel<T, EPI, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1587,7 +1596,6 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
         hipLaunchKernelGGL((gemm_ms_kernel<T, EPI, ST>), dim3((mtiles + 7) / 8 * 8 * (N / 64)), dim3(256), (size_t)ST * 2 * 64 * 128, stream, A, W,
                            bias, R, C, VT, cu, n, tokinfo, N, K, Lp);
     }
-    else if (cfg == 5) go(gemm_bt_kernel<T, EPI, 64, 64, 2, 2>, 64, 64, 256);
     else go(gemm_bt_kernel<T, EPI, 128, 128, 2, 2>, 128, 128, 256);
 }
 

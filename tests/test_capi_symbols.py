@@ -68,3 +68,18 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "HIP_SO", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.AtlasHipError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_product_library_carries_no_tuning_only_kernels(so):
+    """every kernel in libatlas_hip.so is one its own dispatch can launch -- the A/B references of the GEMM configurations
+    (two-workgroup kernel, 256 x 256 single-phase, 64 x 64 single-stage, weights-in-registers, the 16-bit instantiations of the LDS-epilogue
+    ping-pong kernel), the scan variants and the spin kernel exist in the tuning build only"""
+    import subprocess
+
+    names = subprocess.run(["nm", "-C", so], capture_output=True, text=True, check=True).stdout
+    stubs = [ln.split("__device_stub__", 1)[1] for ln in names.splitlines() if "__device_stub__" in ln]
+    assert 40 <= len(stubs) <= 80, len(stubs)
+    banned = ("gemm_co_kernel", "gemm_wr_kernel", "atlas_spin_kernel", "gemm_pp_kernel<F16", "gemm_pp_kernel<BF16", ", 256, 256, 2, 4>", ", 64, 64, 2, 2>",
+              "scan_kernel<8,", "scan_kernel<12,", "scan_kernel<16, 2,")
+    bad = [s for s in stubs if any(b in s for b in banned)]
+    assert not bad, bad
