@@ -15,13 +15,18 @@
 // XCD in neighbouring slots and walk their range in step, so every slab tile comes from HBM once and from that XCD's L2 (or the
 // Infinity Cache) the other ncol - 1 times: HBM traffic is one slab read per launch whatever the batch.
 //
-// Thresholds. A first launch of the same kernel in SAMPLE mode scores s_tiles evenly spread tiles and leaves, per query, the maximum of
-// every 16-row fragment; gtheta_kernel takes the k-th largest of those maxima (scores of DISTINCT rows -> prune_threshold gives a
-// certified threshold) -- the sample grows with the shard (about 1/64 of it), so a query brings ~70 k candidates per
-// million... no: ~64 k x 1.1 candidates to the merge whatever the shard's size. The SCAN launch then keeps what passes, per wave: a
-// wave appends to its own LDS buffer (slots from ballots: no atomics, no barrier) and empties it into the per-query global lists when it
-// is full (one returning atomic per entry on gcnt[query], all lanes at once) -- a few times per millisecond.
+// Thresholds. A first launch of the same kernel in SAMPLE mode scores s_tiles evenly spread tiles (about 1/64 of the slab) and leaves, per
+// query, the maximum of every 16-row fragment; gtheta_kernel takes a lower bound of the k-th largest of those maxima (scores of DISTINCT rows ->
+// prune_threshold gives a certified threshold). The scan then runs as TWO launches: the first eighth of every row range with
+// those thresholds, then -- gtheta_kernel again, over the candidates the first launch left in the lists -- the rest with the k-th best of
+// N / 8 rows: ~650 candidates per query reach the merge at k = 40 whatever the shard's size. A wave appends what passes to its own LDS buffer
+// (slots from ballot prefix counts: no atomics, no barrier) and empties it into the per-query global lists when it is half full (one returning
+// atomic per entry on gcnt[query], all lanes at once) -- a few times per millisecond.
 // The merge is merge_rescore_kernel in FLAT mode (merge_kernel.h): one contiguous list per query, cut into 1024 virtual segments.
+//
+// Measured and NOT adopted (profiles/r04/): a THIRD slab stage (the wave candidate buffers moved to global memory to make room: 5 x 32 KiB
+// of LDS), slab pieces issued two k-tiles ahead behind a counted s_waitcnt vmcnt(8) -- group A's ~400 exposed cycles per k-tile go away and
+// the scan is 3-4 % SLOWER all the same (three_slab_stages.patch, batch_gemm_pass_ab_*_three_slab_stages.txt).
 #pragma once
 #include "scan_kernel.h"
 
