@@ -31,6 +31,9 @@
 #include "common.h"
 #include "scan_kernel.h"
 #include "gscan_kernel.h"
+#if ATLAS_TUNING
+#include "gscan2_kernel.h"
+#endif
 #include "../../include/atlas_hip.h"
 
 using namespace atlas;
@@ -905,6 +908,12 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
             const GPlan g = make_gplan(N, nq, device_cus());
             auto gsample = gscan_kernel<1>;
             auto gscan = trusted ? gscan_kernel<0> : gscan_kernel<2>;          // <2>: the twin that measures every row norm
+            size_t g_lds = GS_LDS_BYTES;
+#if ATLAS_TUNING
+            if (g_scan_gemm == 2) {                    // experiment: the slab through a register ring (gscan2_kernel.h)
+                gsample = gscan2_kernel<1>; gscan = trusted ? gscan2_kernel<0> : gscan2_kernel<2>; g_lds = GS2_LDS_BYTES;
+            }
+#endif
             allow_lds(gsample); allow_lds(gscan); allow_lds(gtheta_kernel);
             uint16_t* q16 = (uint16_t*)(w + g.off_q16);
             uint32_t* gcnt = (uint32_t*)(w + g.off_gcnt);
@@ -915,7 +924,7 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
             gs.lists = (uint2*)(w + g.off_lists); gs.gcnt = gcnt; gs.qflag = (uint32_t*)(w + GS_OFF_QFLAG); gs.gcap = g.gcap;
             gs.wg_stat = (uint32_t*)(w + g.off_wgstat); gs.pmax2_hint = pmax_hint * pmax_hint;
             gs.dbg = g_scan_dbg;
-            hipLaunchKernelGGL(gsample, dim3(g.G), dim3(512), GS_LDS_BYTES, stream, gs);
+            hipLaunchKernelGGL(gsample, dim3(g.G), dim3(512), g_lds, stream, gs);
             hipLaunchKernelGGL(gtheta_kernel, dim3(g.ldq), dim3(256), GTHETA_LDS(g.nmax), stream, (const float*)gs.smax, g.nmax, g.ldq, (const uint16_t*)q16, nq,
                                pmax_hint, k, (float*)(w + g.off_theta), (const uint2*)nullptr, (const uint32_t*)nullptr, 0);
             // the scan, in two launches: the first eighth of every row range with the sample's thresholds, then -- thresholds tightened by what
@@ -925,12 +934,12 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
             const int t1 = tiles_per_range >= 16 ? (tiles_per_range + 7) / 8 : tiles_per_range;
             if (q0 == 0 && ev_scan_begin) (void)hipEventRecord((hipEvent_t)ev_scan_begin, stream);
             gs.tile_begin = 0; gs.tile_end = t1;
-            hipLaunchKernelGGL(gscan, dim3(g.G), dim3(512), GS_LDS_BYTES, stream, gs);
+            hipLaunchKernelGGL(gscan, dim3(g.G), dim3(512), g_lds, stream, gs);
             if (t1 < tiles_per_range) {
                 hipLaunchKernelGGL(gtheta_kernel, dim3(g.ldq), dim3(256), GTHETA_LDS(GTHETA_MAXKEYS), stream, (const float*)gs.smax, g.nmax, g.ldq, (const uint16_t*)q16, nq,
                                    pmax_hint, k, (float*)(w + g.off_theta), (const uint2*)gs.lists, (const uint32_t*)gcnt, g.gcap);
                 gs.tile_begin = t1; gs.tile_end = tiles_per_range; gs.wg_stat += (size_t)g.G * 2;      // (one word pair per workgroup and launch)
-                hipLaunchKernelGGL(gscan, dim3(g.G), dim3(512), GS_LDS_BYTES, stream, gs);
+                hipLaunchKernelGGL(gscan, dim3(g.G), dim3(512), g_lds, stream, gs);
             }
             if (q0 == 0 && ev_scan_end) (void)hipEventRecord((hipEvent_t)ev_scan_end, stream);
             MergeParams mp{};

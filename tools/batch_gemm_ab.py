@@ -13,6 +13,9 @@ args = sys.argv[1:]
 k = 40
 if "--k" in args:
     i = args.index("--k"); k = int(args[i + 1]); del args[i:i + 2]
+modes = (0, 1)
+if "--modes" in args:      # 0 = streaming passes, 1 = gscan_kernel, 2 = gscan2_kernel (experiment: the slab through a register ring)
+    i = args.index("--modes"); modes = tuple(int(x) for x in args[i + 1].split(",")); del args[i:i + 2]
 sizes = [int(a) for a in args] or [4_000_000, 32_000_000]
 NMAX = max(sizes)
 g = torch.Generator(device="cuda").manual_seed(1)
@@ -27,9 +30,9 @@ for N in sizes:
         out_st = torch.empty(_lib.STATUS_HEADER + B, dtype=torch.int32, device="cuda")
         ws = torch.zeros(L.atlas_scan_topk_workspace_bytes(N, B, D, k), dtype=torch.uint8, device="cuda")
         reps = max(3, int((200 if N <= 4_000_000 else 24) * 64 / B))
-        res, outs, stats = {0: [], 1: []}, {}, {}
+        res, outs, stats = {m: [] for m in modes}, {}, {}
         for rnd in range(3):
-            for mode in (0, 1):
+            for mode in modes:
                 L.atlas_tune_set_scan_gemm(mode)
                 def call():
                     rc = L.atlas_scan_topk_flags(q.data_ptr(), _lib.DT_F16, slab.data_ptr(), N, B, D, k, 1.002, out_s.data_ptr(), out_i.data_ptr(), out_st.data_ptr(),
@@ -46,9 +49,12 @@ for N in sizes:
                 cur = (out_s.clone(), out_i.clone())
                 if mode in outs: assert torch.equal(cur[0], outs[mode][0]) and torch.equal(cur[1], outs[mode][1])
                 outs[mode] = cur
-        same = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-        a, b = (float(np.median(res[m])) for m in (0, 1))
+        same = all(torch.equal(outs[modes[0]][0], outs[m][0]) and torch.equal(outs[modes[0]][1], outs[m][1]) for m in modes)
+        if len(modes) > 2:
+            print(f"{N:>9d} rows, {B:4d} queries, k {k}: " + "  ".join(f"mode {m}: {float(np.median(res[m])):8.3f} ms" for m in modes) + f"  identical: {same}", flush=True)
+            continue
+        a, b = (float(np.median(res[m])) for m in modes)
         tf = 2.0 * B * N * D / (b * 1e-3) / 1e12
         print(f"{N:>9d} rows, {B:4d} queries, k {k}: streaming passes {a:8.3f} ms = {B / a * 1e3:8.0f} q/s;  GEMM-shaped {b:8.3f} ms = {B / b * 1e3:8.0f} q/s (x {a / b:5.3f}; {tf:6.0f} TFLOP/s = {tf / 2500:5.3f} of the f16 MFMA peak; "
-              f"{N * 1536 / (b * 1e-3) / 1e12:5.2f} TB/s of slab per pass-set); candidates/query {stats[0][0]:.0f} vs {stats[1][0]:.0f}, rescored {stats[0][1]:.1f} vs {stats[1][1]:.1f}, max err/eps {stats[1][2]:.3f}; identical: {same}", flush=True)
+              f"{N * 1536 / (b * 1e-3) / 1e12:5.2f} TB/s of slab per pass-set); candidates/query {stats[modes[0]][0]:.0f} vs {stats[modes[1]][0]:.0f}, rescored {stats[modes[0]][1]:.1f} vs {stats[modes[1]][1]:.1f}, max err/eps {stats[modes[1]][2]:.3f}; identical: {same}", flush=True)
 L.atlas_tune_set_scan_gemm(1)
