@@ -9,7 +9,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = ["r01/bench_default_32m.json", "r01/bench_4m.json", "r01/bench_1m.json", "r02/bench_default_32m_sessionM.json"]
+LINES = ["r01/bench_default_32m.json", "r01/bench_4m.json", "r01/bench_1m.json", "r02/bench_default_32m_sessionM.json",
+         "r03/bench_default_32m_sessionAC.json", "r04/bench_default_32m_sessionS1.json"]
 
 
 @pytest.mark.parametrize("name", LINES)
@@ -67,6 +68,57 @@ def test_round2_line_carries_parity_sweep_and_streamed_refresh():
     assert st["unit"] == "passages/s" and st["seconds"] >= 2.0 and abs(st["value"] - st["passages_per_refresh"] * st["refreshes"] / st["seconds"]) <= 1e-6 * st["value"]
     assert st["vs_device_resident_ragged"] >= 0.95                       # within 5 % of the device-resident rate
     assert d["cpu_baseline"]["kind"].startswith("port, extrapolated from")
+
+
+def _line(name):
+    return json.loads(open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("name", LINES[4:])
+def test_round3_and_4_lines_carry_both_twins_the_batch_sweep_and_the_power_samples(name):
+    """what rounds 3 and 4 added: the certifying twin beside the trusting one, parity per shard_sweep entry, batches above 64 queries with
+    consistent arithmetic, rocm-smi power / clock samples beside the streamed refresh"""
+    d = _line(name)
+    r = d["roofline"]
+    c = r["certifying"]
+    assert abs(c["frac"] - r["algorithmic_bytes_per_launch"] / (c["kernel_ms_mean"] * 1e-3) / 1e9 / 8000.0) < 1e-9 and c["steps"] == d["steps"]
+    assert c["kernel_ms_mean"] > r["kernel_ms_mean"]                    # measuring every row norm is not free
+    for n, v in d["shard_sweep"].items():
+        assert v["parity_checked"] == {"rows": int(n), "queries_exact": 8}
+    bs = d["batch_sweep"]
+    assert {"64", "96", "128", "192", "256", "512"} <= set(bs)
+    for b, v in bs.items():
+        assert abs(v["queries_per_s"] - int(b) / (v["ms_per_step"] * 1e-3)) <= 1e-6 * v["queries_per_s"]
+        assert v["parity_checked"]["rows"] == 4_000_000 and v["parity_checked"]["queries_exact"] >= 8
+    pw = d["refresh"]["streamed"]["power"]
+    assert pw is None or (pw["samples"] >= 10 and 300 < pw["watts_mean"] <= pw["watts_max"] < 1600)
+
+
+def test_round4_line_reports_the_plan_the_mfma_fraction_and_the_api_level_times():
+    """round 4: batch_sweep entries carry the pass plan the LIBRARY reports (ATLAS_ST_PLAN) and, above 96 queries, the GEMM-shaped pass measured
+    against the matrix pipe; shard_sweep entries up to 4M rows time the synchronous product calls through a real dict; cpu_baseline has the
+    1M-row configuration un-extrapolated"""
+    d = _line(LINES[5])
+    bs = d["batch_sweep"]
+    for b, v in bs.items():
+        B = int(b)
+        flops = 2.0 * B * 4_000_000 * 768
+        assert abs(v["tflops"] - flops / (v["ms_per_step"] * 1e-3) / 1e12) <= 1e-6 * v["tflops"]
+        assert abs(v["frac_of_mfma_peak"] - v["tflops"] / 2500.0) < 1e-9
+        plan = v["plan"]
+        assert sum(plan.values()) >= 1 and v["slab_reads_estimated"] == sum(plan.values())
+        assert (plan["gemm_passes"] >= 1) == (B > 96), (b, plan)       # one streaming pass up to 96 queries, GEMM-shaped above
+    # VERDICT r03 #1: 512 queries on the 4M-row shard <= 3.0 ms at >= 0.42 of the MFMA peak, 256 <= 1.7 ms; monotone except at the half-empty tile
+    assert bs["512"]["ms_per_step"] <= 3.0 and bs["512"]["frac_of_mfma_peak"] >= 0.42 and bs["256"]["ms_per_step"] <= 1.7
+    q = [bs[b]["queries_per_s"] for b in ("64", "96", "128", "192", "256", "512", "1024")]
+    assert all(q[i] < q[i + 1] for i in range(len(q) - 1)), q
+    for n in ("1000000", "4000000"):
+        v = d["shard_sweep"][n]
+        assert v["doc_map"].startswith("dict of") and v["search_knn_ms"] >= v["sync_call_ms"] >= v["ms_per_step"] * 0.98
+        assert abs(v["search_knn_minus_step_ms"] - (v["search_knn_ms"] - v["ms_per_step"])) < 1e-9 and v["search_knn_minus_step_ms"] < 0.15
+    a = d["cpu_baseline"]["at_1m"]
+    assert a["rows"] == 1_000_000 and a["kind"] == "port" and abs(a["queries_per_s"] - 64 / a["seconds"]) <= 1e-6 * a["queries_per_s"]
+    assert d["detail"]["plan"] == {"passes_64": 1, "passes_96": 0, "pairs_64": 0, "pairs_96": 0, "gemm_passes": 0}
 
 
 def test_bench_refuses_to_run_without_a_gpu():
