@@ -223,7 +223,7 @@ gscan_kernel(const GScanParams p) {
                 if (cnt > GS_WBUF_REAL / 2) flush();
                 // (2) passing scores take the buffer slots cnt, cnt + 1, ... in walk order (ballot prefix counts: no atomics, no barrier). A
                 // handful pass per tile and wave and the buffer has room for at least GS_WBUF_REAL / 2 more; slots are CLAMPED to the buffer,
-                // and a tile that brings more than fit (no usable threshold, mass ties: adversarial data) sends the wave's 64 queries to the
+                // and what a tile brings beyond that (no usable threshold, mass ties: adversarial data) sends ITS queries to the
                 // exact path, as a full list does. Rows past the end of the range (zeros in a partial last tile) are dropped by the flush.
                 // The body is kept SMALL (the 32 copies are ~10 KB of code that stays in the instruction cache: a first version with per-entry
                 // capacity checks and out-of-line bodies took ~1 000 cycles per candidate, mostly instruction fetch).
@@ -232,6 +232,7 @@ gscan_kernel(const GScanParams p) {
                 // group of four fragments, then one per fragment, and NO branch inside a hit fragment -- every lane stores, the lanes
                 // without a passing score into a dummy slot of their own behind the real ones.
                 const uint32_t dummy = wb + (uint32_t)(GS_WBUF_REAL + ln) * 8u;
+                uint32_t lost = 0;                      // bit b: a passing score of the lane's query column b found no slot
 #pragma unroll
                 for (int a = 0; a < 8; ++a) {
                     if ((hit & (0xfu << (a * 4))) == 0u) continue;
@@ -244,6 +245,8 @@ gscan_kernel(const GScanParams p) {
                             const bool pass = v[r] > th[b];
                             const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
                             uint32_t idx = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                            // (the buffer's last slot is a trash slot: what lands there or beyond it is LOST, and the query it belongs to is noted)
+                            if (pass && idx >= GS_WBUF_REAL - 1) lost |= 1u << b;
                             idx = idx < GS_WBUF_REAL - 1 ? idx : GS_WBUF_REAL - 1;
                             const unsigned long long e = (unsigned long long)f32_bits(v[r]) |
                                                          ((unsigned long long)(tag0 + (((uint32_t)(b * 16) << 24) | (uint32_t)(a * 16 + r))) << 32);
@@ -253,10 +256,11 @@ gscan_kernel(const GScanParams p) {
                         }
                     }
                 }
-                if (cnt > GS_WBUF_REAL) {               // entries were lost
-                    cnt = GS_WBUF_REAL;
+                if (cnt > GS_WBUF_REAL - 1) {           // entries were lost: exactly the queries that lost one take the exact path
+                    cnt = GS_WBUF_REAL - 1;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) p.qflag[col * GS_TILE + wj * 64 + b * 16 + lr_e] = 1u;
+                    for (int b = 0; b < 4; ++b)
+                        if (lost & (1u << b)) p.qflag[col * GS_TILE + wj * 64 + b * 16 + lr_e] = 1u;
                 }
             }
             GS_ESTAMP(2);

@@ -96,6 +96,36 @@ def test_gemm_shaped_passes_bit_exact_vs_oracle(N, B, k, ps, certify, gpu_index_
         assert st["max_err_over_eps"] < 0.25 and (k > 128 or st["fallback_queries"] == 0), st
 
 
+@pytest.mark.parametrize("N,B,k,ps", [(65536 + 17, 1100, 7, 341), (65536, 97, 1, 342), (90001, 1024, 40, 343), (131072 + 255, 600, 33, 344)])
+def test_gemm_shaped_passes_at_their_edges(N, B, k, ps, gpu_index_cls, oracle_mod):
+    """edges of the GEMM-shaped pass: the smallest shard that takes it (65 536 rows: 256 tiles, half of them the sample), a last tile of 17 / 145 /
+    255 rows, more queries than one pass takes (1100 = 1024 + a second pass), four column tiles, k = 1"""
+    P = synth.passages_f16(N, 768, ps)
+    Q = synth.queries_f32(B, 768, ps + 1)
+    idx = _index(gpu_index_cls, P)
+    s, i = _search(idx, Q, k)
+    es, ei = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, k)
+    parity.assert_identical(s, i, es, ei, f"N={N} B={B} k={k}")
+    st = idx.last_search_stats
+    assert st["path"] == "scan" and st["fallback_queries"] == 0 and st["plan"]["gemm_passes"] >= 1 and sum(st["plan"].values()) >= (2 if B > 1024 else 1), st
+
+
+def test_gemm_shaped_pass_with_mass_ties_falls_back_per_query(gpu_index_cls, oracle_mod):
+    """3 000 copies of one passage straddle the cut of the queries that like it: their candidate lists overflow the merge's band -- those queries take
+    the exact path (flagged per query), the others stay on the scan; same canonical result (ties: lowest row first)"""
+    N, B, k = 100000, 160, 40
+    P = synth.passages_f16(N, 768, 351)
+    P[20000:23000] = P[777]
+    Q = synth.queries_f32(B, 768, 352)
+    Q[:5] = P[777].astype(np.float32) * 3.0 + 0.01 * Q[:5]              # five queries whose best passage is the duplicated one
+    idx = _index(gpu_index_cls, P)
+    s, i = _search(idx, Q, k)
+    es, ei = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, k)
+    parity.assert_identical(s, i, es, ei, "mass ties under the GEMM-shaped pass")
+    st = idx.last_search_stats
+    assert st["plan"]["gemm_passes"] >= 1 and 1 <= st["fallback_queries"] <= 16, st
+
+
 def test_gemm_shaped_pass_finds_a_row_that_violates_the_hint(gpu_index_cls, oracle_mod):
     """the certifying twin of the GEMM-shaped pass measures every row: a 9 x row raises ATLAS_F_PMAX_VIOLATION, the search is repeated
     with the measured bound (the C-ABI contract of atlas_scan_topk), same canonical result"""
