@@ -663,11 +663,15 @@ ExactPlan make_exact_plan(int64_t N, int d, int k, int B) {
 
 // The GEMM-shaped pass of big batches (gscan_kernel.h). One pass takes up to GS_MAXQ queries as ncol = 1, 2 or 4 column tiles of 256.
 constexpr int GS_MAXQ = 1024;
+#ifndef GS_COST_128
+#define GS_COST_128 1.32f          // a pass of up to 128 queries on the 128-wide tile, in units of a 64-query pass (1.37 ms vs 1.06 ms at 4M rows: its
+                                   // k-tile streams the slab at ~5.3 TB/s, the HBM roof, not the MFMA one; profiles/r04/batch_gemm_pass_ab_128wide.txt)
+#endif
 constexpr size_t GS_OFF_QFLAG = 800u << 10;     // its per-query fallback flags: state words (zero between calls) behind the coop scan's granules
 static_assert(GS_OFF_QFLAG >= 512 + 256 + 512 + 1024 + (size_t)QWIDE * 1024 * 8 && GS_OFF_QFLAG + GS_MAXQ * 4 <= PAIR_STATE, "inside the first chunk's state");
 struct GPlan {
     bool ok;
-    int G, ncol, ldq;
+    int G, ncol, ldq, cw;                           // cw: queries per column tile: 256, or 128 for passes of up to 128 queries (gscan_kernel<., 2>)
     int64_t rows_per_range;
     int s_tiles, nmax; int64_t s_stride;
     int gcap;
@@ -676,8 +680,9 @@ struct GPlan {
 GPlan make_gplan(int64_t N, int nq, int cus) {
     GPlan g{};
     int ncol = 1;
-    while (ncol * GS_TILE < nq) ncol *= 2;
-    g.ncol = ncol; g.ldq = ncol * GS_TILE;
+    g.cw = nq <= GS_TILE / 2 ? GS_TILE / 2 : GS_TILE;
+    while (ncol * g.cw < nq) ncol *= 2;
+    g.ncol = ncol; g.ldq = ncol * g.cw;
     g.G = cus / (8 * ncol) * (8 * ncol);
     const int64_t full_tiles = N / GS_TILE, tiles = (N + GS_TILE - 1) / GS_TILE;
     g.ok = nq >= 1 && nq <= GS_MAXQ && g.G >= 8 * ncol && g.G <= 1024 && full_tiles >= 256;
@@ -850,21 +855,21 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
         pair_ok = pp.S > 0 && pp.G == half && scan_plan_supported(pp, wide_ok ? 25 : 26) && ws_bytes >= pp.bulk_begin + 2 * pp.bulk_size;
     }
     const bool pair_wide_ok = pair_ok && wide_ok && half >= QWIDE;
-    bool gemm_ok[3] = {false, false, false};
+    bool gemm_ok[4] = {false, false, false, false};          // passes of up to 128 (the 128-wide tile), 256, 512, 1024 queries
     if (B > QWIDE && scan_variant_index() == 0 && scan_gemm_enabled()) {
-        for (int i = 0; i < 3; ++i) {
-            const GPlan g = make_gplan(N, GS_TILE << i, device_cus());
+        for (int i = 0; i < 4; ++i) {
+            const GPlan g = make_gplan(N, (GS_TILE / 2) << i, device_cus());
             gemm_ok[i] = g.ok && ws_bytes >= g.total;
         }
     }
-    if (B <= QCHUNK || (!wide_ok && !pair_ok && !gemm_ok[0])) {
+    if (B <= QCHUNK || (!wide_ok && !pair_ok && !gemm_ok[1])) {
         for (int r = B; r > 0; r -= QCHUNK) passes.push_back({r < QCHUNK ? r : QCHUNK, 0, false, false});
     } else {
         // costs in units of one 64-query pass (measured at 4M and 32M rows: profiles/r03/batch_paired_pass_ab.txt, profiles/r04/batch_gemm_pass_ab.txt)
-        constexpr int NI = 7;
-        const float cost[NI] = {1.0f, 1.11f, 1.62f, 1.89f, 1.56f, 2.86f, 5.40f};
-        const int size[NI] = {QCHUNK, QWIDE, 2 * QCHUNK, 2 * QWIDE, GS_TILE, 2 * GS_TILE, 4 * GS_TILE};
-        const bool ok[NI] = {true, wide_ok, pair_ok, pair_wide_ok, gemm_ok[0], gemm_ok[1], gemm_ok[2]};
+        constexpr int NI = 8;
+        const float cost[NI] = {1.0f, 1.11f, 1.62f, 1.89f, 1.56f, 2.86f, 5.40f, GS_COST_128};
+        const int size[NI] = {QCHUNK, QWIDE, 2 * QCHUNK, 2 * QWIDE, GS_TILE, 2 * GS_TILE, 4 * GS_TILE, GS_TILE / 2};
+        const bool ok[NI] = {true, wide_ok, pair_ok, pair_wide_ok, gemm_ok[1], gemm_ok[2], gemm_ok[3], gemm_ok[0]};
         std::vector<float> f((size_t)B + 1, 0.f);
         std::vector<unsigned char> take((size_t)B + 1, 0);
         for (int n = 1; n <= B; ++n) {
@@ -872,7 +877,8 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
             for (int it = 0; it < NI; ++it) {
                 if (!ok[it]) continue;
                 if ((it == 2 || it == 3) && n <= size[it - 2]) continue;     // a pair needs more queries than one pass of its kind takes
-                if (it >= 5 && n <= size[it - 1]) continue;                  // a column tile more than the queries fill
+                if ((it == 5 || it == 6) && n <= size[it - 1]) continue;     // a column tile more than the queries fill
+                if (it == 4 && gemm_ok[0] && n <= GS_TILE / 2) continue;     // (up to 128 queries: the 128-wide tile)
                 const float c = cost[it] + f[n > size[it] ? n - size[it] : 0];
                 if (c < best) { best = c; take[n] = (unsigned char)it; }
             }
@@ -906,8 +912,9 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
         if (passes[ci].gemm) {
             // GEMM-shaped pass: queries -> fp16 rows, sample launch -> fragment maxima, thresholds, scan launch, merge (flat lists)
             const GPlan g = make_gplan(N, nq, device_cus());
-            auto gsample = gscan_kernel<1>;
-            auto gscan = trusted ? gscan_kernel<0> : gscan_kernel<2>;          // <2>: the twin that measures every row norm
+            auto gsample = g.cw == GS_TILE ? gscan_kernel<1, 4> : gscan_kernel<1, 2>;
+            auto gscan = g.cw == GS_TILE ? (trusted ? gscan_kernel<0, 4> : gscan_kernel<2, 4>)          // <2, .>: the twin that measures every row norm
+                                         : (trusted ? gscan_kernel<0, 2> : gscan_kernel<2, 2>);
             size_t g_lds = GS_LDS_BYTES;
 #if ATLAS_TUNING
             if (g_scan_gemm == 2) {                    // experiment: the slab through a register ring (gscan2_kernel.h)

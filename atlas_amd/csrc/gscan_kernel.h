@@ -81,9 +81,16 @@ typedef unsigned int gs_u4 __attribute__((ext_vector_type(4)));
 // MODE 0 = scan (filter epilogue), 1 = sample (fragment maxima), 2 = scan that also MEASURES every row's norm (the certifying twin: the caller's
 // pmax is a hint, atlas_scan_topk's default contract). The four waves that share a slab fragment row split its eight fragments: 16 v_dot2
 // per k-tile and wave beside its 64 MFMAs.
-template <int MODE>
+// FB = 16-query fragments per wave: 4 -> the column tile is 256 queries wide (a wave owns 128 rows x 64 queries); 2 -> 128 queries wide (128 x 32:
+// half the MFMAs per k-tile and 48 instead of 64 LDS-DMA pieces -- the tile of batches of 97..128 queries, which a half-empty 256-wide tile would
+// serve at the cost of 256)
+template <int MODE, int FB = 4>
 __global__ void __launch_bounds__(512)
 gscan_kernel(const GScanParams p) {
+    constexpr int QW = 16 * FB;                        // queries per wave
+    constexpr int CW = 4 * QW;                         // queries per column tile
+    constexpr int QPIECES = CW / 8;                    // LDS-DMA pieces of a k-tile's queries: 32 | 16
+    constexpr int QA = FB == 4 ? GS_PIECES_A - 8 : 1;  // ... of them issued by a wave of group A (group B: QPIECES / 4 - QA)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // S0 | S1 | Q0 | Q1 (32 KiB each) | 8 wave buffers
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -123,8 +130,8 @@ gscan_kernel(const GScanParams p) {
     // of the queries are not fetched (zeros land in LDS); the k-tile rides in the scalar offset.
     const uint32_t chb = (uint32_t)(((lane & 7) ^ (lane >> 3)) * 16);
     const uint32_t vbase = (uint32_t)(lane >> 3) * ROWB + chb;
-    int qrows = p.nq - col * GS_TILE;
-    qrows = __builtin_amdgcn_readfirstlane(qrows < 0 ? 0 : (qrows > GS_TILE ? GS_TILE : qrows));     // (hipcc clamps with v_med3: back to an SGPR, or the descriptor lives in VGPRs)
+    int qrows = p.nq - col * CW;
+    qrows = __builtin_amdgcn_readfirstlane(qrows < 0 ? 0 : (qrows > CW ? CW : qrows));     // (hipcc clamps with v_med3: back to an SGPR, or the descriptor lives in VGPRs)
     // A k-tile is 64 pieces of 8 rows x 128 B (32 of the slab, 32 of the queries), one wave instruction each. They are NOT split evenly: group
     // A issues its pieces in its read phase, beside the partner's MFMAs (~95 cycles of the wave's time per piece, hidden), group B in front of
     // its own MFMAs, where every piece is ~90 cycles of an idle matrix pipe -- so an A wave takes GS_PIECES_A = 11 (8 of the slab + 3 of the
@@ -136,7 +143,7 @@ gscan_kernel(const GScanParams p) {
     auto stage = [&](const int buf, const int it) __attribute__((always_inline)) {
         // (both descriptors are formed HERE, SGPR arithmetic: a descriptor carried across the k-loop ends up in VGPRs and every DMA in a
         //  readfirstlane loop)
-        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(p.q16 + (size_t)col * GS_TILE * D_FAST), 0, qrows * ROWB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(p.q16 + (size_t)col * CW * D_FAST), 0, qrows * ROWB, 0x00020000);
         const int ti = it / GS_NK, kt = it - ti * GS_NK;
         const int64_t r0 = tile_row0(ti);
         int64_t rem = (SCAN ? end : p.N) - r0;
@@ -153,27 +160,27 @@ gscan_kernel(const GScanParams p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) piece(rs, 0, w4 + 4 * j);
 #pragma unroll
-            for (int j = 0; j < GS_PIECES_A - 8; ++j) piece(rq, 1, w4 + 4 * j);
+            for (int j = 0; j < QA; ++j) piece(rq, 1, w4 + 4 * j);
         } else {
 #pragma unroll
-            for (int j = 0; j < 16 - GS_PIECES_A; ++j) piece(rq, 1, 4 * (GS_PIECES_A - 8) + w4 + 4 * j);
+            for (int j = 0; j < QPIECES / 4 - QA; ++j) piece(rq, 1, 4 * QA + w4 + 4 * j);
         }
     };
 
-    // the lane's fragment chunks: slab rows wi * 128 + 16 a + lr (MFMA A operand), query rows wj * 64 + 16 b + lr (B operand); k-step 0 of a
+    // the lane's fragment chunks: slab rows wi * 128 + 16 a + lr (MFMA A operand), query rows wj * QW + 16 b + lr (B operand); k-step 0 of a
     // k-tile = chunks 0..3 (chunk lg of the lane), k-step 1 = chunks 4..7
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const uint32_t as0 = lds0 + (wi * 128 + lr) * 128 + ((0 + lg) ^ (lr & 7)) * 16;
     const uint32_t as1 = lds0 + (wi * 128 + lr) * 128 + ((4 + lg) ^ (lr & 7)) * 16;
-    const uint32_t aq0 = lds0 + 2 * GS_STG + (wj * 64 + lr) * 128 + ((0 + lg) ^ (lr & 7)) * 16;
-    const uint32_t aq1 = lds0 + 2 * GS_STG + (wj * 64 + lr) * 128 + ((4 + lg) ^ (lr & 7)) * 16;
+    const uint32_t aq0 = lds0 + 2 * GS_STG + (wj * QW + lr) * 128 + ((0 + lg) ^ (lr & 7)) * 16;
+    const uint32_t aq1 = lds0 + 2 * GS_STG + (wj * QW + lr) * 128 + ((4 + lg) ^ (lr & 7)) * 16;
 
     // C layout of v_mfma_f32_16x16x32_f16: lane l holds query column l & 15 and slab rows 4 (l >> 4) + r of the 16 x 16 block: the lane
     // OWNS its queries, the thresholds are four per-lane scalars for the whole kernel
-    float th[4];
+    float th[FB];
     if (SCAN) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) th[b] = p.theta[col * GS_TILE + wj * 64 + b * 16 + lr];
+        for (int b = 0; b < FB; ++b) th[b] = p.theta[col * CW + wj * QW + b * 16 + lr];
     }
     uint2* wbuf = (uint2*)(smem + 4 * GS_STG) + wave * GS_WBUF_ENTRIES;
     uint32_t cnt = 0;                                   // entries in this wave's buffer (wave-uniform)
@@ -183,7 +190,7 @@ gscan_kernel(const GScanParams p) {
         for (uint32_t i = (uint32_t)lane_now(); i < cnt; i += 64) {
             const uint2 e = wbuf[i];
             if ((e.y & 0xffffffu) >= nrows) continue;           // a row past the end of the range (zeros of a partial last tile)
-            const uint32_t qq = (uint32_t)(col * GS_TILE) + (e.y >> 24);
+            const uint32_t qq = (uint32_t)(col * CW) + (e.y >> 24);
             const uint32_t gs = atomicAdd(&p.gcnt[qq], 1u);
             if (gs < (uint32_t)p.gcap) p.lists[(size_t)qq * p.gcap + gs] = make_uint2(e.x, (uint32_t)begin + (e.y & 0xffffffu));
             else p.qflag[qq] = 1u;                      // the list is full (mass ties, no usable threshold): exact path
@@ -191,11 +198,11 @@ gscan_kernel(const GScanParams p) {
         cnt = 0;
     };
 
-    f32x4 acc[8][4];
+    f32x4 acc[8][FB];
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < FB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto epilogue = [&](const int ti) __attribute__((always_inline)) {
         if (SCAN) {
@@ -206,19 +213,19 @@ gscan_kernel(const GScanParams p) {
 #pragma unroll
             for (int a = 0; a < 8; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
+                for (int b = 0; b < FB; ++b) {
                     const f32x4 v = acc[a][b];
                     float m;
                     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(v[0]), "v"(v[1]), "v"(v[2]));      // (fmaxf: two canonicalising v_max more)
                     const uint64_t any = __builtin_amdgcn_ballot_w64(m > th[b]) | __builtin_amdgcn_ballot_w64(v[3] > th[b]);
-                    hit |= (any != 0ull ? 1u : 0u) << (a * 4 + b);
+                    hit |= (any != 0ull ? 1u : 0u) << (a * FB + b);
                 }
             GS_ESTAMP(1);
             if (hit != 0u) {
                 // (everything lane-derived is formed HERE from a lane id hipcc cannot trace back: hoisted over the k-loop -- which runs at the
                 //  register cap: 128 accumulators + 96 fragment registers -- it would push fragments into scratch)
                 const int ln = lane_now(), lr_e = ln & 15, lg_e = ln >> 4;
-                const uint32_t tag0 = ((uint32_t)(wj * 64 + lr_e) << 24) | (uint32_t)((p.tile_begin + ti) * GS_TILE + wi * 128 + lg_e * 4);   // (query << 24) | row relative to `begin` (< 2^24) of acc[0][0][0]
+                const uint32_t tag0 = ((uint32_t)(wj * QW + lr_e) << 24) | (uint32_t)((p.tile_begin + ti) * GS_TILE + wi * 128 + lg_e * 4);   // (query << 24) | row relative to `begin` (< 2^24) of acc[0][0][0]
                 const uint32_t wb = lds0 + 4 * GS_STG + (uint32_t)wave * (GS_WBUF_ENTRIES * 8);
                 if (cnt > GS_WBUF_REAL / 2) flush();
                 // (2) passing scores take the buffer slots cnt, cnt + 1, ... in walk order (ballot prefix counts: no atomics, no barrier). A
@@ -235,10 +242,10 @@ gscan_kernel(const GScanParams p) {
                 uint32_t lost = 0;                      // bit b: a passing score of the lane's query column b found no slot
 #pragma unroll
                 for (int a = 0; a < 8; ++a) {
-                    if ((hit & (0xfu << (a * 4))) == 0u) continue;
+                    if ((hit & (((1u << FB) - 1u) << (a * FB))) == 0u) continue;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        if ((hit & (1u << (a * 4 + b))) == 0u) continue;
+                    for (int b = 0; b < FB; ++b) {
+                        if ((hit & (1u << (a * FB + b))) == 0u) continue;
                         const f32x4 v = acc[a][b];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -259,8 +266,8 @@ gscan_kernel(const GScanParams p) {
                 if (cnt > GS_WBUF_REAL - 1) {           // entries were lost: exactly the queries that lost one take the exact path
                     cnt = GS_WBUF_REAL - 1;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        if (lost & (1u << b)) p.qflag[col * GS_TILE + wj * 64 + b * 16 + lr_e] = 1u;
+                    for (int b = 0; b < FB; ++b)
+                        if (lost & (1u << b)) p.qflag[col * CW + wj * QW + b * 16 + lr_e] = 1u;
                 }
             }
             GS_ESTAMP(2);
@@ -270,17 +277,17 @@ gscan_kernel(const GScanParams p) {
 #endif
         } else {
             const int ts = range + ti * nranges;
-            const size_t ldq = (size_t)p.ncol * GS_TILE;
+            const size_t ldq = (size_t)p.ncol * CW;
             const int ln = lane_now(), lr_e = ln & 15, lg_e = ln >> 4;
 #pragma unroll
             for (int a = 0; a < 8; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
+                for (int b = 0; b < FB; ++b) {
                     const f32x4 v = acc[a][b];
                     float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
                     m = fmaxf(m, __shfl_xor(m, 16));
                     m = fmaxf(m, __shfl_xor(m, 32));
-                    if (lg_e == 0) p.smax[((size_t)ts * GS_FRAG_PER_TILE + wi * 8 + a) * ldq + (size_t)(col * GS_TILE + wj * 64 + b * 16 + lr_e)] = m;
+                    if (lg_e == 0) p.smax[((size_t)ts * GS_FRAG_PER_TILE + wi * 8 + a) * ldq + (size_t)(col * CW + wj * QW + b * 16 + lr_e)] = m;
                 }
         }
     };
@@ -311,24 +318,41 @@ gscan_kernel(const GScanParams p) {
         // of its multiply phase
         if (!grpB && it + 1 < total_it) stage(buf ^ 1, it + 1);
         __builtin_amdgcn_sched_barrier(0);
-        gs_u4 fs0[8], fq0[4], fs1[8], fq1[4];
+        gs_u4 fs0[8], fq0[FB], fs1[8], fq1[FB];
         {
             // (inline asm: hipcc's wait insertion would drain vmcnt(0) in front of any ds_read it sees behind an LDS-DMA it cannot prove disjoint)
             const uint32_t s0 = as0 + buf * GS_STG, s1 = as1 + buf * GS_STG, q0 = aq0 + buf * GS_STG, q1 = aq1 + buf * GS_STG;
-            asm volatile(
-                "ds_read_b128 %0, %24\n ds_read_b128 %1, %24 offset:2048\n ds_read_b128 %2, %24 offset:4096\n ds_read_b128 %3, %24 offset:6144\n"
-                "ds_read_b128 %4, %24 offset:8192\n ds_read_b128 %5, %24 offset:10240\n ds_read_b128 %6, %24 offset:12288\n ds_read_b128 %7, %24 offset:14336\n"
-                "ds_read_b128 %8, %25\n ds_read_b128 %9, %25 offset:2048\n ds_read_b128 %10, %25 offset:4096\n ds_read_b128 %11, %25 offset:6144\n"
-                "ds_read_b128 %12, %26\n ds_read_b128 %13, %26 offset:2048\n ds_read_b128 %14, %26 offset:4096\n ds_read_b128 %15, %26 offset:6144\n"
-                "ds_read_b128 %16, %26 offset:8192\n ds_read_b128 %17, %26 offset:10240\n ds_read_b128 %18, %26 offset:12288\n ds_read_b128 %19, %26 offset:14336\n"
-                "ds_read_b128 %20, %27\n ds_read_b128 %21, %27 offset:2048\n ds_read_b128 %22, %27 offset:4096\n ds_read_b128 %23, %27 offset:6144\n"
-                "s_waitcnt lgkmcnt(0)"
-                : "=&v"(fs0[0]), "=&v"(fs0[1]), "=&v"(fs0[2]), "=&v"(fs0[3]), "=&v"(fs0[4]), "=&v"(fs0[5]), "=&v"(fs0[6]), "=&v"(fs0[7]),
-                  "=&v"(fq0[0]), "=&v"(fq0[1]), "=&v"(fq0[2]), "=&v"(fq0[3]),
-                  "=&v"(fs1[0]), "=&v"(fs1[1]), "=&v"(fs1[2]), "=&v"(fs1[3]), "=&v"(fs1[4]), "=&v"(fs1[5]), "=&v"(fs1[6]), "=&v"(fs1[7]),
-                  "=&v"(fq1[0]), "=&v"(fq1[1]), "=&v"(fq1[2]), "=&v"(fq1[3])
-                : "v"(s0), "v"(q0), "v"(s1), "v"(q1)
-                : "memory");
+            if constexpr (FB == 4) {
+                asm volatile(
+                    "ds_read_b128 %0, %24\n ds_read_b128 %1, %24 offset:2048\n ds_read_b128 %2, %24 offset:4096\n ds_read_b128 %3, %24 offset:6144\n"
+                    "ds_read_b128 %4, %24 offset:8192\n ds_read_b128 %5, %24 offset:10240\n ds_read_b128 %6, %24 offset:12288\n ds_read_b128 %7, %24 offset:14336\n"
+                    "ds_read_b128 %8, %25\n ds_read_b128 %9, %25 offset:2048\n ds_read_b128 %10, %25 offset:4096\n ds_read_b128 %11, %25 offset:6144\n"
+                    "ds_read_b128 %12, %26\n ds_read_b128 %13, %26 offset:2048\n ds_read_b128 %14, %26 offset:4096\n ds_read_b128 %15, %26 offset:6144\n"
+                    "ds_read_b128 %16, %26 offset:8192\n ds_read_b128 %17, %26 offset:10240\n ds_read_b128 %18, %26 offset:12288\n ds_read_b128 %19, %26 offset:14336\n"
+                    "ds_read_b128 %20, %27\n ds_read_b128 %21, %27 offset:2048\n ds_read_b128 %22, %27 offset:4096\n ds_read_b128 %23, %27 offset:6144\n"
+                    "s_waitcnt lgkmcnt(0)"
+                    : "=&v"(fs0[0]), "=&v"(fs0[1]), "=&v"(fs0[2]), "=&v"(fs0[3]), "=&v"(fs0[4]), "=&v"(fs0[5]), "=&v"(fs0[6]), "=&v"(fs0[7]),
+                      "=&v"(fq0[0]), "=&v"(fq0[1]), "=&v"(fq0[2]), "=&v"(fq0[3]),
+                      "=&v"(fs1[0]), "=&v"(fs1[1]), "=&v"(fs1[2]), "=&v"(fs1[3]), "=&v"(fs1[4]), "=&v"(fs1[5]), "=&v"(fs1[6]), "=&v"(fs1[7]),
+                      "=&v"(fq1[0]), "=&v"(fq1[1]), "=&v"(fq1[2]), "=&v"(fq1[3])
+                    : "v"(s0), "v"(q0), "v"(s1), "v"(q1)
+                    : "memory");
+            } else {
+                asm volatile(
+                    "ds_read_b128 %0, %20\n ds_read_b128 %1, %20 offset:2048\n ds_read_b128 %2, %20 offset:4096\n ds_read_b128 %3, %20 offset:6144\n"
+                    "ds_read_b128 %4, %20 offset:8192\n ds_read_b128 %5, %20 offset:10240\n ds_read_b128 %6, %20 offset:12288\n ds_read_b128 %7, %20 offset:14336\n"
+                    "ds_read_b128 %8, %21\n ds_read_b128 %9, %21 offset:2048\n"
+                    "ds_read_b128 %10, %22\n ds_read_b128 %11, %22 offset:2048\n ds_read_b128 %12, %22 offset:4096\n ds_read_b128 %13, %22 offset:6144\n"
+                    "ds_read_b128 %14, %22 offset:8192\n ds_read_b128 %15, %22 offset:10240\n ds_read_b128 %16, %22 offset:12288\n ds_read_b128 %17, %22 offset:14336\n"
+                    "ds_read_b128 %18, %23\n ds_read_b128 %19, %23 offset:2048\n"
+                    "s_waitcnt lgkmcnt(0)"
+                    : "=&v"(fs0[0]), "=&v"(fs0[1]), "=&v"(fs0[2]), "=&v"(fs0[3]), "=&v"(fs0[4]), "=&v"(fs0[5]), "=&v"(fs0[6]), "=&v"(fs0[7]),
+                      "=&v"(fq0[0]), "=&v"(fq0[1]),
+                      "=&v"(fs1[0]), "=&v"(fs1[1]), "=&v"(fs1[2]), "=&v"(fs1[3]), "=&v"(fs1[4]), "=&v"(fs1[5]), "=&v"(fs1[6]), "=&v"(fs1[7]),
+                      "=&v"(fq1[0]), "=&v"(fq1[1])
+                    : "v"(s0), "v"(q0), "v"(s1), "v"(q1)
+                    : "memory");
+            }
         }
         GS_STAMP(1);
         if (grpB) __builtin_amdgcn_s_waitcnt(0x0F70);  // B: its pieces of k-tile it + 1 (issued a phase ago) have landed
@@ -344,19 +368,19 @@ gscan_kernel(const GScanParams p) {
 #pragma unroll
             for (int a = 0; a < 8; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < FB; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fs0[a]), __builtin_bit_cast(f16x8, fq0[b]), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         } else {
 #pragma unroll
             for (int a = 0; a < 8; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < FB; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fs0[a]), __builtin_bit_cast(f16x8, fq0[b]), acc[a][b], 0, 0, 0);
         }
 #pragma unroll
         for (int a = 0; a < 8; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+            for (int b = 0; b < FB; ++b)
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fs1[a]), __builtin_bit_cast(f16x8, fq1[b]), acc[a][b], 0, 0, 0);
         if (CERT) {
             // row sums of squares: this wave's two of the eight fragments of its slab rows (the lane holds 8 + 8 of a row's 64 elements of this k-tile)

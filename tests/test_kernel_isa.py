@@ -71,18 +71,18 @@ def test_gemm_shaped_scan_has_a_clean_k_loop():
     three instantiations carry no private segment; the 64 MFMAs of
     a k-tile are free of vector-memory waits and every LDS-DMA descriptor lives in SGPRs (no readfirstlane loop around a DMA)"""
     fns = {k: v for k, v in _functions(_asm("atlas_hip")).items() if "gscan_kernelILi" in k}
-    assert len(fns) == 3, sorted(fns)                        # scan, sample, certifying scan
+    assert len(fns) == 6, sorted(fns)                        # scan, sample, certifying scan x the 256- and the 128-query column tile
     for name, body in fns.items():
-        cert = "ILi2E" in name
+        fb = 4 if "ELi4EEE" in name else 2
         assert _scratch_bytes(body) == 0 and "scratch_" not in body, (name, _scratch_bytes(body))
         lines = [l.strip() for l in body.split("\n")]
         mf = [i for i, l in enumerate(lines) if l.startswith("v_mfma")]
-        assert len(mf) == 96, (name, len(mf))                # the k-step of a tile's first k-tile (C = 0) and the two of every k-tile
-        # the last 64 MFMAs = the accumulate k-step pair of the steady loop: nothing but MFMAs (and the certifying twin's v_dot2) in between
-        loop = lines[mf[32]:mf[-1] + 1]
+        assert len(mf) == 24 * fb, (name, len(mf))           # the k-step of a tile's first k-tile (C = 0) and the two of every k-tile
+        # the last 16 x fb MFMAs = the accumulate k-step pair of the steady loop: nothing but MFMAs (and the certifying twin's v_dot2) in between
+        loop = lines[mf[8 * fb]:mf[-1] + 1]
         assert not any(l.startswith(("s_waitcnt", "scratch_", "buffer_", "global_", "ds_")) for l in loop), name
         dma = [i for i, l in enumerate(lines) if l.startswith("buffer_load_dwordx4") and " lds" in l]
-        assert len(dma) >= 32, (name, len(dma))
+        assert len(dma) >= 8 * fb, (name, len(dma))
         assert body.count("v_readfirstlane_b32") <= 6, (name, body.count("v_readfirstlane_b32"))   # the wave index and the clamped query rows, not descriptors
 
 

@@ -1,6 +1,6 @@
 """Batches above 96 queries: the streaming passes of round 3 (64 / 96-query passes, single or paired) vs the GEMM-shaped passes (gscan_kernel.h), same
 process (tuning build), results compared bit for bit.
-    python tools/batch_gemm_ab.py [rows, default 4000000 and 32000000] [--k K]"""
+    python tools/batch_gemm_ab.py [rows, default 4000000 and 32000000] [--k K] [--batches 97,128,...] [--modes 0,1]"""
 import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
 from _tune import L  # noqa: E402
 import sys, time
@@ -16,6 +16,9 @@ if "--k" in args:
 modes = (0, 1)
 if "--modes" in args:      # 0 = streaming passes, 1 = gscan_kernel, 2 = gscan2_kernel (experiment: the slab through a register ring)
     i = args.index("--modes"); modes = tuple(int(x) for x in args[i + 1].split(",")); del args[i:i + 2]
+batches = (64, 96, 128, 192, 256, 384, 512, 1024)
+if "--batches" in args:
+    i = args.index("--batches"); batches = tuple(int(x) for x in args[i + 1].split(",")); del args[i:i + 2]
 sizes = [int(a) for a in args] or [4_000_000, 32_000_000]
 NMAX = max(sizes)
 g = torch.Generator(device="cuda").manual_seed(1)
@@ -24,7 +27,7 @@ for r0 in range(0, NMAX, 1_000_000):
     n = min(1_000_000, NMAX - r0); x = torch.randn((n, D), generator=g, device="cuda"); slab[r0:r0 + n] = (x / x.norm(dim=1, keepdim=True)).half()
 stream = torch.cuda.current_stream().cuda_stream
 for N in sizes:
-    for B in (64, 96, 128, 192, 256, 384, 512, 1024):
+    for B in batches:
         q = torch.randn((B, D), generator=torch.Generator(device="cuda").manual_seed(99), device="cuda").half()
         out_s = torch.empty((B, k), dtype=torch.float16, device="cuda"); out_i = torch.empty((B, k), dtype=torch.int64, device="cuda")
         out_st = torch.empty(_lib.STATUS_HEADER + B, dtype=torch.int32, device="cuda")
