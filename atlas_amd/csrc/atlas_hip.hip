@@ -663,15 +663,21 @@ ExactPlan make_exact_plan(int64_t N, int d, int k, int B) {
 
 // The GEMM-shaped pass of big batches (gscan_kernel.h). One pass takes up to GS_MAXQ queries as ncol = 1, 2 or 4 column tiles of 256.
 constexpr int GS_MAXQ = 1024;
-#ifndef GS_COST_128
-#define GS_COST_128 1.32f          // a pass of up to 128 queries on the 128-wide tile, in units of a 64-query pass (1.37 ms vs 1.06 ms at 4M rows: its
-                                   // k-tile streams the slab at ~5.3 TB/s, the HBM roof, not the MFMA one; profiles/r04/batch_gemm_pass_ab_128wide.txt)
+// Pass widths of the GEMM-shaped scan: column tiles of 128 / 192 / 256 queries (gscan_kernel<., 2 | 3 | 4>) x 1, 2 or 4 of them. A pass takes
+// the narrowest width that holds its queries; GS_COSTS = measured cost in units of one 64-query pass (1.06 ms at 4M rows:
+// profiles/r04/batch_gemm_pass_ab_tile_widths.txt). The 128-wide tile's k-tile streams the slab at ~5.3 TB/s: the HBM roof, not the MFMA one.
+// (Four column tiles of 192 = 768 queries: measured 5.06 ms at 4M rows, a 512- plus a 256-query pass 4.85 ms -- not a width.)
+constexpr int GS_NW = 6;
+constexpr int GS_WIDTH[GS_NW] = {128, 192, 256, 384, 512, 1024};
+constexpr int GS_CW[GS_NW] = {128, 192, 256, 192, 256, 256};
+#ifndef GS_COSTS
+#define GS_COSTS {1.28f, 1.44f, 1.61f, 2.55f, 2.96f, 5.53f}
 #endif
 constexpr size_t GS_OFF_QFLAG = 800u << 10;     // its per-query fallback flags: state words (zero between calls) behind the coop scan's granules
 static_assert(GS_OFF_QFLAG >= 512 + 256 + 512 + 1024 + (size_t)QWIDE * 1024 * 8 && GS_OFF_QFLAG + GS_MAXQ * 4 <= PAIR_STATE, "inside the first chunk's state");
 struct GPlan {
     bool ok;
-    int G, ncol, ldq, cw;                           // cw: queries per column tile: 256, or 128 for passes of up to 128 queries (gscan_kernel<., 2>)
+    int G, ncol, ldq, cw;                           // cw: queries per column tile (128, 192 or 256)
     int64_t rows_per_range;
     int s_tiles, nmax; int64_t s_stride;
     int gcap;
@@ -680,8 +686,9 @@ struct GPlan {
 GPlan make_gplan(int64_t N, int nq, int cus) {
     GPlan g{};
     int ncol = 1;
-    g.cw = nq <= GS_TILE / 2 ? GS_TILE / 2 : GS_TILE;
-    while (ncol * g.cw < nq) ncol *= 2;
+    int wi = 0;
+    while (wi + 1 < GS_NW && GS_WIDTH[wi] < nq) ++wi;
+    g.cw = GS_CW[wi]; ncol = GS_WIDTH[wi] / g.cw;
     g.ncol = ncol; g.ldq = ncol * g.cw;
     g.G = cus / (8 * ncol) * (8 * ncol);
     const int64_t full_tiles = N / GS_TILE, tiles = (N + GS_TILE - 1) / GS_TILE;
@@ -855,21 +862,24 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
         pair_ok = pp.S > 0 && pp.G == half && scan_plan_supported(pp, wide_ok ? 25 : 26) && ws_bytes >= pp.bulk_begin + 2 * pp.bulk_size;
     }
     const bool pair_wide_ok = pair_ok && wide_ok && half >= QWIDE;
-    bool gemm_ok[4] = {false, false, false, false};          // passes of up to 128 (the 128-wide tile), 256, 512, 1024 queries
+    bool gemm_ok[GS_NW] = {}, any_gemm = false;
     if (B > QWIDE && scan_variant_index() == 0 && scan_gemm_enabled()) {
-        for (int i = 0; i < 4; ++i) {
-            const GPlan g = make_gplan(N, (GS_TILE / 2) << i, device_cus());
+        for (int i = 0; i < GS_NW; ++i) {
+            const GPlan g = make_gplan(N, GS_WIDTH[i], device_cus());
             gemm_ok[i] = g.ok && ws_bytes >= g.total;
+            any_gemm = any_gemm || gemm_ok[i];
         }
     }
-    if (B <= QCHUNK || (!wide_ok && !pair_ok && !gemm_ok[1])) {
+    if (B <= QCHUNK || (!wide_ok && !pair_ok && !any_gemm)) {
         for (int r = B; r > 0; r -= QCHUNK) passes.push_back({r < QCHUNK ? r : QCHUNK, 0, false, false});
     } else {
         // costs in units of one 64-query pass (measured at 4M and 32M rows: profiles/r03/batch_paired_pass_ab.txt, profiles/r04/batch_gemm_pass_ab.txt)
-        constexpr int NI = 8;
-        const float cost[NI] = {1.0f, 1.11f, 1.62f, 1.89f, 1.56f, 2.86f, 5.40f, GS_COST_128};
-        const int size[NI] = {QCHUNK, QWIDE, 2 * QCHUNK, 2 * QWIDE, GS_TILE, 2 * GS_TILE, 4 * GS_TILE, GS_TILE / 2};
-        const bool ok[NI] = {true, wide_ok, pair_ok, pair_wide_ok, gemm_ok[1], gemm_ok[2], gemm_ok[3], gemm_ok[0]};
+        constexpr int NI = 4 + GS_NW;
+        const float gcost[GS_NW] = GS_COSTS;
+        float cost[NI] = {1.0f, 1.11f, 1.62f, 1.89f};
+        int size[NI] = {QCHUNK, QWIDE, 2 * QCHUNK, 2 * QWIDE};
+        bool ok[NI] = {true, wide_ok, pair_ok, pair_wide_ok};
+        for (int i = 0; i < GS_NW; ++i) { cost[4 + i] = gcost[i]; size[4 + i] = GS_WIDTH[i]; ok[4 + i] = gemm_ok[i]; }
         std::vector<float> f((size_t)B + 1, 0.f);
         std::vector<unsigned char> take((size_t)B + 1, 0);
         for (int n = 1; n <= B; ++n) {
@@ -877,8 +887,7 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
             for (int it = 0; it < NI; ++it) {
                 if (!ok[it]) continue;
                 if ((it == 2 || it == 3) && n <= size[it - 2]) continue;     // a pair needs more queries than one pass of its kind takes
-                if ((it == 5 || it == 6) && n <= size[it - 1]) continue;     // a column tile more than the queries fill
-                if (it == 4 && gemm_ok[0] && n <= GS_TILE / 2) continue;     // (up to 128 queries: the 128-wide tile)
+                if (it > 4 && ok[it - 1] && n <= size[it - 1]) continue;     // a wider pass than the queries need
                 const float c = cost[it] + f[n > size[it] ? n - size[it] : 0];
                 if (c < best) { best = c; take[n] = (unsigned char)it; }
             }
@@ -912,9 +921,10 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
         if (passes[ci].gemm) {
             // GEMM-shaped pass: queries -> fp16 rows, sample launch -> fragment maxima, thresholds, scan launch, merge (flat lists)
             const GPlan g = make_gplan(N, nq, device_cus());
-            auto gsample = g.cw == GS_TILE ? gscan_kernel<1, 4> : gscan_kernel<1, 2>;
-            auto gscan = g.cw == GS_TILE ? (trusted ? gscan_kernel<0, 4> : gscan_kernel<2, 4>)          // <2, .>: the twin that measures every row norm
-                                         : (trusted ? gscan_kernel<0, 2> : gscan_kernel<2, 2>);
+            auto gsample = g.cw == 256 ? gscan_kernel<1, 4> : g.cw == 192 ? gscan_kernel<1, 3> : gscan_kernel<1, 2>;
+            auto gscan = g.cw == 256 ? (trusted ? gscan_kernel<0, 4> : gscan_kernel<2, 4>)          // <2, .>: the twin that measures every row norm
+                       : g.cw == 192 ? (trusted ? gscan_kernel<0, 3> : gscan_kernel<2, 3>)
+                                     : (trusted ? gscan_kernel<0, 2> : gscan_kernel<2, 2>);
             size_t g_lds = GS_LDS_BYTES;
 #if ATLAS_TUNING
             if (g_scan_gemm == 2) {                    // experiment: the slab through a register ring (gscan2_kernel.h)

@@ -81,16 +81,17 @@ typedef unsigned int gs_u4 __attribute__((ext_vector_type(4)));
 // MODE 0 = scan (filter epilogue), 1 = sample (fragment maxima), 2 = scan that also MEASURES every row's norm (the certifying twin: the caller's
 // pmax is a hint, atlas_scan_topk's default contract). The four waves that share a slab fragment row split its eight fragments: 16 v_dot2
 // per k-tile and wave beside its 64 MFMAs.
-// FB = 16-query fragments per wave: 4 -> the column tile is 256 queries wide (a wave owns 128 rows x 64 queries); 2 -> 128 queries wide (128 x 32:
-// half the MFMAs per k-tile and 48 instead of 64 LDS-DMA pieces -- the tile of batches of 97..128 queries, which a half-empty 256-wide tile would
-// serve at the cost of 256)
+// FB = 16-query fragments per wave: 4 -> the column tile is 256 queries wide (a wave owns 128 rows x 64 queries); 3 -> 192 wide; 2 -> 128 wide
+// (128 x 32: half the MFMAs per k-tile and 48 instead of 64 LDS-DMA pieces). The narrower tiles serve the pass widths a 256-wide tile would
+// leave part empty at the full cost: 97..128 and 129..192 queries, and -- two or four column tiles of 192 -- 257..384 and 513..768.
 template <int MODE, int FB = 4>
 __global__ void __launch_bounds__(512)
 gscan_kernel(const GScanParams p) {
     constexpr int QW = 16 * FB;                        // queries per wave
     constexpr int CW = 4 * QW;                         // queries per column tile
-    constexpr int QPIECES = CW / 8;                    // LDS-DMA pieces of a k-tile's queries: 32 | 16
-    constexpr int QA = FB == 4 ? GS_PIECES_A - 8 : 1;  // ... of them issued by a wave of group A (group B: QPIECES / 4 - QA)
+    constexpr int QPIECES = CW / 8;                    // LDS-DMA pieces of a k-tile's queries: 32 | 24 | 16
+    constexpr int QA = FB == 4 ? GS_PIECES_A - 8 : FB - 1;  // ... of them issued by a wave of group A (group B: QPIECES / 4 - QA)
+    static_assert(FB >= 2 && FB <= 4, "column tiles of 128, 192 or 256 queries");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // S0 | S1 | Q0 | Q1 (32 KiB each) | 8 wave buffers
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -335,6 +336,21 @@ gscan_kernel(const GScanParams p) {
                       "=&v"(fq0[0]), "=&v"(fq0[1]), "=&v"(fq0[2]), "=&v"(fq0[3]),
                       "=&v"(fs1[0]), "=&v"(fs1[1]), "=&v"(fs1[2]), "=&v"(fs1[3]), "=&v"(fs1[4]), "=&v"(fs1[5]), "=&v"(fs1[6]), "=&v"(fs1[7]),
                       "=&v"(fq1[0]), "=&v"(fq1[1]), "=&v"(fq1[2]), "=&v"(fq1[3])
+                    : "v"(s0), "v"(q0), "v"(s1), "v"(q1)
+                    : "memory");
+            } else if constexpr (FB == 3) {
+                asm volatile(
+                    "ds_read_b128 %0, %22\n ds_read_b128 %1, %22 offset:2048\n ds_read_b128 %2, %22 offset:4096\n ds_read_b128 %3, %22 offset:6144\n"
+                    "ds_read_b128 %4, %22 offset:8192\n ds_read_b128 %5, %22 offset:10240\n ds_read_b128 %6, %22 offset:12288\n ds_read_b128 %7, %22 offset:14336\n"
+                    "ds_read_b128 %8, %23\n ds_read_b128 %9, %23 offset:2048\n ds_read_b128 %10, %23 offset:4096\n"
+                    "ds_read_b128 %11, %24\n ds_read_b128 %12, %24 offset:2048\n ds_read_b128 %13, %24 offset:4096\n ds_read_b128 %14, %24 offset:6144\n"
+                    "ds_read_b128 %15, %24 offset:8192\n ds_read_b128 %16, %24 offset:10240\n ds_read_b128 %17, %24 offset:12288\n ds_read_b128 %18, %24 offset:14336\n"
+                    "ds_read_b128 %19, %25\n ds_read_b128 %20, %25 offset:2048\n ds_read_b128 %21, %25 offset:4096\n"
+                    "s_waitcnt lgkmcnt(0)"
+                    : "=&v"(fs0[0]), "=&v"(fs0[1]), "=&v"(fs0[2]), "=&v"(fs0[3]), "=&v"(fs0[4]), "=&v"(fs0[5]), "=&v"(fs0[6]), "=&v"(fs0[7]),
+                      "=&v"(fq0[0]), "=&v"(fq0[1]), "=&v"(fq0[2]),
+                      "=&v"(fs1[0]), "=&v"(fs1[1]), "=&v"(fs1[2]), "=&v"(fs1[3]), "=&v"(fs1[4]), "=&v"(fs1[5]), "=&v"(fs1[6]), "=&v"(fs1[7]),
+                      "=&v"(fq1[0]), "=&v"(fq1[1]), "=&v"(fq1[2])
                     : "v"(s0), "v"(q0), "v"(s1), "v"(q1)
                     : "memory");
             } else {

@@ -77,7 +77,8 @@ def test_batches_above_64_queries_bit_exact_vs_oracle(N, B, k, ps, gpu_index_cls
 
 @pytest.mark.parametrize("N,B,k,ps,certify", [(150000, 128, 40, 321, 0), (100000, 256, 100, 322, 0), (70000, 512, 256, 323, 0), (66000, 300, 40, 324, 0),
                                              (150000, 128, 100, 325, 1), (100000, 384, 40, 326, 1), (70000, 512, 256, 327, 1),
-                                             (120000, 97, 40, 328, 0), (90000, 113, 100, 329, 1), (80000, 320, 40, 330, 0)])
+                                             (120000, 97, 40, 328, 0), (90000, 113, 100, 329, 1), (80000, 320, 40, 330, 0),
+                                             (110000, 192, 40, 331, 0), (90000, 160, 100, 332, 1), (80000, 384, 40, 333, 0), (70000, 700, 40, 334, 1)])
 def test_gemm_shaped_passes_bit_exact_vs_oracle(N, B, k, ps, certify, gpu_index_cls, oracle_mod):
     """batches above 96 queries on the GEMM-shaped passes (one / two column tiles of 256 queries, partial tiles, the tail range shorter than
     the others, k = 40 / 100 / 256), the twin that trusts pmax and the one that measures every row norm (certify_every = 1: the C-ABI's

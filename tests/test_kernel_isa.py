@@ -71,9 +71,9 @@ def test_gemm_shaped_scan_has_a_clean_k_loop():
     three instantiations carry no private segment; the 64 MFMAs of
     a k-tile are free of vector-memory waits and every LDS-DMA descriptor lives in SGPRs (no readfirstlane loop around a DMA)"""
     fns = {k: v for k, v in _functions(_asm("atlas_hip")).items() if "gscan_kernelILi" in k}
-    assert len(fns) == 6, sorted(fns)                        # scan, sample, certifying scan x the 256- and the 128-query column tile
+    assert len(fns) == 9, sorted(fns)                        # scan, sample, certifying scan x the 256-, 192- and 128-query column tile
     for name, body in fns.items():
-        fb = 4 if "ELi4EEE" in name else 2
+        fb = int(re.search(r"ELi(\d)EEE", name).group(1))
         assert _scratch_bytes(body) == 0 and "scratch_" not in body, (name, _scratch_bytes(body))
         lines = [l.strip() for l in body.split("\n")]
         mf = [i for i, l in enumerate(lines) if l.startswith("v_mfma")]
