@@ -40,7 +40,9 @@ namespace atlas {
 #define GS_LDS_BYTES (4 * GS_STG + 8 * GS_WBUF_ENTRIES * 8)     // 159 744
 #define GTHETA_LDS(nmax) (64 + 4096 + (size_t)(nmax) * 4)
 #define GTHETA_MAXKEYS 32768
+#ifndef GS_PIECES_A
 #define GS_PIECES_A 11            // LDS-DMA pieces per k-tile of a wave of group A (of 16 per pair of waves; see `stage`)
+#endif
 #define GS_FRAG_PER_TILE 16       // 16-row fragments of a tile: the sample keeps one maximum per fragment and query
 
 struct GScanParams {
@@ -77,6 +79,17 @@ struct GScanParams {
 #endif
 
 typedef unsigned int gs_u4 __attribute__((ext_vector_type(4)));
+template <int B, int E, class F>
+static __device__ __forceinline__ void gs_static_for(F&& f) {           // f(integral_constant<int, B>) ... f(integral_constant<int, E - 1>)
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); gs_static_for<B + 1, E>(f); }
+}
+template <int OFF>
+static __device__ __forceinline__ void gs_ds_read(gs_u4& dst, const uint32_t addr) {      // issued, NOT waited for
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+#ifndef GS_INTERLEAVE
+#define GS_INTERLEAVE 1
+#endif
 
 // MODE 0 = scan (filter epilogue), 1 = sample (fragment maxima), 2 = scan that also MEASURES every row's norm (the certifying twin: the caller's
 // pmax is a hint, atlas_scan_topk's default contract). The four waves that share a slab fragment row split its eight fragments: 16 v_dot2
@@ -141,7 +154,7 @@ gscan_kernel(const GScanParams p) {
     // two query pieces left in front of B's MFMAs: the ~500 cycles in front of the MFMAs shrink neither with the piece count nor with the
     // descriptor arithmetic moved in front of the barrier (the first DMA issue behind a barrier is what costs); 2.5 % slower:
     // profiles/r04/gscan_phases_512_phase_aware_pieces.txt)
-    auto stage = [&](const int buf, const int it) __attribute__((always_inline)) {
+    auto stage = [&](const int buf, const int it, auto&& between) __attribute__((always_inline)) {
         // (both descriptors are formed HERE, SGPR arithmetic: a descriptor carried across the k-loop ends up in VGPRs and every DMA in a
         //  readfirstlane loop)
         const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(p.q16 + (size_t)col * CW * D_FAST), 0, qrows * ROWB, 0x00020000);
@@ -158,10 +171,14 @@ gscan_kernel(const GScanParams p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(smem + op * 2 * GS_STG + buf * GS_STG + rg * 1024), 16, (int)(vo + (uint32_t)(rg * 8 * ROWB)), kb, 0, 0);
         };
         if (!grpB) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) piece(rs, 0, w4 + 4 * j);
-#pragma unroll
-            for (int j = 0; j < QA; ++j) piece(rq, 1, w4 + 4 * j);
+            // (group A issues from its read phase: each piece is followed by its share of the phase's fragment reads -- a piece holds the
+            //  wave's issue for ~95 cycles, the TIME the vector-memory unit takes to accept the next one, and a ds_read issued in that
+            //  shadow costs nothing; behind all pieces the reads were another ~700 cycles of the phase)
+            gs_static_for<0, 8 + QA>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i < 8) piece(rs, 0, w4 + 4 * i); else piece(rq, 1, w4 + 4 * (i - 8));
+                between(ic);
+            });
         } else {
 #pragma unroll
             for (int j = 0; j < QPIECES / 4 - QA; ++j) piece(rq, 1, 4 * QA + w4 + 4 * j);
@@ -299,11 +316,12 @@ gscan_kernel(const GScanParams p) {
     // One flat loop over the k-tiles of ALL tiles of the workgroup: the staging runs straight through the tile boundaries. The epilogue of a
     // tile needs no barrier and no stage buffer: a group runs it behind the barrier that ends its tile's last multiply phase, while the
     // other group is still multiplying or already reading.
-    stage(0, 0);
+    auto nothing = [](auto) __attribute__((always_inline)) {};
+    stage(0, 0, nothing);
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's pieces of k-tile 0 have landed
     __builtin_amdgcn_s_barrier();
     if (grpB) {                                        // B's phase 0: nothing to multiply yet
-        if (total_it > 1) stage(1, 1);
+        if (total_it > 1) stage(1, 1, nothing);
         __builtin_amdgcn_s_barrier();
     }
     int kt = 0, ti = 0;
@@ -317,12 +335,35 @@ gscan_kernel(const GScanParams p) {
         GS_STAMP(0);
         // A's pieces of k-tile it + 1 go out FIRST, in front of its reads: they come from HBM (~2k cycles to land) and A waits for them at the end
         // of its multiply phase
-        if (!grpB && it + 1 < total_it) stage(buf ^ 1, it + 1);
-        __builtin_amdgcn_sched_barrier(0);
         gs_u4 fs0[8], fq0[FB], fs1[8], fq1[FB];
-        {
+        const uint32_t s0 = as0 + buf * GS_STG, s1 = as1 + buf * GS_STG, q0 = aq0 + buf * GS_STG, q1 = aq1 + buf * GS_STG;
+        constexpr int NR = 16 + 2 * FB, NP = 8 + QA;   // fragment reads of a phase, group A's pieces of a k-tile
+        const bool a_stages = GS_INTERLEAVE && !grpB && it + 1 < total_it;
+        if (a_stages) {
+            stage(buf ^ 1, it + 1, [&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                gs_static_for<i * NR / NP, (i + 1) * NR / NP>([&](auto kc) __attribute__((always_inline)) {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (k < 8) gs_ds_read<k * 2048>(fs0[k], s0);
+                    else if constexpr (k < 8 + FB) gs_ds_read<(k - 8) * 2048>(fq0[k - 8], q0);
+                    else if constexpr (k < 16 + FB) gs_ds_read<(k - 8 - FB) * 2048>(fs1[k - 8 - FB], s1);
+                    else gs_ds_read<(k - 16 - FB) * 2048>(fq1[k - 16 - FB], q1);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // (every fragment register is an in/out operand of the wait: nothing reads one in front of it)
+#define GS_FS_OPS "+v"(fs0[0]), "+v"(fs0[1]), "+v"(fs0[2]), "+v"(fs0[3]), "+v"(fs0[4]), "+v"(fs0[5]), "+v"(fs0[6]), "+v"(fs0[7]), \
+                  "+v"(fs1[0]), "+v"(fs1[1]), "+v"(fs1[2]), "+v"(fs1[3]), "+v"(fs1[4]), "+v"(fs1[5]), "+v"(fs1[6]), "+v"(fs1[7]), \
+                  "+v"(fq0[0]), "+v"(fq0[1]), "+v"(fq1[0]), "+v"(fq1[1])
+            if constexpr (FB == 4) asm volatile("s_waitcnt lgkmcnt(0)" : GS_FS_OPS, "+v"(fq0[2]), "+v"(fq1[2]), "+v"(fq0[3]), "+v"(fq1[3]) :: "memory");
+            else if constexpr (FB == 3) asm volatile("s_waitcnt lgkmcnt(0)" : GS_FS_OPS, "+v"(fq0[2]), "+v"(fq1[2]) :: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : GS_FS_OPS :: "memory");
+#undef GS_FS_OPS
+        } else {
+            if (!GS_INTERLEAVE && !grpB && it + 1 < total_it) stage(buf ^ 1, it + 1, nothing);
+            __builtin_amdgcn_sched_barrier(0);
             // (inline asm: hipcc's wait insertion would drain vmcnt(0) in front of any ds_read it sees behind an LDS-DMA it cannot prove disjoint)
-            const uint32_t s0 = as0 + buf * GS_STG, s1 = as1 + buf * GS_STG, q0 = aq0 + buf * GS_STG, q1 = aq1 + buf * GS_STG;
             if constexpr (FB == 4) {
                 asm volatile(
                     "ds_read_b128 %0, %24\n ds_read_b128 %1, %24 offset:2048\n ds_read_b128 %2, %24 offset:4096\n ds_read_b128 %3, %24 offset:6144\n"
@@ -378,7 +419,7 @@ gscan_kernel(const GScanParams p) {
         skip_b1 = false;
         __builtin_amdgcn_sched_barrier(0);
         GS_STAMP(3);
-        if (grpB && it + 2 < total_it) stage(buf, it + 2);                 // into the buffer both groups have finished reading
+        if (grpB && it + 2 < total_it) stage(buf, it + 2, nothing);                 // into the buffer both groups have finished reading
         GS_STAMP(4);
         if (kt == 0) {                                 // a tile's first k-tile starts from C = 0 (an inline constant: no 128 v_mov per tile)
 #pragma unroll

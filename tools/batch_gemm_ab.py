@@ -53,7 +53,7 @@ for N in sizes:
                 if mode in outs: assert torch.equal(cur[0], outs[mode][0]) and torch.equal(cur[1], outs[mode][1])
                 outs[mode] = cur
         same = all(torch.equal(outs[modes[0]][0], outs[m][0]) and torch.equal(outs[modes[0]][1], outs[m][1]) for m in modes)
-        if len(modes) > 2:
+        if len(modes) != 2:
             print(f"{N:>9d} rows, {B:4d} queries, k {k}: " + "  ".join(f"mode {m}: {float(np.median(res[m])):8.3f} ms" for m in modes) + f"  identical: {same}", flush=True)
             continue
         a, b = (float(np.median(res[m])) for m in modes)
