@@ -40,9 +40,6 @@ namespace atlas {
 #define GS_LDS_BYTES (4 * GS_STG + 8 * GS_WBUF_ENTRIES * 8)     // 159 744
 #define GTHETA_LDS(nmax) (64 + 4096 + (size_t)(nmax) * 4)
 #define GTHETA_MAXKEYS 32768
-#ifndef GS_PIECES_A
-#define GS_PIECES_A 11            // LDS-DMA pieces per k-tile of a wave of group A (of 16 per pair of waves; see `stage`)
-#endif
 #define GS_FRAG_PER_TILE 16       // 16-row fragments of a tile: the sample keeps one maximum per fragment and query
 
 struct GScanParams {
@@ -87,9 +84,6 @@ template <int OFF>
 static __device__ __forceinline__ void gs_ds_read(gs_u4& dst, const uint32_t addr) {      // issued, NOT waited for
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
-#ifndef GS_INTERLEAVE
-#define GS_INTERLEAVE 1
-#endif
 
 // MODE 0 = scan (filter epilogue), 1 = sample (fragment maxima), 2 = scan that also MEASURES every row's norm (the certifying twin: the caller's
 // pmax is a hint, atlas_scan_topk's default contract). The four waves that share a slab fragment row split its eight fragments: 16 v_dot2
@@ -102,8 +96,6 @@ __global__ void __launch_bounds__(512)
 gscan_kernel(const GScanParams p) {
     constexpr int QW = 16 * FB;                        // queries per wave
     constexpr int CW = 4 * QW;                         // queries per column tile
-    constexpr int QPIECES = CW / 8;                    // LDS-DMA pieces of a k-tile's queries: 32 | 24 | 16
-    constexpr int QA = FB == 4 ? GS_PIECES_A - 8 : FB - 1;  // ... of them issued by a wave of group A (group B: QPIECES / 4 - QA)
     static_assert(FB >= 2 && FB <= 4, "column tiles of 128, 192 or 256 queries");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // S0 | S1 | Q0 | Q1 (32 KiB each) | 8 wave buffers
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -146,15 +138,23 @@ gscan_kernel(const GScanParams p) {
     const uint32_t vbase = (uint32_t)(lane >> 3) * ROWB + chb;
     int qrows = p.nq - col * CW;
     qrows = __builtin_amdgcn_readfirstlane(qrows < 0 ? 0 : (qrows > CW ? CW : qrows));     // (hipcc clamps with v_med3: back to an SGPR, or the descriptor lives in VGPRs)
-    // A k-tile is 64 pieces of 8 rows x 128 B (32 of the slab, 32 of the queries), one wave instruction each. They are NOT split evenly: group
-    // A issues its pieces in its read phase, beside the partner's MFMAs (~95 cycles of the wave's time per piece, hidden), group B in front of
-    // its own MFMAs, where every piece is ~90 cycles of an idle matrix pipe -- so an A wave takes GS_PIECES_A = 11 (8 of the slab + 3 of the
-    // queries), a B wave 5 (queries): measured k-tile period (stamps on) 8 + 8: 4.7k cycles, 11 + 5 with A's pieces in front of its reads: 4.3k.
-    // (Measured and not kept: group B refilling A's slab rows in its own READ phase -- A's half of a buffer is free a phase early -- with only
-    // two query pieces left in front of B's MFMAs: the ~500 cycles in front of the MFMAs shrink neither with the piece count nor with the
-    // descriptor arithmetic moved in front of the barrier (the first DMA issue behind a barrier is what costs); 2.5 % slower:
-    // profiles/r04/gscan_phases_512_phase_aware_pieces.txt)
-    auto stage = [&](const int buf, const int it, auto&& between) __attribute__((always_inline)) {
+    // A k-tile is 64 pieces of 8 rows x 128 B (32 of the slab, 32 of the queries), one wave instruction each, and EVERY piece is issued from a
+    // READ phase, between the phase's fragment reads: a piece holds the wave's instruction issue until the CU's one vector-memory front end
+    // takes it (~95 cycles when 4 waves issue together), which costs nothing beside the partner group's MFMAs and beside ds_reads that are in
+    // flight anyway -- but ~500 cycles of an idle matrix pipe in front of a group's own MFMAs, however few pieces (round 4's first version: group
+    // B's 5 query pieces, queued behind group A's 44). What lets every piece go out a phase or more before its buffer is read:
+    //   * slab rows 0..127 of a stage are read by group A only, rows 128..255 by group B only: each half is refilled by the OTHER group in
+    //     its next read phase (A: half 1 of k-tile it + 1 while it reads k-tile it; B: half 0 of k-tile it + 2 while it reads k-tile it);
+    //   * query rows wj * QW .. + QW are read by the two waves (wj, wj + 4) of one SIMD only: wave wj + 4 refills one half of them for k-tile
+    //     it + 2 right behind its own reads of k-tile it (its twin read them a phase earlier), wave wj the other half a phase later.
+    // NPW = 4 + QW / 16 pieces per wave and phase, 32 KiB per phase for the CU; landing time: a k-tile period or more (the slab: HBM), a
+    // phase and a half for group A's query pieces (L2), all behind COUNTED s_waitcnt vmcnt (a wave's LDS-DMA loads land in order).
+    constexpr int QP = QW / 16;                        // query pieces per wave and phase
+    constexpr int NPW = 4 + QP;                        // pieces per wave and phase
+    // (per piece: m0, one v_add, the DMA -- everything else is formed once per phase; the group is a compile-time parameter of the phase's code:
+    //  a first version that SELECTED descriptor, rows and destination per piece by group spent ~200 cycles of scalar code on every piece)
+    auto stage = [&](auto grp_tag, const int buf, const int it, auto&& between) __attribute__((always_inline)) {     // this wave's pieces of k-tile `it` into stage `buf`
+        constexpr bool GB = decltype(grp_tag)::value;
         // (both descriptors are formed HERE, SGPR arithmetic: a descriptor carried across the k-loop ends up in VGPRs and every DMA in a
         //  readfirstlane loop)
         const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(p.q16 + (size_t)col * CW * D_FAST), 0, qrows * ROWB, 0x00020000);
@@ -164,25 +164,24 @@ gscan_kernel(const GScanParams p) {
         if (rem > GS_TILE) rem = GS_TILE;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.slab + (size_t)r0 * D_FAST), 0, (int)rem * ROWB, 0x00020000);
         const int kb = kt * 128;
-        const int w4 = wave & 3;
-        auto piece = [&](const __amdgpu_buffer_rsrc_t& rsrc, const int op, const int rg) __attribute__((always_inline)) {      // rows [8 rg, 8 rg + 8) of operand op
-            uint32_t vo = vbase;                       // (formed here from a copy hipcc cannot hoist: hoisted, the row offsets of all pieces live across the k-loop)
-            asm volatile("" : "+v"(vo));
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(smem + op * 2 * GS_STG + buf * GS_STG + rg * 1024), 16, (int)(vo + (uint32_t)(rg * 8 * ROWB)), kb, 0, 0);
-        };
-        if (!grpB) {
-            // (group A issues from its read phase: each piece is followed by its share of the phase's fragment reads -- a piece holds the
-            //  wave's issue for ~95 cycles, the TIME the vector-memory unit takes to accept the next one, and a ds_read issued in that
-            //  shadow costs nothing; behind all pieces the reads were another ~700 cycles of the phase)
-            gs_static_for<0, 8 + QA>([&](auto ic) __attribute__((always_inline)) {
-                constexpr int i = decltype(ic)::value;
-                if constexpr (i < 8) piece(rs, 0, w4 + 4 * i); else piece(rq, 1, w4 + 4 * (i - 8));
-                between(ic);
-            });
-        } else {
-#pragma unroll
-            for (int j = 0; j < QPIECES / 4 - QA; ++j) piece(rq, 1, 4 * QA + w4 + 4 * j);
-        }
+        const int sp0 = (GB ? 0 : 16) + wj;                        // slab pieces sp0 + 4 i: the OTHER group's half, spread over the four waves
+        const int qp0 = wj * (QW / 8) + (GB ? QP : 0);             // query pieces qp0 + i: this wave's half of the SIMD's QW rows
+        unsigned char* const ls = smem + buf * GS_STG + sp0 * 1024;
+        unsigned char* const lq = smem + 2 * GS_STG + buf * GS_STG + qp0 * 1024;
+        uint32_t vs = vbase, vq = vbase;               // (from copies hipcc cannot hoist: hoisted, they live across the k-loop)
+        asm volatile("" : "+v"(vs));
+        vq = vs + (uint32_t)(qp0 * 8 * ROWB);
+        vs += (uint32_t)(sp0 * 8 * ROWB);
+        // group A: query pieces first (they are needed a phase and a half on: `vmcnt(4)` at the end of the multiply phase covers them), group B:
+        // slab pieces first (its query pieces overwrite rows it reads in this very phase: they go out behind those reads)
+        gs_static_for<0, NPW>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr bool isq = GB ? (i >= 4) : (i < QP);
+            constexpr int j = GB ? (i >= 4 ? i - 4 : i) : (i < QP ? i : i - QP);          // the j-th query / slab piece of the phase
+            if constexpr (isq) __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_ptr)(lq + j * 1024), 16, (int)(vq + (uint32_t)(j * 8 * ROWB)), kb, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(ls + j * 4096), 16, (int)(vs + (uint32_t)(j * 32 * ROWB)), kb, 0, 0);
+            between(ic);
+        });
     };
 
     // the lane's fragment chunks: slab rows wi * 128 + 16 a + lr (MFMA A operand), query rows wj * QW + 16 b + lr (B operand); k-step 0 of a
@@ -311,39 +310,50 @@ gscan_kernel(const GScanParams p) {
     };
 
     // Phases are separated by s_barrier (all 8 waves); group A = waves 0-3, group B = waves 4-7 (wave w and w + 4 share a SIMD):
-    //     phase 2i     : A reads k-tile i (+ issues the DMA of i + 1)      | B multiplies k-tile i - 1 (+ issues the DMA of i + 1 first)
-    //     phase 2i + 1 : A multiplies k-tile i                             | B reads k-tile i
+    //     phase 2i     : A reads k-tile i, issues its pieces of k-tile i + 1       | B multiplies k-tile i - 1
+    //     phase 2i + 1 : A multiplies k-tile i                                     | B reads k-tile i, issues its pieces of k-tile i + 2
     // One flat loop over the k-tiles of ALL tiles of the workgroup: the staging runs straight through the tile boundaries. The epilogue of a
-    // tile needs no barrier and no stage buffer: a group runs it behind the barrier that ends its tile's last multiply phase, while the
-    // other group is still multiplying or already reading.
+    // tile needs no barrier and no stage buffer: both groups run it side by side (below), which puts group A's reads of a tile's FIRST k-tile
+    // into the same phase as group B's -- there, and only there, group B's pieces wait for the barrier behind its reads (they overwrite what
+    // group A is still reading) and go out in front of its MFMAs.
     auto nothing = [](auto) __attribute__((always_inline)) {};
-    stage(0, 0, nothing);
+    if (!grpB) stage(std::false_type{}, 0, 0, nothing); else stage(std::true_type{}, 0, 0, nothing);
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's pieces of k-tile 0 have landed
     __builtin_amdgcn_s_barrier();
     if (grpB) {                                        // B's phase 0: nothing to multiply yet
-        if (total_it > 1) stage(1, 1, nothing);
+        if (total_it > 1) stage(std::true_type{}, 1, 1, nothing);
         __builtin_amdgcn_s_barrier();
     }
-    int kt = 0, ti = 0;
+    int kt = 0, ti = 0, tile_first = 0;
     bool skip_b1 = false;
     float nrm0 = 0.f, nrm1 = 0.f, pm = 0.f;          // MODE 2: running sums of squares of two slab rows' elements, largest row sum seen
-    // (measured and not kept: group B's DMA pieces issued BETWEEN its MFMAs, one per eight, in a group-specialised copy of the loop -- the
-    //  ~700 cycles they cost in a block in front of the MFMAs only moved into the MFMA block: 1 950 cycles either way)
 #pragma unroll 1
     for (int it = 0; it < total_it; ++it) {
         const int buf = it & 1;
         GS_STAMP(0);
-        // A's pieces of k-tile it + 1 go out FIRST, in front of its reads: they come from HBM (~2k cycles to land) and A waits for them at the end
-        // of its multiply phase
         gs_u4 fs0[8], fq0[FB], fs1[8], fq1[FB];
         const uint32_t s0 = as0 + buf * GS_STG, s1 = as1 + buf * GS_STG, q0 = aq0 + buf * GS_STG, q1 = aq1 + buf * GS_STG;
-        constexpr int NR = 16 + 2 * FB, NP = 8 + QA;   // fragment reads of a phase, group A's pieces of a k-tile
-        const bool a_stages = GS_INTERLEAVE && !grpB && it + 1 < total_it;
-        if (a_stages) {
-            stage(buf ^ 1, it + 1, [&](auto ic) __attribute__((always_inline)) {
+        constexpr int NR = 16 + 2 * FB;                // fragment reads of a phase
+        // (every fragment register is an in/out operand of the phase's last wait: nothing reads one in front of it)
+#define GS_FS_OPS "+v"(fs0[0]), "+v"(fs0[1]), "+v"(fs0[2]), "+v"(fs0[3]), "+v"(fs0[4]), "+v"(fs0[5]), "+v"(fs0[6]), "+v"(fs0[7]), \
+                  "+v"(fs1[0]), "+v"(fs1[1]), "+v"(fs1[2]), "+v"(fs1[3]), "+v"(fs1[4]), "+v"(fs1[5]), "+v"(fs1[6]), "+v"(fs1[7]), \
+                  "+v"(fq0[0]), "+v"(fq0[1]), "+v"(fq1[0]), "+v"(fq1[1])
+#define GS_READS_DONE() do { \
+            if constexpr (FB == 4) asm volatile("s_waitcnt lgkmcnt(0)" : GS_FS_OPS, "+v"(fq0[2]), "+v"(fq1[2]), "+v"(fq0[3]), "+v"(fq1[3]) :: "memory"); \
+            else if constexpr (FB == 3) asm volatile("s_waitcnt lgkmcnt(0)" : GS_FS_OPS, "+v"(fq0[2]), "+v"(fq1[2]) :: "memory"); \
+            else asm volatile("s_waitcnt lgkmcnt(0)" : GS_FS_OPS :: "memory"); } while (0)
+        // (B's first read phase of a tile coincides with A's, see above. A flag of its own, opaque to hipcc: derived from `kt == 0` -- the
+        //  condition of the C = 0 form of the MFMAs below -- the phase is threaded into two copies, and the second copy's registers into scratch)
+        asm volatile("" : "+s"(tile_first));
+        const bool b_defer = grpB && tile_first != 0;
+        const bool stages = grpB ? (!b_defer && it + 2 < total_it) : (it + 1 < total_it);
+        if (stages && !grpB) {
+            // group A: its pieces of k-tile it + 1 (the other stage), every piece followed by its share of the reads
+            __builtin_amdgcn_sched_barrier(0);
+            stage(std::false_type{}, buf ^ 1, it + 1, [&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
                 __builtin_amdgcn_sched_barrier(0);
-                gs_static_for<i * NR / NP, (i + 1) * NR / NP>([&](auto kc) __attribute__((always_inline)) {
+                gs_static_for<i * NR / NPW, (i + 1) * NR / NPW>([&](auto kc) __attribute__((always_inline)) {
                     constexpr int k = decltype(kc)::value;
                     if constexpr (k < 8) gs_ds_read<k * 2048>(fs0[k], s0);
                     else if constexpr (k < 8 + FB) gs_ds_read<(k - 8) * 2048>(fq0[k - 8], q0);
@@ -352,16 +362,34 @@ gscan_kernel(const GScanParams p) {
                 });
                 __builtin_amdgcn_sched_barrier(0);
             });
-            // (every fragment register is an in/out operand of the wait: nothing reads one in front of it)
-#define GS_FS_OPS "+v"(fs0[0]), "+v"(fs0[1]), "+v"(fs0[2]), "+v"(fs0[3]), "+v"(fs0[4]), "+v"(fs0[5]), "+v"(fs0[6]), "+v"(fs0[7]), \
-                  "+v"(fs1[0]), "+v"(fs1[1]), "+v"(fs1[2]), "+v"(fs1[3]), "+v"(fs1[4]), "+v"(fs1[5]), "+v"(fs1[6]), "+v"(fs1[7]), \
-                  "+v"(fq0[0]), "+v"(fq0[1]), "+v"(fq1[0]), "+v"(fq1[1])
-            if constexpr (FB == 4) asm volatile("s_waitcnt lgkmcnt(0)" : GS_FS_OPS, "+v"(fq0[2]), "+v"(fq1[2]), "+v"(fq0[3]), "+v"(fq1[3]) :: "memory");
-            else if constexpr (FB == 3) asm volatile("s_waitcnt lgkmcnt(0)" : GS_FS_OPS, "+v"(fq0[2]), "+v"(fq1[2]) :: "memory");
-            else asm volatile("s_waitcnt lgkmcnt(0)" : GS_FS_OPS :: "memory");
-#undef GS_FS_OPS
+            GS_READS_DONE();
+        } else if (stages) {
+            // group B: its pieces of k-tile it + 2 into THIS stage. The query fragments first; the four slab pieces (rows only group A reads,
+            // and read a phase ago), each followed by its share of the slab reads; then -- the query reads have returned: lgkmcnt = the slab
+            // reads issued since -- the query pieces, which overwrite the rows just read
+            __builtin_amdgcn_sched_barrier(0);
+            gs_static_for<0, FB>([&](auto bc) __attribute__((always_inline)) {
+                constexpr int b = decltype(bc)::value;
+                gs_ds_read<b * 2048>(fq0[b], q0);
+                gs_ds_read<b * 2048>(fq1[b], q1);
+            });
+            stage(std::true_type{}, buf, it + 2, [&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                gs_static_for<i * 16 / NPW, (i + 1) * 16 / NPW>([&](auto kc) __attribute__((always_inline)) {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (k < 8) gs_ds_read<k * 2048>(fs0[k], s0); else gs_ds_read<(k - 8) * 2048>(fs1[k - 8], s1);
+                });
+                if constexpr (i == 3) {
+                    constexpr int since = 4 * 16 / NPW;
+                    if constexpr (since == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                    else if constexpr (since == 9) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
+                    else { static_assert(since == 10, "NPW 6 | 7 | 8"); asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory"); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            GS_READS_DONE();
         } else {
-            if (!GS_INTERLEAVE && !grpB && it + 1 < total_it) stage(buf ^ 1, it + 1, nothing);
             __builtin_amdgcn_sched_barrier(0);
             // (inline asm: hipcc's wait insertion would drain vmcnt(0) in front of any ds_read it sees behind an LDS-DMA it cannot prove disjoint)
             if constexpr (FB == 4) {
@@ -411,15 +439,20 @@ gscan_kernel(const GScanParams p) {
                     : "memory");
             }
         }
+#undef GS_READS_DONE
+#undef GS_FS_OPS
         GS_STAMP(1);
-        if (grpB) __builtin_amdgcn_s_waitcnt(0x0F70);  // B: its pieces of k-tile it + 1 (issued a phase ago) have landed
+        // what must have LANDED before the barrier: pieces issued before this phase (the slab rows the other group reads next, group B's
+        // query rows) -- all but this phase's NPW
+        if (stages) __builtin_amdgcn_s_waitcnt(0x0F70 | NPW); else __builtin_amdgcn_s_waitcnt(0x0F70);
         GS_STAMP(2);
         __builtin_amdgcn_sched_barrier(0);
         if (!skip_b1) __builtin_amdgcn_s_barrier();    // (group A took a tile's first barrier ahead of its epilogue: below)
         skip_b1 = false;
         __builtin_amdgcn_sched_barrier(0);
         GS_STAMP(3);
-        if (grpB && it + 2 < total_it) stage(buf, it + 2, nothing);                 // into the buffer both groups have finished reading
+        if (b_defer && it + 2 < total_it) stage(std::true_type{}, buf, it + 2, nothing);       // once per tile: in front of the MFMAs
+        tile_first = 0;
         GS_STAMP(4);
         if (kt == 0) {                                 // a tile's first k-tile starts from C = 0 (an inline constant: no 128 v_mov per tile)
 #pragma unroll
@@ -454,7 +487,8 @@ gscan_kernel(const GScanParams p) {
         }
         __builtin_amdgcn_sched_barrier(0);
         GS_STAMP(5);
-        if (!grpB) __builtin_amdgcn_s_waitcnt(0x0F70); // A: its pieces of k-tile it + 1 have landed
+        // A: its QUERY pieces of k-tile it + 1 (issued first; read in the next phase) have landed, the four slab pieces may still fly
+        if (!grpB) { if (stages) __builtin_amdgcn_s_waitcnt(0x0F70 | 4); else __builtin_amdgcn_s_waitcnt(0x0F70); }
         GS_STAMP(6);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -465,7 +499,7 @@ gscan_kernel(const GScanParams p) {
             // and its MFMAs (every buffer hand-over goes through the OTHER barrier, see above): it only keeps the groups in opposite phases. So
             // group A takes the next tile's first one HERE, ahead of its epilogue -- it meets group B coming out of the tile's last MFMAs --
             // and skips it in the next iteration; after the last tile it is the barrier that group B's phase 0 is owed.
-            if (!grpB) { __builtin_amdgcn_s_barrier(); skip_b1 = true; }
+            if (!grpB) { __builtin_amdgcn_s_waitcnt(0x0F70); __builtin_amdgcn_s_barrier(); skip_b1 = true; }       // (vmcnt(0): group B reads the next k-tile in the SAME phase as A)
             __builtin_amdgcn_sched_barrier(0);
             if (CERT) {                                // full row norms: the 4 lanes {l, l + 16, l + 32, l + 48} hold the 4 chunks of row l & 15
                 float x = nrm0, y = nrm1;
@@ -476,6 +510,7 @@ gscan_kernel(const GScanParams p) {
             }
             epilogue(ti);
             kt = 0;
+            tile_first = 1;
             ++ti;
         }
     }

@@ -67,9 +67,10 @@ def test_scan_has_no_scratch_and_a_clean_loop():
 
 
 def test_gemm_shaped_scan_has_a_clean_k_loop():
-    """gscan_kernel (batches above 96 queries): at the 256-register cap of its 8-wave workgroup (128 accumulators + 96 fragment registers); the
-    three instantiations carry no private segment; the 64 MFMAs of
-    a k-tile are free of vector-memory waits and every LDS-DMA descriptor lives in SGPRs (no readfirstlane loop around a DMA)"""
+    """gscan_kernel (batches above 96 queries): at the 256-register cap of its 8-wave workgroup (128 accumulators + 96 fragment registers); no
+    instantiation carries a private segment (the fragment registers are filled ASYNCHRONOUSLY by single ds_reads between the LDS-DMA pieces: a
+    spill or a copy of one in front of the phase's wait would read garbage); the MFMAs of a k-tile are free of vector-memory waits and every
+    LDS-DMA descriptor lives in SGPRs (no readfirstlane loop around a DMA)"""
     fns = {k: v for k, v in _functions(_asm("atlas_hip")).items() if "gscan_kernelILi" in k}
     assert len(fns) == 9, sorted(fns)                        # scan, sample, certifying scan x the 256-, 192- and 128-query column tile
     for name, body in fns.items():
@@ -80,7 +81,8 @@ def test_gemm_shaped_scan_has_a_clean_k_loop():
         assert len(mf) == 24 * fb, (name, len(mf))           # the k-step of a tile's first k-tile (C = 0) and the two of every k-tile
         # the last 16 x fb MFMAs = the accumulate k-step pair of the steady loop: nothing but MFMAs (and the certifying twin's v_dot2) in between
         loop = lines[mf[8 * fb]:mf[-1] + 1]
-        assert not any(l.startswith(("s_waitcnt", "scratch_", "buffer_", "global_", "ds_")) for l in loop), name
+        # (a lone `s_waitcnt lgkmcnt(0)` between the k-steps is hipcc's wait for a scalar load: the phase's ds_reads were waited for in front of the barrier)
+        assert not any(l.startswith(("scratch_", "buffer_", "global_", "ds_")) or (l.startswith("s_waitcnt") and "vmcnt" in l) for l in loop), name
         dma = [i for i, l in enumerate(lines) if l.startswith("buffer_load_dwordx4") and " lds" in l]
         assert len(dma) >= 8 * fb, (name, len(dma))
         assert body.count("v_readfirstlane_b32") <= 6, (name, body.count("v_readfirstlane_b32"))   # the wave index and the clamped query rows, not descriptors
