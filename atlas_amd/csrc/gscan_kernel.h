@@ -128,6 +128,10 @@ gscan_kernel(const GScanParams p) {
     };
     if (SCAN && tid == 0) { p.wg_stat[(size_t)blockIdx.x * 2] = 0u; p.wg_stat[(size_t)blockIdx.x * 2 + 1] = 0u; }
     if (ntl == 0) return;
+#if ATLAS_TUNING
+    // (both clocks at the two ends of workgroup 0: what a 'cycle' of the stamps is in wall time)
+    if (MODE != 1 && p.dbg != nullptr && blockIdx.x == 0 && tid == 0) { p.dbg[8 * GS_STAMP_ITERS * 8 + 8 * 8 * 4 + 0] = wall_clock64(); p.dbg[8 * GS_STAMP_ITERS * 8 + 8 * 8 * 4 + 1] = __builtin_readcyclecounter(); }
+#endif
     const int total_it = ntl * GS_NK;
 
     // LDS-DMA: one wave instruction writes 8 LDS rows x 128 B, lane-linear; wave w stages LDS rows 32 w + 8 i + (lane >> 3), i = 0..3, of
@@ -223,22 +227,29 @@ gscan_kernel(const GScanParams p) {
 
     auto epilogue = [&](const int ti) __attribute__((always_inline)) {
         if (SCAN) {
-            // (1) which of the 32 fragments hold a passing score: 32 independent chains of two VALU + two compares that end in scalar bit
-            // arithmetic -- no branch (a chain that ends in a branch costs its whole latency, ~70 cycles per fragment, 32 times per tile)
-            uint32_t hit = 0;
+            // (1) which of the wave's query COLUMNS hold a passing score: the maximum of a column's 32 scores (8 fragments x 4 rows) is a chain
+            // of 16 v_max3, one compare per column -- ~70 VALU instructions, no branch. (Round 4's first version tested the 32 fragments one
+            // by one: ~230 instructions, 1 200 cycles per tile and wave.) A lane OWNS its query columns: th[b] is per-lane.
+            uint32_t colhit = 0;
             GS_ESTAMP(0);
 #pragma unroll
-            for (int a = 0; a < 8; ++a)
+            for (int b = 0; b < FB; ++b) {
+                float m;
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(acc[0][b][0]), "v"(acc[0][b][1]), "v"(acc[0][b][2]));      // (fmaxf: two canonicalising v_max more)
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(acc[0][b][3]), "v"(acc[1][b][0]));
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(acc[1][b][1]), "v"(acc[1][b][2]));
 #pragma unroll
-                for (int b = 0; b < FB; ++b) {
-                    const f32x4 v = acc[a][b];
-                    float m;
-                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(v[0]), "v"(v[1]), "v"(v[2]));      // (fmaxf: two canonicalising v_max more)
-                    const uint64_t any = __builtin_amdgcn_ballot_w64(m > th[b]) | __builtin_amdgcn_ballot_w64(v[3] > th[b]);
-                    hit |= (any != 0ull ? 1u : 0u) << (a * FB + b);
+                for (int a = 2; a < 8; a += 2) {
+                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(acc[a - 1][b][3]), "v"(acc[a][b][0]));
+                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(acc[a][b][1]), "v"(acc[a][b][2]));
+                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(acc[a][b][3]), "v"(acc[a + 1][b][0]));
+                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(acc[a + 1][b][1]), "v"(acc[a + 1][b][2]));
                 }
+                m = fmaxf(m, acc[7][b][3]);
+                colhit |= (__builtin_amdgcn_ballot_w64(m > th[b]) != 0ull ? 1u : 0u) << b;
+            }
             GS_ESTAMP(1);
-            if (hit != 0u) {
+            if (colhit != 0u) {
                 // (everything lane-derived is formed HERE from a lane id hipcc cannot trace back: hoisted over the k-loop -- which runs at the
                 //  register cap: 128 accumulators + 96 fragment registers -- it would push fragments into scratch)
                 const int ln = lane_now(), lr_e = ln & 15, lg_e = ln >> 4;
@@ -249,20 +260,30 @@ gscan_kernel(const GScanParams p) {
                 // handful pass per tile and wave and the buffer has room for at least GS_WBUF_REAL / 2 more; slots are CLAMPED to the buffer,
                 // and what a tile brings beyond that (no usable threshold, mass ties: adversarial data) sends ITS queries to the
                 // exact path, as a full list does. Rows past the end of the range (zeros in a partial last tile) are dropped by the flush.
-                // The body is kept SMALL (the 32 copies are ~10 KB of code that stays in the instruction cache: a first version with per-entry
-                // capacity checks and out-of-line bodies took ~1 000 cycles per candidate, mostly instruction fetch).
-                // TAKEN BRANCHES are what this walk costs (~80 cycles each beside a partner wave that streams MFMAs; measured: 2.5k cycles for
-                // 32 skipped fragments, + 310 per hit fragment whose four `if (pass)` regions each ended in an execz branch): so one test per
-                // group of four fragments, then one per fragment, and NO branch inside a hit fragment -- every lane stores, the lanes
-                // without a passing score into a dummy slot of their own behind the real ones.
+                // The fragment bodies are kept SMALL and OUT OF LINE (the 32 copies are ~10 KB of code that stays in the instruction cache).
+                // TAKEN BRANCHES are what this walk costs (~80 cycles each beside a partner wave that streams MFMAs): one test per column
+                // (a column holds a passing score in ~30 % of the tiles), inside a hit column one test per fragment whose COMMON outcome --
+                // nothing here -- falls through, and NO branch inside a hit fragment: every lane stores, the lanes without a passing score
+                // into a dummy slot of their own behind the real ones.
                 const uint32_t dummy = wb + (uint32_t)(GS_WBUF_REAL + ln) * 8u;
                 uint32_t lost = 0;                      // bit b: a passing score of the lane's query column b found no slot
 #pragma unroll
-                for (int a = 0; a < 8; ++a) {
-                    if ((hit & (((1u << FB) - 1u) << (a * FB))) == 0u) continue;
+                for (int b = 0; b < FB; ++b) {
+                    if ((colhit & (1u << b)) == 0u) continue;
+                    // which of the column's 8 fragments: eight independent chains that end in scalar bit arithmetic (a chain that ends in a
+                    // branch costs its whole latency, ~100 cycles per fragment), then one test per fragment that falls through
+                    uint32_t fhit = 0;
 #pragma unroll
-                    for (int b = 0; b < FB; ++b) {
-                        if ((hit & (1u << (a * FB + b))) == 0u) continue;
+                    for (int a = 0; a < 8; ++a) {
+                        const f32x4 v = acc[a][b];
+                        float m;
+                        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(v[0]), "v"(v[1]), "v"(v[2]));
+                        const uint64_t any = __builtin_amdgcn_ballot_w64(m > th[b]) | __builtin_amdgcn_ballot_w64(v[3] > th[b]);
+                        fhit |= (any != 0ull ? 1u : 0u) << a;
+                    }
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) {
+                        if (__builtin_expect((fhit & (1u << a)) == 0u, 1)) continue;
                         const f32x4 v = acc[a][b];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -290,7 +311,7 @@ gscan_kernel(const GScanParams p) {
             GS_ESTAMP(2);
 #if ATLAS_TUNING
             if (p.dbg != nullptr && blockIdx.x == 0 && ti < 8 && lane_now() == 0)
-                p.dbg[(size_t)8 * GS_STAMP_ITERS * 8 + ((size_t)wave * 8 + ti) * 4 + 3] = ((unsigned long long)__popc(hit) << 32) | cnt;
+                p.dbg[(size_t)8 * GS_STAMP_ITERS * 8 + ((size_t)wave * 8 + ti) * 4 + 3] = ((unsigned long long)__popc(colhit) << 32) | cnt;
 #endif
         } else {
             const int ts = range + ti * nranges;
@@ -515,6 +536,9 @@ gscan_kernel(const GScanParams p) {
         }
     }
     if (SCAN) flush();
+#if ATLAS_TUNING
+    if (MODE != 1 && p.dbg != nullptr && blockIdx.x == 0 && tid == 0) { p.dbg[8 * GS_STAMP_ITERS * 8 + 8 * 8 * 4 + 2] = wall_clock64(); p.dbg[8 * GS_STAMP_ITERS * 8 + 8 * 8 * 4 + 3] = __builtin_readcyclecounter(); }
+#endif
     if (CERT) {
         // largest row norm^2 of the workgroup (x 1.001: v_dot2 accumulates in fp32): waves -> LDS -> one word pair, as scan_kernel.h leaves it
 #pragma unroll

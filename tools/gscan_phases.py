@@ -19,7 +19,7 @@ out_st = torch.empty(_lib.STATUS_HEADER + B, dtype=torch.int32, device="cuda")
 ws = torch.zeros(L.atlas_scan_topk_workspace_bytes(N, B, D, k), dtype=torch.uint8, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
 IT = 32
-dbg = torch.zeros(8 * IT * 8 + 8 * 8 * 4, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(8 * IT * 8 + 8 * 8 * 4 + 4, dtype=torch.int64, device="cuda")
 def call():
     rc = L.atlas_scan_topk_flags(q.data_ptr(), _lib.DT_F16, slab.data_ptr(), N, B, D, k, 1.002, out_s.data_ptr(), out_i.data_ptr(), out_st.data_ptr(),
                                  ws.data_ptr(), ws.numel(), stream, None, None, _lib.SCAN_TRUST_PMAX)
@@ -30,7 +30,10 @@ L.atlas_tune_set_scan_stamps(dbg.data_ptr())
 call(); torch.cuda.synchronize()
 L.atlas_tune_set_scan_stamps(None)
 t = dbg.cpu()[:8 * IT * 8].view(8, IT, 8)
-e = dbg.cpu()[8 * IT * 8:].view(8, 8, 4)
+e = dbg.cpu()[8 * IT * 8:8 * IT * 8 + 8 * 8 * 4].view(8, 8, 4)
+ck = dbg.cpu()[8 * IT * 8 + 8 * 8 * 4:]
+if int(ck[2]) > int(ck[0]):
+    print("workgroup 0 of the last scan launch: %d stamp cycles in %.1f us of the 100 MHz clock = %.3f GHz" % (int(ck[3] - ck[1]), (int(ck[2] - ck[0])) / 100.0, (int(ck[3] - ck[1])) / ((int(ck[2] - ck[0])) * 10.0)))
 t0 = int(t[:, 0, 0].min())
 names = ["reads", "dmaA/waitB", "bar1", "dmaB", "mfma", "waitA", "bar2"]
 for w in (0, 1, 4, 5):
