@@ -870,6 +870,14 @@ gemm_co_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 // 32 workgroups walk its (token tile, column tile) pairs in order, so one token tile's column tiles run side by side on one L2.
 // ------------------------------------------------------------------------------------------
 typedef unsigned int pt_u4 __attribute__((ext_vector_type(4)));
+template <int B, int E, class F>
+static __device__ __forceinline__ void pt_static_for(F&& f) {           // f(integral_constant<int, B>) ... f(integral_constant<int, E - 1>)
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); pt_static_for<B + 1, E>(f); }
+}
+template <int OFF>
+static __device__ __forceinline__ void pt_ds_read(u4v& dst, const uint32_t addr) {      // issued, NOT waited for
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
 // the lane id, recomputed where it is called (volatile: neither hoisted nor merged): what a tile's epilogue derives from the lane is then
 // not carried through the k-loop, which has no register to spare (every value kept alive across it ended up in scratch)
 static __device__ __forceinline__ int pt_fresh_lane() {
@@ -1036,34 +1044,53 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     // so their piece offset rides in the scalar offset.
     const uint32_t chb = (uint32_t)(((lane & 7) ^ (lane >> 3)) * 16);
     const uint32_t perm_lane = (uint32_t)(8 * (lane >> 5) + ((lane >> 3) & 3));
-    const uint32_t vw = VTR ? (uint32_t)(wave * 32 + (lane >> 3)) * K2 + chb
-                            : ((uint32_t)(128 * (wave >> 2) + 32 * (wave & 3)) + perm_lane) * K2 + chb;
-    const uint32_t va = VTR ? ((uint32_t)(64 * (wave >> 1) + 32 * (wave & 1)) + perm_lane) * K2 + chb
-                            : (uint32_t)(wave * 32 + (lane >> 3)) * K2 + chb;
+    // Which rows a wave stages (round 4; before, wave w staged LDS rows [32 w, 32 w + 32) of both operands, group A in its read phase, group B in
+    // front of its MFMAs): every piece is issued from a READ phase, between the phase's fragment reads -- in front of a group's own MFMAs a piece
+    // costs ~100 cycles of an idle matrix pipe, queued behind the other group's pieces. What makes that possible:
+    //   * W rows 0..127 of a stage are read by group A only, rows 128..255 by group B only: each half is refilled by the OTHER group in its next
+    //     read phase (wave w takes the rows wave w ^ 4 used to: A the half-1 rows of k-tile g + 1 while it reads k-tile g, B the half-0 rows
+    //     of k-tile g + 2 while it reads k-tile g);
+    //   * activation rows [64 wj, 64 wj + 64) are read by the two waves (wj, wj + 4) of one SIMD only: wave wj + 4 refills the upper 32 of them
+    //     for k-tile g + 2 right behind its own reads of k-tile g (its twin read them a phase earlier), wave wj the lower 32 a phase later.
+    // 8 pieces per wave and phase, landing behind COUNTED s_waitcnt vmcnt (vector-memory operations of a wave complete in order).
+    const int we = wave ^ 4, wa = 2 * wj + (grpB ? 1 : 0);          // whose rows this wave stages: W | activations (in units of 32 LDS rows)
+    const uint32_t vw = VTR ? (uint32_t)(we * 32 + (lane >> 3)) * K2 + chb
+                            : ((uint32_t)(128 * (we >> 2) + 32 * (we & 3)) + perm_lane) * K2 + chb;
+    const uint32_t va = VTR ? ((uint32_t)(64 * (wa >> 1) + 32 * (wa & 1)) + perm_lane) * K2 + chb
+                            : (uint32_t)(wa * 32 + (lane >> 3)) * K2 + chb;
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    auto stage = [&](const int buf, const int j, const int kt) {       // k-tile kt of tile j -> stage buffer buf
+    // this wave's pieces of k-tile kt of tile j -> stage buffer buf; `between(i)` runs behind piece i. Group A: its activation pieces first (read
+    // a phase and a half on: `vmcnt(4)` at the end of its multiply phase covers them), group B: its W pieces first (its activation pieces
+    // overwrite rows it reads in this very phase: they go out behind those reads)
+    auto stage = [&](auto grp_tag, const int buf, const int j, const int kt, auto&& between) __attribute__((always_inline)) {
+        constexpr bool GB = decltype(grp_tag)::value;
         const uint32_t kb = (uint32_t)kt * 128u;
         const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)tile_n0(j) * K), 0, (int)(256u * K2), 0x00020000);
         const __amdgpu_buffer_rsrc_t ra = rows_rsrc(A, tile_m0(j), K);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t rw_ = (uint32_t)(VTR ? 8 * i : 16 * (i & 1) + 4 * (i >> 1)) * K2;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem_raw + buf * STG + (wave * 32 + i * 8) * 128), 16, (int)vw, (int)(rw_ + kb), 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t ra_ = (uint32_t)(VTR ? 16 * (i & 1) + 4 * (i >> 1) : 8 * i) * K2;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(smem_raw + 2 * STG + buf * STG + (wave * 32 + i * 8) * 128), 16, (int)(va + ra_), (int)kb, 0, 0);
-        }
+        unsigned char* const lw = smem_raw + buf * STG + (we * 32) * 128;
+        unsigned char* const la = smem_raw + 2 * STG + buf * STG + (wa * 32) * 128;
+        pt_static_for<0, 8>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int p8 = decltype(ic)::value;
+            constexpr bool isw = GB ? (p8 < 4) : (p8 >= 4);
+            constexpr int i = p8 & 3;
+            if constexpr (isw) {
+                constexpr uint32_t rw_ = (uint32_t)(VTR ? 8 * i : 16 * (i & 1) + 4 * (i >> 1));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(lw + i * 8 * 128), 16, (int)vw, (int)(rw_ * K2 + kb), 0, 0);
+            } else {
+                constexpr uint32_t ra_ = (uint32_t)(VTR ? 16 * (i & 1) + 4 * (i >> 1) : 8 * i);
+                uint32_t vo = va;                      // (from a copy hipcc cannot hoist: hoisted, the four piece offsets live across the k-loop)
+                asm volatile("" : "+v"(vo));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(la + i * 8 * 128), 16, (int)(vo + ra_ * K2), (int)kb, 0, 0);
+            }
+            between(ic);
+        });
     };
+    auto nothing = [](auto) __attribute__((always_inline)) {};
 
     // LDS byte addresses of this lane's fragment chunks (fragment a / b adds a * 2048: rows 16 apart keep row & 7)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
     const int lr0 = lane & 15, lg0 = lane >> 4;
     const uint32_t aw0 = lds0 + (wi * 128 + lr0) * 128 + ((0 + lg0) ^ (lr0 & 7)) * 16;
-    const uint32_t aw1 = lds0 + (wi * 128 + lr0) * 128 + ((4 + lg0) ^ (lr0 & 7)) * 16;
-    const uint32_t aa0 = lds0 + 2 * STG + (wj * 64 + lr0) * 128 + ((0 + lg0) ^ (lr0 & 7)) * 16;
-    const uint32_t aa1 = lds0 + 2 * STG + (wj * 64 + lr0) * 128 + ((4 + lg0) ^ (lr0 & 7)) * 16;
 
     f4 acc[FA][FB];
 #pragma unroll
@@ -1093,11 +1120,11 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
     }
 #endif
-    stage(0, jc, 0);
+    if (!grpB) stage(std::false_type{}, 0, jc, 0, nothing); else stage(std::true_type{}, 0, jc, 0, nothing);
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's pieces of k-tile 0 have landed
     __builtin_amdgcn_s_barrier();
-    if (grpB) {                                        // B's phase 0: nothing to multiply yet
-        stage(1, jc, 1);
+    if (grpB) {                                        // B's phase 0: nothing to multiply yet; its pieces of k-tile 1
+        stage(std::true_type{}, 1, jc, 1, nothing);
         __builtin_amdgcn_s_barrier();
     }
     int buf = 0;
@@ -1115,8 +1142,58 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         constexpr bool LAST = decltype(last_tag)::value;
         const bool has_next = jc + nslots < njobs;
         u4v fw0[FA], fa0[FB], fw1[FA], fa1[FB];
-        {
-            const uint32_t w0 = aw0 + buf * STG, w1 = aw1 + buf * STG, a0 = aa0 + buf * STG, a1 = aa1 + buf * STG;
+        // (one lane-dependent address lives across the k-loop; k-step 1 = chunk (4 + lg) ^ (lr & 7) = k-step 0's with bit 2 flipped: byte
+        //  address ^ 64 -- the dynamic LDS segment starts at a multiple of 128 --, the activations sit a wave-uniform distance behind the weights)
+        const uint32_t w0 = aw0 + buf * STG, w1 = w0 ^ 64u, a0 = w0 + (uint32_t)(2 * STG + (wj * 64 - wi * 128) * 128), a1 = a0 ^ 64u;
+        // what this wave stages in this phase. Group A: the k-tile after this one (the other stage). Group B: the one after that, into THIS stage
+        // -- except in a tile's first iteration, where its reads share the phase with group A's (both groups come out of their epilogues side by
+        // side, see the tile loop): there its pieces wait for the barrier behind its reads and go out in front of its MFMAs.
+        const bool b_first = grpB && skip_wait;
+        bool stages; int sj, skt;
+        if (!grpB) { stages = !LAST || has_next; sj = LAST ? jc + nslots : jc; skt = LAST ? 0 : kt + 1; }
+        else { stages = !b_first && (kt + 2 < nk || has_next); sj = kt + 2 < nk ? jc : jc + nslots; skt = kt + 2 < nk ? kt + 2 : kt + 2 - nk; }
+        // (every fragment register is an in/out operand of the phase's last wait: nothing reads one in front of it; the reads are single
+        //  asm statements so that they can sit between the pieces, and the registers they fill asynchronously must not be copied or spilled:
+        //  tests/test_kernel_isa.py)
+#define PT_READS_DONE() asm volatile("s_waitcnt lgkmcnt(0)" \
+            : "+v"(fw0[0]), "+v"(fw0[1]), "+v"(fw0[2]), "+v"(fw0[3]), "+v"(fw0[4]), "+v"(fw0[5]), "+v"(fw0[6]), "+v"(fw0[7]), \
+              "+v"(fw1[0]), "+v"(fw1[1]), "+v"(fw1[2]), "+v"(fw1[3]), "+v"(fw1[4]), "+v"(fw1[5]), "+v"(fw1[6]), "+v"(fw1[7]), \
+              "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]), "+v"(fa1[0]), "+v"(fa1[1]), "+v"(fa1[2]), "+v"(fa1[3]) :: "memory")
+        if (stages && !grpB) {
+            __builtin_amdgcn_sched_barrier(0);
+            stage(std::false_type{}, buf ^ 1, sj, skt, [&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                pt_static_for<3 * i, 3 * i + 3>([&](auto kc) __attribute__((always_inline)) {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (k < 8) pt_ds_read<k * 2048>(fw0[k], w0);
+                    else if constexpr (k < 12) pt_ds_read<(k - 8) * 2048>(fa0[k - 8], a0);
+                    else if constexpr (k < 20) pt_ds_read<(k - 12) * 2048>(fw1[k - 12], w1);
+                    else pt_ds_read<(k - 20) * 2048>(fa1[k - 20], a1);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            PT_READS_DONE();
+        } else if (stages) {
+            // group B: the activation fragments first; its four W pieces (rows only group A reads, and read a phase ago) with half of the W
+            // reads; then -- the activation reads have returned: lgkmcnt(8) -- its activation pieces, which overwrite rows just read
+            __builtin_amdgcn_sched_barrier(0);
+            pt_static_for<0, 4>([&](auto bc) __attribute__((always_inline)) {
+                constexpr int b = decltype(bc)::value;
+                pt_ds_read<b * 2048>(fa0[b], a0);
+                pt_ds_read<b * 2048>(fa1[b], a1);
+            });
+            stage(std::true_type{}, buf, sj, skt, [&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (i < 4) { pt_ds_read<(2 * i) * 2048>(fw0[2 * i], w0); pt_ds_read<(2 * i + 1) * 2048>(fw0[2 * i + 1], w0); }
+                else { pt_ds_read<(2 * i - 8) * 2048>(fw1[2 * i - 8], w1); pt_ds_read<(2 * i - 7) * 2048>(fw1[2 * i - 7], w1); }
+                if constexpr (i == 3) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            PT_READS_DONE();
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
             asm volatile(
                 "ds_read_b128 %0, %24\n ds_read_b128 %1, %24 offset:2048\n ds_read_b128 %2, %24 offset:4096\n ds_read_b128 %3, %24 offset:6144\n"
                 "ds_read_b128 %4, %24 offset:8192\n ds_read_b128 %5, %24 offset:10240\n ds_read_b128 %6, %24 offset:12288\n ds_read_b128 %7, %24 offset:14336\n"
@@ -1132,13 +1209,13 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
                 : "v"(w0), "v"(a0), "v"(w1), "v"(a1)
                 : "memory");
         }
+#undef PT_READS_DONE
         if (LAST) PT_STAMP(1);
-        if (!grpB) {                                   // A stages the k-tile after this one (after its reads: see gemm_pp_kernel)
-            if (!LAST) stage(buf ^ 1, jc, kt + 1);
-            else if (has_next) stage(buf ^ 1, jc + nslots, 0);
-        } else if (!skip_wait) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);        // B: its pieces of the next k-tile (issued a phase ago) have landed
-        }
+        // what must have LANDED before the barrier: the pieces issued before this phase (the W rows the other group reads next, group B's
+        // activation rows) -- all but this phase's 8. A tile's first iteration: nothing is owed (both groups drained before the epilogue) and
+        // the epilogue's stores are still in flight -- no wait
+        if (stages) { if (!(skip_b1 || skip_wait)) __builtin_amdgcn_s_waitcnt(0x0F70 | 8); }
+        else if (!(skip_b1 || skip_wait)) __builtin_amdgcn_s_waitcnt(0x0F70);
         if (EPI == 2 && grpB && kt == nk - 3) touch_residual();
         __builtin_amdgcn_sched_barrier(0);
         if (!skip_b1) __builtin_amdgcn_s_barrier();    // (group A took a tile's first barrier ahead of its epilogue: see the tile loop)
@@ -1146,10 +1223,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         __builtin_amdgcn_sched_barrier(0);
         if (kt == 0) PT_STAMP(9);
         if (LAST) PT_STAMP(2);
-        if (grpB) {                                    // B stages two k-tiles on, into the buffer both groups have finished reading
-            if (!LAST) { if (kt + 2 < nk) stage(buf, jc, kt + 2); else if (has_next) stage(buf, jc + nslots, 0); }
-            else if (has_next) stage(buf, jc + nslots, 1);
-        }
+        if (b_first && (kt + 2 < nk || has_next)) stage(std::true_type{}, buf, sj, skt, nothing);      // once per tile: in front of the MFMAs
         if constexpr (VTR) {                           // activations as the MFMA A operand: C^T fragments, the same products in the same order
 #pragma unroll
             for (int a = 0; a < FA; ++a)
@@ -1200,7 +1274,9 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (!grpB) __builtin_amdgcn_s_waitcnt(0x0F70); // A: its pieces of the next k-tile have landed (and its epilogue stores, if any, are out)
+        // A: its ACTIVATION pieces of the next k-tile (issued first; read in the next phase) have landed, the four W pieces may still fly. (The
+        // last iteration of a tile: everything, the epilogue's operands were requested behind the pieces.)
+        if (!grpB) { if (stages && !LAST) __builtin_amdgcn_s_waitcnt(0x0F70 | 4); else __builtin_amdgcn_s_waitcnt(0x0F70); }
         if (EPI == 2 && !grpB && kt == nk - 3) touch_residual();
         if (LAST) PT_STAMP(4);
         __builtin_amdgcn_s_barrier();
