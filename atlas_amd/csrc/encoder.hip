@@ -1021,6 +1021,10 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     const int ntt = (int)((M + 255) >> 8);
     const int njobs = (ntt > xcd ? (ntt - xcd + 7) >> 3 : 0) * ncol;        // (token tile, column tile) pairs of this XCD
     if (slot >= njobs) return;
+#if ATLAS_TUNING
+    // (both clocks at the two ends of workgroup 0: what the shader clock is under this kernel's load)
+    if (dbg != nullptr && blockIdx.x == 0 && tid == 0) { dbg[1024] = wall_clock64(); dbg[1025] = __builtin_readcyclecounter(); }
+#endif
     const int nk = K >> 6;                                                    // k-tiles of 128 bytes per tile (>= 2)
     const uint32_t K2 = (uint32_t)K * 2u;
 
@@ -1329,6 +1333,9 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         jc += nslots;
         if (jc >= njobs) break;
     }
+#if ATLAS_TUNING
+    if (dbg != nullptr && blockIdx.x == 0 && tid == 0) { dbg[1026] = wall_clock64(); dbg[1027] = __builtin_readcyclecounter(); }
+#endif
 #undef PT_STAMP
 }
 

@@ -23,7 +23,8 @@ for which, nth in (("ffn2 (EPI 2, K = 3072)", 5), ("ffn1 (EPI 1)", 4), ("out-pro
     m.embed_into(out, ids, mask); torch.cuda.synchronize()
     L.atlas_tune_set_gemm_stamps_nth(None, 0)
     t = dbg.cpu()[:1024].view(8, 8, 16)
-    print("==", which)
+    ck = dbg.cpu()[1024:1028]
+    print("==", which, "-- workgroup 0: %.1f us, shader clock %.3f GHz" % (int(ck[2] - ck[0]) / 100.0, int(ck[3] - ck[1]) / (int(ck[2] - ck[0]) * 10.0)) if int(ck[2]) > int(ck[0]) else "")
     for w in (0, 4):
         for ti in (1, 2):
             r = t[w, ti]
