@@ -192,9 +192,8 @@ gscan_kernel(const GScanParams p) {
     // k-tile = chunks 0..3 (chunk lg of the lane), k-step 1 = chunks 4..7
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const uint32_t as0 = lds0 + (wi * 128 + lr) * 128 + ((0 + lg) ^ (lr & 7)) * 16;
-    const uint32_t as1 = lds0 + (wi * 128 + lr) * 128 + ((4 + lg) ^ (lr & 7)) * 16;
-    const uint32_t aq0 = lds0 + 2 * GS_STG + (wj * QW + lr) * 128 + ((0 + lg) ^ (lr & 7)) * 16;
-    const uint32_t aq1 = lds0 + 2 * GS_STG + (wj * QW + lr) * 128 + ((4 + lg) ^ (lr & 7)) * 16;
+    // (ONE lane-dependent address lives across the k-loop: k-step 1 = chunk (4 + lg) ^ (lr & 7) = k-step 0's with bit 2 flipped, byte address
+    //  ^ 64 -- the dynamic LDS segment starts at a multiple of 128 --, and the query rows sit a wave-uniform distance behind the slab rows)
 
     // C layout of v_mfma_f32_16x16x32_f16: lane l holds query column l & 15 and slab rows 4 (l >> 4) + r of the 16 x 16 block: the lane
     // OWNS its queries, the thresholds are four per-lane scalars for the whole kernel
@@ -334,9 +333,10 @@ gscan_kernel(const GScanParams p) {
     //     phase 2i     : A reads k-tile i, issues its pieces of k-tile i + 1       | B multiplies k-tile i - 1
     //     phase 2i + 1 : A multiplies k-tile i                                     | B reads k-tile i, issues its pieces of k-tile i + 2
     // One flat loop over the k-tiles of ALL tiles of the workgroup: the staging runs straight through the tile boundaries. The epilogue of a
-    // tile needs no barrier and no stage buffer: both groups run it side by side (below), which puts group A's reads of a tile's FIRST k-tile
-    // into the same phase as group B's -- there, and only there, group B's pieces wait for the barrier behind its reads (they overwrite what
-    // group A is still reading) and go out in front of its MFMAs.
+    // tile needs no barrier and no stage buffer, and the phases stay aligned across it: group B runs its epilogue where its tile ends (behind
+    // the barrier of its last multiply phase, in front of its next reads); group A, whose tile ends a phase earlier, first READS the next
+    // tile's first k-tile (beside group B's last MFMAs, as in every other phase; the fragments wait in registers) and runs its epilogue
+    // behind that phase's barrier, in front of its own MFMAs -- side by side with group B's (two waves per SIMD fill each other's gaps).
     auto nothing = [](auto) __attribute__((always_inline)) {};
     if (!grpB) stage(std::false_type{}, 0, 0, nothing); else stage(std::true_type{}, 0, 0, nothing);
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's pieces of k-tile 0 have landed
@@ -345,15 +345,14 @@ gscan_kernel(const GScanParams p) {
         if (total_it > 1) stage(std::true_type{}, 1, 1, nothing);
         __builtin_amdgcn_s_barrier();
     }
-    int kt = 0, ti = 0, tile_first = 0;
-    bool skip_b1 = false;
+    int kt = 0, ti = 0, a_due = 0;
     float nrm0 = 0.f, nrm1 = 0.f, pm = 0.f;          // MODE 2: running sums of squares of two slab rows' elements, largest row sum seen
 #pragma unroll 1
     for (int it = 0; it < total_it; ++it) {
         const int buf = it & 1;
         GS_STAMP(0);
         gs_u4 fs0[8], fq0[FB], fs1[8], fq1[FB];
-        const uint32_t s0 = as0 + buf * GS_STG, s1 = as1 + buf * GS_STG, q0 = aq0 + buf * GS_STG, q1 = aq1 + buf * GS_STG;
+        const uint32_t s0 = as0 + buf * GS_STG, s1 = s0 ^ 64u, q0 = s0 + (uint32_t)(2 * GS_STG + (wj * QW - wi * 128) * 128), q1 = q0 ^ 64u;
         constexpr int NR = 16 + 2 * FB;                // fragment reads of a phase
         // (every fragment register is an in/out operand of the phase's last wait: nothing reads one in front of it)
 #define GS_FS_OPS "+v"(fs0[0]), "+v"(fs0[1]), "+v"(fs0[2]), "+v"(fs0[3]), "+v"(fs0[4]), "+v"(fs0[5]), "+v"(fs0[6]), "+v"(fs0[7]), \
@@ -363,11 +362,7 @@ gscan_kernel(const GScanParams p) {
             if constexpr (FB == 4) asm volatile("s_waitcnt lgkmcnt(0)" : GS_FS_OPS, "+v"(fq0[2]), "+v"(fq1[2]), "+v"(fq0[3]), "+v"(fq1[3]) :: "memory"); \
             else if constexpr (FB == 3) asm volatile("s_waitcnt lgkmcnt(0)" : GS_FS_OPS, "+v"(fq0[2]), "+v"(fq1[2]) :: "memory"); \
             else asm volatile("s_waitcnt lgkmcnt(0)" : GS_FS_OPS :: "memory"); } while (0)
-        // (B's first read phase of a tile coincides with A's, see above. A flag of its own, opaque to hipcc: derived from `kt == 0` -- the
-        //  condition of the C = 0 form of the MFMAs below -- the phase is threaded into two copies, and the second copy's registers into scratch)
-        asm volatile("" : "+s"(tile_first));
-        const bool b_defer = grpB && tile_first != 0;
-        const bool stages = grpB ? (!b_defer && it + 2 < total_it) : (it + 1 < total_it);
+        const bool stages = grpB ? (it + 2 < total_it) : (it + 1 < total_it);
         if (stages && !grpB) {
             // group A: its pieces of k-tile it + 1 (the other stage), every piece followed by its share of the reads
             __builtin_amdgcn_sched_barrier(0);
@@ -468,13 +463,15 @@ gscan_kernel(const GScanParams p) {
         if (stages) __builtin_amdgcn_s_waitcnt(0x0F70 | NPW); else __builtin_amdgcn_s_waitcnt(0x0F70);
         GS_STAMP(2);
         __builtin_amdgcn_sched_barrier(0);
-        if (!skip_b1) __builtin_amdgcn_s_barrier();    // (group A took a tile's first barrier ahead of its epilogue: below)
-        skip_b1 = false;
+        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         GS_STAMP(3);
-        if (b_defer && it + 2 < total_it) stage(std::true_type{}, buf, it + 2, nothing);       // once per tile: in front of the MFMAs
-        tile_first = 0;
         GS_STAMP(4);
+        // group A: the epilogue of the tile that ended a phase ago (see above). (A flag of its own, opaque to hipcc: derived from `kt == 0` --
+        // the condition of the C = 0 form of the MFMAs below -- the whole phase is threaded into two copies, and the second copy's registers
+        // go to scratch)
+        asm volatile("" : "+s"(a_due));
+        if (a_due != 0) { epilogue(ti - 1); a_due = 0; }
         if (kt == 0) {                                 // a tile's first k-tile starts from C = 0 (an inline constant: no 128 v_mov per tile)
 #pragma unroll
             for (int a = 0; a < 8; ++a)
@@ -515,13 +512,6 @@ gscan_kernel(const GScanParams p) {
         __builtin_amdgcn_sched_barrier(0);
         GS_STAMP(7);
         if (++kt == GS_NK) {
-            // The epilogues of BOTH groups side by side: an epilogue is chains of dependent VALU / scalar work that one wave per SIMD runs at
-            // 10+ cycles per instruction; two waves per SIMD fill each other's gaps. No LDS hazard hangs on the barrier between a group's reads
-            // and its MFMAs (every buffer hand-over goes through the OTHER barrier, see above): it only keeps the groups in opposite phases. So
-            // group A takes the next tile's first one HERE, ahead of its epilogue -- it meets group B coming out of the tile's last MFMAs --
-            // and skips it in the next iteration; after the last tile it is the barrier that group B's phase 0 is owed.
-            if (!grpB) { __builtin_amdgcn_s_waitcnt(0x0F70); __builtin_amdgcn_s_barrier(); skip_b1 = true; }       // (vmcnt(0): group B reads the next k-tile in the SAME phase as A)
-            __builtin_amdgcn_sched_barrier(0);
             if (CERT) {                                // full row norms: the 4 lanes {l, l + 16, l + 32, l + 48} hold the 4 chunks of row l & 15
                 float x = nrm0, y = nrm1;
                 x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
@@ -529,12 +519,12 @@ gscan_kernel(const GScanParams p) {
                 pm = fmaxf(pm, fmaxf(x, y));
                 nrm0 = 0.f; nrm1 = 0.f;
             }
-            epilogue(ti);
+            if (grpB) epilogue(ti); else a_due = 1;
             kt = 0;
-            tile_first = 1;
             ++ti;
         }
     }
+    if (!grpB) { __builtin_amdgcn_s_barrier(); epilogue(ti - 1); }      // (the barrier group B's phase 0 is owed; group A's last tile)
     if (SCAN) flush();
 #if ATLAS_TUNING
     if (MODE != 1 && p.dbg != nullptr && blockIdx.x == 0 && tid == 0) { p.dbg[8 * GS_STAMP_ITERS * 8 + 8 * 8 * 4 + 2] = wall_clock64(); p.dbg[8 * GS_STAMP_ITERS * 8 + 8 * 8 * 4 + 3] = __builtin_readcyclecounter(); }
