@@ -664,14 +664,21 @@ ExactPlan make_exact_plan(int64_t N, int d, int k, int B) {
 // The GEMM-shaped pass of big batches (gscan_kernel.h). One pass takes up to GS_MAXQ queries as ncol = 1, 2 or 4 column tiles of 256.
 constexpr int GS_MAXQ = 1024;
 // Pass widths of the GEMM-shaped scan: column tiles of 128 / 192 / 256 queries (gscan_kernel<., 2 | 3 | 4>) x 1, 2 or 4 of them. A pass takes
-// the narrowest width that holds its queries; GS_COSTS = measured cost in units of one 64-query pass (1.06 ms at 4M rows:
-// profiles/r04/batch_gemm_pass_ab_tile_widths.txt). The 128-wide tile's k-tile streams the slab at ~5.3 TB/s: the HBM roof, not the MFMA one.
+// the narrowest width that holds its queries; GS_COSTS = measured cost in units of one 64-query pass (1.035 ms at 4M rows, 8.27 ms at 32M:
+// profiles/r04/batch_gemm_pass_ab_4m.txt, _32m.txt). The 128-wide tile's k-tile streams the slab at ~5.3 TB/s: the HBM roof, not the MFMA one.
 // (Four column tiles of 192 = 768 queries: measured 5.06 ms at 4M rows, a 512- plus a 256-query pass 4.85 ms -- not a width.)
 constexpr int GS_NW = 6;
 constexpr int GS_WIDTH[GS_NW] = {128, 192, 256, 384, 512, 1024};
 constexpr int GS_CW[GS_NW] = {128, 192, 256, 192, 256, 256};
+// Batches of 65..96 queries: the 96-query streaming pass and the 128-wide GEMM-shaped pass cost the same at 4M rows (1.165 / 1.158 ms); the
+// GEMM-shaped one is 5 % faster at 32M (8.83 / 9.29 ms) and carries ~0.1 ms of launches (sample, two threshold kernels, two scan launches) that
+// a small shard does not amortise (1M rows: 0.36 / 0.32 ms, 2M: 0.62 / 0.60, 8M: 2.13 / 2.29, 16M: 4.15 / 4.53: profiles/r04/batch_65_96_crossover.txt): from
+// GS_SMALL_BATCH_MIN_ROWS rows on.
+#ifndef GS_SMALL_BATCH_MIN_ROWS
+#define GS_SMALL_BATCH_MIN_ROWS 6000000
+#endif
 #ifndef GS_COSTS
-#define GS_COSTS {1.28f, 1.44f, 1.61f, 2.55f, 2.96f, 5.53f}
+#define GS_COSTS {1.10f, 1.30f, 1.50f, 2.32f, 2.69f, 5.02f}
 #endif
 constexpr size_t GS_OFF_QFLAG = 800u << 10;     // its per-query fallback flags: state words (zero between calls) behind the coop scan's granules
 static_assert(GS_OFF_QFLAG >= 512 + 256 + 512 + 1024 + (size_t)QWIDE * 1024 * 8 && GS_OFF_QFLAG + GS_MAXQ * 4 <= PAIR_STATE, "inside the first chunk's state");
@@ -796,7 +803,7 @@ size_t atlas_scan_topk_workspace_bytes(int64_t N, int B, int d, int k) {
             mx = t2 > mx ? t2 : mx;
         }
     }
-    if (B > QWIDE) {                   // GEMM-shaped passes (gscan_kernel.h)
+    if (B > QCHUNK) {                  // GEMM-shaped passes (gscan_kernel.h)
         const GPlan g = make_gplan(N, B < GS_MAXQ ? B : GS_MAXQ, device_cus());
         if (g.ok && g.total > mx) mx = g.total;
     }
@@ -863,7 +870,7 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
     }
     const bool pair_wide_ok = pair_ok && wide_ok && half >= QWIDE;
     bool gemm_ok[GS_NW] = {}, any_gemm = false;
-    if (B > QWIDE && scan_variant_index() == 0 && scan_gemm_enabled()) {
+    if ((B > QWIDE || (B > QCHUNK && N >= GS_SMALL_BATCH_MIN_ROWS)) && scan_variant_index() == 0 && scan_gemm_enabled()) {
         for (int i = 0; i < GS_NW; ++i) {
             const GPlan g = make_gplan(N, GS_WIDTH[i], device_cus());
             gemm_ok[i] = g.ok && ws_bytes >= g.total;
@@ -888,6 +895,7 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
                 if (!ok[it]) continue;
                 if ((it == 2 || it == 3) && n <= size[it - 2]) continue;     // a pair needs more queries than one pass of its kind takes
                 if (it > 4 && ok[it - 1] && n <= size[it - 1]) continue;     // a wider pass than the queries need
+                if (it == 4 && n <= QWIDE && wide_ok && N < GS_SMALL_BATCH_MIN_ROWS) continue;   // (up to 96 queries on a small shard: the streaming pass)
                 const float c = cost[it] + f[n > size[it] ? n - size[it] : 0];
                 if (c < best) { best = c; take[n] = (unsigned char)it; }
             }

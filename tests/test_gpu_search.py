@@ -599,6 +599,33 @@ def test_duplicated_passages_at_1m_stay_bounded(big, gpu_index_cls):
     assert dt < 0.25, f"{dt:.3f} s for a search with {st['fallback_queries']} flagged queries"
 
 
+def test_batches_of_65_to_96_queries_on_a_large_shard_take_the_gemm_shaped_pass_and_agree_with_the_streaming_passes(gpu_index_cls):
+    """from 6M rows on a batch of 65..96 queries is one 128-wide GEMM-shaped pass (atlas_hip.hip: GS_SMALL_BATCH_MIN_ROWS); its results must be
+    those of the two halves searched on their own (64-query streaming passes) and of the MFMA-free exact path -- a size-independent property"""
+    g = torch.Generator(device="cuda").manual_seed(4321)
+    N = 6_500_000
+    slab = torch.empty((N, 768), dtype=torch.float16, device="cuda")
+    for r0 in range(0, N, 500_000):
+        x = torch.randn((500_000, 768), generator=g, device="cuda")
+        slab[r0 : r0 + 500_000] = (x / x.norm(dim=1, keepdim=True)).half()
+    q = torch.randn((80, 768), generator=g, device="cuda")
+    idx = gpu_index_cls()
+    idx.init_embeddings([None] * 0)
+    idx._set_slab(slab)
+    idx.doc_map = {}
+    s, i = idx._compute_scores_and_indices(q, 40)
+    st = dict(idx.last_search_stats)
+    assert st["path"] == "scan" and st["fallback_queries"] == 0 and st["plan"]["gemm_passes"] == 1 and sum(st["plan"].values()) == 1, st
+    for lo, hi in ((0, 40), (40, 80)):
+        hs, hi_ = idx._compute_scores_and_indices(q[lo:hi], 40)
+        assert idx.last_search_stats["plan"]["gemm_passes"] == 0
+        assert torch.equal(s[lo:hi], hs) and torch.equal(i[lo:hi], hi_)
+    es, ei = idx._exact_topk(q[:4], 40)
+    assert torch.equal(s[:4], es) and torch.equal(i[:4], ei)
+    del idx, slab
+    torch.cuda.empty_cache()
+
+
 def test_search_knn_over_rccl_world_size_1(gpu_index_cls, oracle_mod):
     """The distributed branch of search_knn is taken whenever a process group exists, even at W = 1 (index.py:134). With the
     `nccl` (= RCCL) backend this runs the device-side pack -> all_gather_into_tensor -> merge kernels and the fp16 query
