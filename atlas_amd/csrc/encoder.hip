@@ -1003,8 +1003,11 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 #if ATLAS_TUNING
     int tstamp = 0;                                                  // tile counter of the stamps
 #define PT_STAMP(i) do { if (dbg != nullptr && blockIdx.x == 0 && tstamp < 8 && pt_fresh_lane() == 0) dbg[((int)wave * 8 + tstamp) * 16 + (i)] = wall_clock64(); } while (0)
+    int itc = 0;                                                     // iteration counter of the per-iteration stamps: shader cycles, iterations 24 .. 55
+#define PT_ISTAMP(i) do { if (dbg != nullptr && blockIdx.x == 0 && itc >= 24 && itc < 56 && pt_fresh_lane() == 0) dbg[2048 + ((int)wave * 32 + itc - 24) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define PT_STAMP(i) do { } while (0)
+#define PT_ISTAMP(i) do { } while (0)
 #endif
     constexpr int FA = 8, FB = 4;
     constexpr bool VTR = (EPI == 4);                                 // V tile: token rows staged permuted, MFMA operands swapped
@@ -1134,6 +1137,14 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     int buf = 0;
     bool skip_wait = false;                            // B: its wait of a tile's first iteration was taken before the epilogue
     bool skip_b1 = false;                              // A: its first barrier of a tile was taken before the epilogue
+    // READ-AHEAD (as gscan_kernel.h does it): group A, whose tile ends a phase before group B's, could first READ the next tile's first k-tile --
+    // beside group B's last MFMAs, the fragments waiting in registers -- and run its epilogue behind that phase's barrier, in front of its own
+    // MFMAs: the phases stay aligned across the tile boundary (no extra barrier, group B's pieces never deferred). Built and NOT enabled: with
+    // 96 fragment registers alive beside the 128 accumulators the epilogues spill (EPI 3: 152 B, EPI 4: 188 B, EPI 1: 216 B of scratch; EPI 2's
+    // 16 residual pieces rule it out from the start), and a kernel with a private segment pays ~12 us per launch.
+    constexpr bool RA = false;
+    bool a_due = false;                                // RA, group A: the previous tile's epilogue is still to run
+    int jprev = 0;
     pt_u4 rv[16], bq[4];
     int2 tki[4];
 #pragma unroll
@@ -1142,9 +1153,28 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     for (int i = 0; i < 4; ++i) tki[i] = make_int2(0, 0);
 
     // One iteration = one k-tile; phases as in gemm_pp_kernel. The k-tiles staged here (one and two steps on) may be the next tile's.
+    auto run_epilogue = [&](const int j) __attribute__((always_inline)) {       // tile j leaves the accumulators; they start the next tile from zero
+#define PT_EPILOGUE(AUX) pt_epilogue<T, EPI, AUX>(acc, smem_raw + TR_OFF + wave * 4096, bq, rv, tki, rows_rsrc(C, tile_m0(j), N), tile_m0(j), tile_n0(j), wi, wj, M, N, VT, tokinfo, Lp)
+#if ATLAS_TUNING
+        if (diag & 1) { if (acc[0][0][0] == 12345.678f) C[0] = 0; }
+        else if ((diag & 12) == 4) PT_EPILOGUE(2);
+        else if ((diag & 12) == 8) PT_EPILOGUE(16);
+        else
+#endif
+        PT_EPILOGUE(0);
+#undef PT_EPILOGUE
+        __builtin_amdgcn_sched_barrier(0);
+        PT_STAMP(7);
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+#pragma unroll
+            for (int b = 0; b < FB; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto iteration = [&](const int kt, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
         const bool has_next = jc + nslots < njobs;
+        PT_ISTAMP(0);
         u4v fw0[FA], fa0[FB], fw1[FA], fa1[FB];
         // (one lane-dependent address lives across the k-loop; k-step 1 = chunk (4 + lg) ^ (lr & 7) = k-step 0's with bit 2 flipped: byte
         //  address ^ 64 -- the dynamic LDS segment starts at a multiple of 128 --, the activations sit a wave-uniform distance behind the weights)
@@ -1152,7 +1182,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         // what this wave stages in this phase. Group A: the k-tile after this one (the other stage). Group B: the one after that, into THIS stage
         // -- except in a tile's first iteration, where its reads share the phase with group A's (both groups come out of their epilogues side by
         // side, see the tile loop): there its pieces wait for the barrier behind its reads and go out in front of its MFMAs.
-        const bool b_first = grpB && skip_wait;
+        const bool b_first = !RA && grpB && skip_wait;
         bool stages; int sj, skt;
         if (!grpB) { stages = !LAST || has_next; sj = LAST ? jc + nslots : jc; skt = LAST ? 0 : kt + 1; }
         else { stages = !b_first && (kt + 2 < nk || has_next); sj = kt + 2 < nk ? jc : jc + nslots; skt = kt + 2 < nk ? kt + 2 : kt + 2 - nk; }
@@ -1215,11 +1245,13 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         }
 #undef PT_READS_DONE
         if (LAST) PT_STAMP(1);
+        PT_ISTAMP(1);
         // what must have LANDED before the barrier: the pieces issued before this phase (the W rows the other group reads next, group B's
         // activation rows) -- all but this phase's 8. A tile's first iteration: nothing is owed (both groups drained before the epilogue) and
         // the epilogue's stores are still in flight -- no wait
         if (stages) { if (!(skip_b1 || skip_wait)) __builtin_amdgcn_s_waitcnt(0x0F70 | 8); }
         else if (!(skip_b1 || skip_wait)) __builtin_amdgcn_s_waitcnt(0x0F70);
+        PT_ISTAMP(2);
         if (EPI == 2 && grpB && kt == nk - 3) touch_residual();
         __builtin_amdgcn_sched_barrier(0);
         if (!skip_b1) __builtin_amdgcn_s_barrier();    // (group A took a tile's first barrier ahead of its epilogue: see the tile loop)
@@ -1227,7 +1259,10 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         __builtin_amdgcn_sched_barrier(0);
         if (kt == 0) PT_STAMP(9);
         if (LAST) PT_STAMP(2);
+        PT_ISTAMP(3);
         if (b_first && (kt + 2 < nk || has_next)) stage(std::true_type{}, buf, sj, skt, nothing);      // once per tile: in front of the MFMAs
+        bool a_ran = false;                            // RA, group A: the previous tile's epilogue, behind the barrier of the phase that read this k-tile
+        if constexpr (RA) { if (a_due) { run_epilogue(jprev); a_due = false; a_ran = true; } }
         if constexpr (VTR) {                           // activations as the MFMA A operand: C^T fragments, the same products in the same order
 #pragma unroll
             for (int a = 0; a < FA; ++a)
@@ -1244,6 +1279,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         __builtin_amdgcn_sched_barrier(0);
         if (kt == 0) PT_STAMP(10);
         if (LAST) PT_STAMP(3);
+        PT_ISTAMP(5);
         if (LAST) {
             // what the epilogue adds is requested behind the tile's last MFMAs (the fragment registers are free now) and lands under the
             // wait / barrier that follows: the lane's bias values and, for EPI 2, its 16 residual pieces
@@ -1278,15 +1314,29 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // A: its ACTIVATION pieces of the next k-tile (issued first; read in the next phase) have landed, the four W pieces may still fly. (The
-        // last iteration of a tile: everything, the epilogue's operands were requested behind the pieces.)
-        if (!grpB) { if (stages && !LAST) __builtin_amdgcn_s_waitcnt(0x0F70 | 4); else __builtin_amdgcn_s_waitcnt(0x0F70); }
+        // A: its ACTIVATION pieces of the next k-tile (issued first; read in the next phase) have landed, the four W pieces may still fly.
+        // (The last iteration of a tile: the epilogue's operands were requested behind the pieces and are not waited for HERE -- they land
+        // while group B multiplies its last k-tile and are waited for in front of the epilogue: EPL loads on top of the four W pieces.)
+        constexpr int EPL = EPI == 4 ? 12 : EPI == 2 ? 20 : 4;
+        // (RA, the iteration the epilogue ran in: its 16 stores were issued behind the pieces too; EPI 4's store count varies: everything.)
+        constexpr int VMA = LAST ? 4 + EPL : 4;     // (s_waitcnt simm16: vmcnt[3:0] in bits 3:0, vmcnt[5:4] in bits 15:14)
+        constexpr int VMR = 4 + 16;
+        if (!grpB) {
+            if (!stages || (a_ran && EPI == 4)) __builtin_amdgcn_s_waitcnt(0x0F70);
+            else if (a_ran) __builtin_amdgcn_s_waitcnt(0x0F70 | (VMR & 15) | ((VMR >> 4) << 14));
+            else __builtin_amdgcn_s_waitcnt(0x0F70 | (VMA & 15) | ((VMA >> 4) << 14));
+        }
         if (EPI == 2 && !grpB && kt == nk - 3) touch_residual();
         if (LAST) PT_STAMP(4);
+        PT_ISTAMP(6);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (kt == 0) PT_STAMP(11);
         if (LAST) PT_STAMP(5);
+        PT_ISTAMP(7);
+#if ATLAS_TUNING
+        ++itc;
+#endif
         buf ^= 1;
         skip_wait = false;
     };
@@ -1306,26 +1356,22 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         // one -- profiles/r03/enc_builds_split_epilogue.txt.)
         // (The wait: group B's pieces of the next tile's k-tile 1, the bias and the residual; group A waited in front of the tile's last
         // barrier -- for it this is a no-op that tells hipcc's wait insertion that nothing is in flight.)
+        if constexpr (RA) {
+            if (!grpB) {                               // group A: the epilogue runs inside the next tile's first iteration (or behind the loop)
+                jprev = jc; a_due = true;
+#if ATLAS_TUNING
+                ++tstamp;
+#endif
+                jc += nslots;
+                if (jc >= njobs) break;
+                continue;
+            }
+        }
         __builtin_amdgcn_s_waitcnt(0x0F70);
         PT_STAMP(6);
         if (grpB) skip_wait = true;
-#define PT_EPILOGUE(AUX) pt_epilogue<T, EPI, AUX>(acc, smem_raw + TR_OFF + wave * 4096, bq, rv, tki, rows_rsrc(C, tile_m0(jc), N), tile_m0(jc), tile_n0(jc), wi, wj, M, N, VT, tokinfo, Lp)
-        if (!grpB) { __builtin_amdgcn_s_barrier(); skip_b1 = true; }
-#if ATLAS_TUNING
-        if (diag & 1) { if (acc[0][0][0] == 12345.678f) C[0] = 0; }
-        else if ((diag & 12) == 4) PT_EPILOGUE(2);
-        else if ((diag & 12) == 8) PT_EPILOGUE(16);
-        else
-#endif
-        PT_EPILOGUE(0);
-#undef PT_EPILOGUE
-        __builtin_amdgcn_sched_barrier(0);
-        PT_STAMP(7);
-#pragma unroll
-        for (int a = 0; a < FA; ++a)
-#pragma unroll
-            for (int b = 0; b < FB; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
-        __builtin_amdgcn_sched_barrier(0);
+        if (!RA && !grpB) { __builtin_amdgcn_s_barrier(); skip_b1 = true; }
+        run_epilogue(jc);
         PT_STAMP(8);
 #if ATLAS_TUNING
         ++tstamp;
@@ -1333,10 +1379,18 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         jc += nslots;
         if (jc >= njobs) break;
     }
+    if constexpr (RA) {
+        if (a_due) {                                   // group A's last tile; the barrier is the one group B's last iteration still owes
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_s_barrier();
+            run_epilogue(jprev);
+        }
+    }
 #if ATLAS_TUNING
     if (dbg != nullptr && blockIdx.x == 0 && tid == 0) { dbg[1026] = wall_clock64(); dbg[1027] = __builtin_readcyclecounter(); }
 #endif
 #undef PT_STAMP
+#undef PT_ISTAMP
 }
 
 // ------------------------------------------------------------------------------------------
