@@ -853,7 +853,8 @@ gemm_co_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 // epilogue that parked the C tile in LDS (it occupies all four stage buffers) behind two barriers: ~10 us per tile whatever its kind,
 // 365 us of a 1 045 us layer with the k-loops switched off. Here
 //   * the LDS-DMA of the next tile's first two k-tiles is issued from inside the current tile's last two iterations (the k index simply
-//     runs on: k-tile g+1 is staged by group A in iteration g, k-tile g+2 by group B), so a tile's first MFMAs find their operands in LDS;
+//     runs on: group A stages its pieces of k-tile g+1 while it reads k-tile g, group B its pieces of k-tile g+2), so a tile's first MFMAs
+//     find their operands in LDS. EVERY piece goes out from a read phase, between the phase's fragment reads (round 4: see `stage`);
 //   * the C tile leaves STRAIGHT FROM THE ACCUMULATOR REGISTERS as 16-byte stores. A lane of v_mfma_f32_16x16x32 holds 4 consecutive
 //     MFMA rows of one MFMA column per fragment; which weight row an MFMA row IS, is decided by the LDS-DMA source address alone. The
 //     weight rows are therefore staged permuted -- LDS row 16 a + i of a wave's 128 holds weight row 32 (a >> 1) + 8 (i >> 2) + 4 (a & 1)
@@ -1139,12 +1140,10 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     bool skip_b1 = false;                              // A: its first barrier of a tile was taken before the epilogue
     // READ-AHEAD (as gscan_kernel.h does it): group A, whose tile ends a phase before group B's, could first READ the next tile's first k-tile --
     // beside group B's last MFMAs, the fragments waiting in registers -- and run its epilogue behind that phase's barrier, in front of its own
-    // MFMAs: the phases stay aligned across the tile boundary (no extra barrier, group B's pieces never deferred). Built and NOT enabled: with
+    // MFMAs: the phases stay aligned across the tile boundary (no extra barrier, group B's pieces never deferred). Built and NOT kept: with
     // 96 fragment registers alive beside the 128 accumulators the epilogues spill (EPI 3: 152 B, EPI 4: 188 B, EPI 1: 216 B of scratch; EPI 2's
     // 16 residual pieces rule it out from the start), and a kernel with a private segment pays ~12 us per launch.
-    constexpr bool RA = false;
-    bool a_due = false;                                // RA, group A: the previous tile's epilogue is still to run
-    int jprev = 0;
+    // (git history: "gemm_pt: the last iteration of a tile waits for its activation pieces only" carries the code.)
     pt_u4 rv[16], bq[4];
     int2 tki[4];
 #pragma unroll
@@ -1182,7 +1181,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         // what this wave stages in this phase. Group A: the k-tile after this one (the other stage). Group B: the one after that, into THIS stage
         // -- except in a tile's first iteration, where its reads share the phase with group A's (both groups come out of their epilogues side by
         // side, see the tile loop): there its pieces wait for the barrier behind its reads and go out in front of its MFMAs.
-        const bool b_first = !RA && grpB && skip_wait;
+        const bool b_first = grpB && skip_wait;
         bool stages; int sj, skt;
         if (!grpB) { stages = !LAST || has_next; sj = LAST ? jc + nslots : jc; skt = LAST ? 0 : kt + 1; }
         else { stages = !b_first && (kt + 2 < nk || has_next); sj = kt + 2 < nk ? jc : jc + nslots; skt = kt + 2 < nk ? kt + 2 : kt + 2 - nk; }
@@ -1261,8 +1260,6 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         if (LAST) PT_STAMP(2);
         PT_ISTAMP(3);
         if (b_first && (kt + 2 < nk || has_next)) stage(std::true_type{}, buf, sj, skt, nothing);      // once per tile: in front of the MFMAs
-        bool a_ran = false;                            // RA, group A: the previous tile's epilogue, behind the barrier of the phase that read this k-tile
-        if constexpr (RA) { if (a_due) { run_epilogue(jprev); a_due = false; a_ran = true; } }
         if constexpr (VTR) {                           // activations as the MFMA A operand: C^T fragments, the same products in the same order
 #pragma unroll
             for (int a = 0; a < FA; ++a)
@@ -1318,14 +1315,8 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         // (The last iteration of a tile: the epilogue's operands were requested behind the pieces and are not waited for HERE -- they land
         // while group B multiplies its last k-tile and are waited for in front of the epilogue: EPL loads on top of the four W pieces.)
         constexpr int EPL = EPI == 4 ? 12 : EPI == 2 ? 20 : 4;
-        // (RA, the iteration the epilogue ran in: its 16 stores were issued behind the pieces too; EPI 4's store count varies: everything.)
         constexpr int VMA = LAST ? 4 + EPL : 4;     // (s_waitcnt simm16: vmcnt[3:0] in bits 3:0, vmcnt[5:4] in bits 15:14)
-        constexpr int VMR = 4 + 16;
-        if (!grpB) {
-            if (!stages || (a_ran && EPI == 4)) __builtin_amdgcn_s_waitcnt(0x0F70);
-            else if (a_ran) __builtin_amdgcn_s_waitcnt(0x0F70 | (VMR & 15) | ((VMR >> 4) << 14));
-            else __builtin_amdgcn_s_waitcnt(0x0F70 | (VMA & 15) | ((VMA >> 4) << 14));
-        }
+        if (!grpB) { if (stages) __builtin_amdgcn_s_waitcnt(0x0F70 | (VMA & 15) | ((VMA >> 4) << 14)); else __builtin_amdgcn_s_waitcnt(0x0F70); }
         if (EPI == 2 && !grpB && kt == nk - 3) touch_residual();
         if (LAST) PT_STAMP(4);
         PT_ISTAMP(6);
@@ -1356,21 +1347,10 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         // one -- profiles/r03/enc_builds_split_epilogue.txt.)
         // (The wait: group B's pieces of the next tile's k-tile 1, the bias and the residual; group A waited in front of the tile's last
         // barrier -- for it this is a no-op that tells hipcc's wait insertion that nothing is in flight.)
-        if constexpr (RA) {
-            if (!grpB) {                               // group A: the epilogue runs inside the next tile's first iteration (or behind the loop)
-                jprev = jc; a_due = true;
-#if ATLAS_TUNING
-                ++tstamp;
-#endif
-                jc += nslots;
-                if (jc >= njobs) break;
-                continue;
-            }
-        }
         __builtin_amdgcn_s_waitcnt(0x0F70);
         PT_STAMP(6);
         if (grpB) skip_wait = true;
-        if (!RA && !grpB) { __builtin_amdgcn_s_barrier(); skip_b1 = true; }
+        if (!grpB) { __builtin_amdgcn_s_barrier(); skip_b1 = true; }
         run_epilogue(jc);
         PT_STAMP(8);
 #if ATLAS_TUNING
@@ -1378,13 +1358,6 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 #endif
         jc += nslots;
         if (jc >= njobs) break;
-    }
-    if constexpr (RA) {
-        if (a_due) {                                   // group A's last tile; the barrier is the one group B's last iteration still owes
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            __builtin_amdgcn_s_barrier();
-            run_epilogue(jprev);
-        }
     }
 #if ATLAS_TUNING
     if (dbg != nullptr && blockIdx.x == 0 && tid == 0) { dbg[1026] = wall_clock64(); dbg[1027] = __builtin_readcyclecounter(); }
