@@ -31,9 +31,6 @@
 #include "common.h"
 #include "scan_kernel.h"
 #include "gscan_kernel.h"
-#if ATLAS_TUNING
-#include "gscan2_kernel.h"
-#endif
 #include "../../include/atlas_hip.h"
 
 using namespace atlas;
@@ -933,12 +930,7 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
             auto gscan = g.cw == 256 ? (trusted ? gscan_kernel<0, 4> : gscan_kernel<2, 4>)          // <2, .>: the twin that measures every row norm
                        : g.cw == 192 ? (trusted ? gscan_kernel<0, 3> : gscan_kernel<2, 3>)
                                      : (trusted ? gscan_kernel<0, 2> : gscan_kernel<2, 2>);
-            size_t g_lds = GS_LDS_BYTES;
-#if ATLAS_TUNING
-            if (g_scan_gemm == 2) {                    // experiment: the slab through a register ring (gscan2_kernel.h)
-                gsample = gscan2_kernel<1>; gscan = trusted ? gscan2_kernel<0> : gscan2_kernel<2>; g_lds = GS2_LDS_BYTES;
-            }
-#endif
+            const size_t g_lds = GS_LDS_BYTES;
             allow_lds(gsample); allow_lds(gscan); allow_lds(gtheta_kernel);
             uint16_t* q16 = (uint16_t*)(w + g.off_q16);
             uint32_t* gcnt = (uint32_t*)(w + g.off_gcnt);

@@ -10,10 +10,26 @@
 //
 // Decomposition. One workgroup per CU (all 160 KiB of LDS), 8 waves as 2 (slab rows) x 4 (queries); the two waves of a SIMD run in
 // opposite phases (one reads its fragments and issues LDS-DMA while the other multiplies: the ping-pong schedule of encoder.hip's bulk
-// GEMM). Workgroup g: XCD x = g & 7, slot s = g >> 3; query column tile c = s % ncol (256 queries each), row range (x, s / ncol): a
-// contiguous, tile-aligned share of the slab. The ncol workgroups that score the same rows against different query tiles sit on the SAME
-// XCD in neighbouring slots and walk their range in step, so every slab tile comes from HBM once and from that XCD's L2 (or the
-// Infinity Cache) the other ncol - 1 times: HBM traffic is one slab read per launch whatever the batch.
+// GEMM). Workgroup g: XCD x = g & 7, slot s = g >> 3; query column tile c = s % ncol, row range (x, s / ncol): a contiguous, tile-aligned
+// share of the slab. The ncol workgroups that score the same rows against different query tiles sit on the SAME XCD in neighbouring slots
+// and walk their range in step, so every slab tile comes from HBM once and from that XCD's L2 (or the Infinity Cache) the other ncol - 1
+// times: HBM traffic is one slab read per launch whatever the batch (PMC: 1.12 x the slab, profiles/r04/gscan_fetch_size.txt).
+// A column tile is 256, 192 or 128 queries wide (FB = 4 | 3 | 2 query fragments per wave): a pass takes the narrowest of 128, 192, 256,
+// 2 x 192, 2 x 256, 4 x 256 that holds its queries (atlas_hip.hip: GS_WIDTH, with the measured cost of each).
+//
+// The k-loop (round 4's second version; `stage` and the loop have the details). Steady state: ~2 150 cycles per k-tile against the 2 048 the
+// 2 x 64 MFMAs of a SIMD's two waves take (shader-cycle stamps, tools/gscan_phases.py); what got it there from ~3 400:
+//   * EVERY LDS-DMA piece is issued from a READ phase, between the phase's fragment reads (single ds_read_b128 asm statements): a piece holds
+//     the wave's instruction issue until the CU's vector-memory front end takes it, which is free beside the partner group's MFMAs and
+//     beside reads that are in flight anyway -- and ~500 cycles of an idle matrix pipe in front of a group's own MFMAs (the first version:
+//     group B's query pieces). For that, each group refills the slab half the OTHER group reads, and each wave its own SIMD's query rows,
+//     so that no piece waits for a barrier; landing is checked with counted s_waitcnt vmcnt;
+//   * the filter epilogue looks at COLUMN maxima first (16 v_max3 per query column of the wave), fragments only inside a hit column, with
+//     the fragment bodies out of line: ~750 cycles for a tile without a candidate instead of ~2 700;
+//   * group A reads the next tile's first k-tile BEFORE its epilogue: the phases stay aligned across tile boundaries (no extra barrier, no
+//     deferred pieces); a tile boundary costs ~2 200 cycles (of ~28 000 per tile) instead of ~6 000.
+// The shader clock under this kernel is 1.69 GHz (both clocks stamped at the ends of workgroup 0), not the 2.4 GHz the 2.5 PFLOP/s peak is
+// quoted at: 1 024 queries x 4M rows run at 0.48 of that peak = 0.68 of what the matrix pipe can do at the clock it is given.
 //
 // Thresholds. A first launch of the same kernel in SAMPLE mode scores s_tiles evenly spread tiles (about 1/64 of the slab) and leaves, per
 // query, the maximum of every 16-row fragment; gtheta_kernel takes a lower bound of the k-th largest of those maxima (scores of DISTINCT rows ->
@@ -25,8 +41,10 @@
 // The merge is merge_rescore_kernel in FLAT mode (merge_kernel.h): one contiguous list per query, cut into 1024 virtual segments.
 //
 // Measured and NOT adopted (profiles/r04/): a THIRD slab stage (the wave candidate buffers moved to global memory to make room: 5 x 32 KiB
-// of LDS), slab pieces issued two k-tiles ahead behind a counted s_waitcnt vmcnt(8) -- group A's ~400 exposed cycles per k-tile go away and
-// the scan is 3-4 % SLOWER all the same (three_slab_stages.patch, batch_gemm_pass_ab_*_three_slab_stages.txt).
+// of LDS), slab pieces issued two k-tiles ahead behind a counted s_waitcnt vmcnt(8) -- 3-4 % SLOWER (three_slab_stages.patch,
+// batch_gemm_pass_ab_*_three_slab_stages.txt); the slab through a register ring instead of LDS (gscan2_kernel.h, tuning build: 3-4 % slower);
+// more of the pieces on group A, 13 / 14 / 16 of 16 per wave pair (slower step by step); one instruction stream for both groups with the
+// piece parameters SELECTED per piece (~200 cycles of scalar code per piece: 16 % slower).
 #pragma once
 #include "scan_kernel.h"
 
@@ -46,14 +64,14 @@ struct GScanParams {
     const uint16_t* slab;     // [N][768] fp16
     int64_t N;
     const uint16_t* q16;      // [nq][768] the queries of this pass as fp16 rows (gprep_kernel)
-    int nq, ncol;             // queries of the pass, column tiles of 256 (ncol divides gridDim.x / 8)
+    int nq, ncol;             // queries of the pass, column tiles (of 64 FB queries; ncol divides gridDim.x / 8)
     int64_t rows_per_range;   // SCAN: rows of every row range (a multiple of 256)
     int tile_begin, tile_end; // SCAN: this launch takes tiles [tile_begin, tile_end) of every range (two launches per pass: the second one runs with
                               // thresholds tightened by what the first one found, gtheta_kernel)
     int s_tiles;              // SAMPLE: tiles of the sample; tile t = rows [t * s_stride, + 256), all inside the slab
     int64_t s_stride;
-    const float* theta;       // SCAN: [ncol * 256] pruning thresholds (+inf for the padding queries)
-    float* smax;              // SAMPLE: [s_tiles * 16][ncol * 256] fragment maxima
+    const float* theta;       // SCAN: [ncol * 64 FB] pruning thresholds (+inf for the padding queries)
+    float* smax;              // SAMPLE: [s_tiles * 16][ncol * 64 FB] fragment maxima
     uint2* lists;             // SCAN: [nq][gcap] {f32 bits of the approximate score, shard-local row}
     uint32_t* gcnt;           // SCAN: [nq] entries appended to lists[q] (may exceed gcap: the query is then flagged)
     uint32_t* qflag;          // SCAN: [nq] fallback flags (plain idempotent stores)

@@ -14,7 +14,7 @@ k = 40
 if "--k" in args:
     i = args.index("--k"); k = int(args[i + 1]); del args[i:i + 2]
 modes = (0, 1)
-if "--modes" in args:      # 0 = streaming passes, 1 = gscan_kernel, 2 = gscan2_kernel (experiment: the slab through a register ring)
+if "--modes" in args:      # 0 = streaming passes, 1 = gscan_kernel (one mode: timing only, e.g. for library variants via ATLAS_HIP_SO)
     i = args.index("--modes"); modes = tuple(int(x) for x in args[i + 1].split(",")); del args[i:i + 2]
 batches = (64, 96, 128, 192, 256, 384, 512, 1024)
 if "--batches" in args:
