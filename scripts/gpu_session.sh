@@ -60,7 +60,7 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for f in glob.glob("$OUT/gpmc_fetch/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "gscan_kernel<0>" in r["Kernel_Name"] or "gscan_kernelILi0" in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "gscan_kernel<0" in r["Kernel_Name"] or "gscan_kernelILi0" in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for c, v in acc.items():
     per_call = sum(v) / (len(v) / 2)          # two scan launches per search
     print("gscan_kernel<0>, 4M rows x 512 queries: FETCH_SIZE %.0f KiB per search (2 launches) = %.3f x the slab's %d bytes after the gfx950 x 2 correction for 16-byte-per-lane reads (uncalibrated for LDS-DMA: an upper bound of ~2 slab reads would be 2.0)" % (per_call, per_call * 1024 * 2 / (4000000 * 1536), 4000000 * 1536))
