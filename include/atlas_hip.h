@@ -104,13 +104,13 @@ const char* atlas_build_info(void);          /* "gfx950 <compile date> ..." */
  * Fast path requires d == 768 (EMBEDDINGS_DIM, src/retrievers.py:13) and k <= 256;
  * otherwise returns ATLAS_E_UNSUPPORTED (callers then use atlas_exact_topk).
  * Any B >= 1 is accepted: up to 64 queries are one slab pass; a larger batch is a sequence of passes chosen by measured cost
- * (ATLAS_ST_PLAN reports it). Up to 96 queries the slab BYTES are the bound and the passes stream (a 96-query pass -- 147 KiB query image,
- * 6 MFMAs per 16-byte slab load -- takes ~1.11 of a 64-query pass). Above 96 queries the matrix pipe is the bound and the passes are
- * GEMM-shaped (csrc/gscan_kernel.h; shards of >= 65 536 rows): 256 slab rows x 256 queries per workgroup tile, both operands staged through
- * LDS, up to 256 / 512 / 1024 queries per pass for ONE slab read from HBM (the workgroups that score the same rows against different query
- * tiles share them through the L2); a sample launch gives every query its first threshold, a second launch runs with thresholds tightened
- * by the candidates of the first eighth of the slab. Costs in units of a 64-query pass: 1.56 (<= 256 queries), 2.86 (<= 512), 5.4
- * (<= 1024); 512 queries on a 4M-row shard: 3.0 ms against 5.7 ms for round 3's streaming passes (paired 64- / 96-query passes, which
+ * (ATLAS_ST_PLAN reports it). Up to 64 queries the slab BYTES are the bound and the pass streams. Above that the matrix pipe takes over and the
+ * passes are GEMM-shaped (csrc/gscan_kernel.h; shards of >= 65 536 rows; 65..96 queries from 6M rows on, a 96-query streaming pass below):
+ * 256 slab rows x a column tile of 128, 192 or 256 queries per workgroup tile, both operands staged through LDS, up to 128 / 192 / 256 / 384 /
+ * 512 / 1024 queries per pass for ONE slab read from HBM (the workgroups that score the same rows against different query tiles share them
+ * through the L2); a sample launch gives every query its first threshold, a second scan launch runs with thresholds tightened by the
+ * candidates of the first eighth of the slab. Costs in units of a 64-query pass: 1.10 / 1.30 / 1.50 / 2.32 / 2.69 / 5.02; 512 queries on a
+ * 4M-row shard: 2.75 ms (0.46 of the f16 MFMA peak) against 5.7 ms for round 3's streaming passes (paired 64- / 96-query passes, which
  * remain for small shards). The workspace size depends on B: a workspace sized for a larger batch serves every smaller one; the state
  * words at its head do not move with B.
  *
