@@ -854,8 +854,9 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
     // on half the chip each (1.62 for up to 128 queries: the second reader of a slab row hits the Infinity Cache), a pair of 96-query
     // passes (1.89 for up to 192); f(n) = min over the items of cost + f(n - size): 128 -> a pair of 64, 192 -> a pair of 96,
     // 512 -> 2 pairs of 96 + a pair of 64.
-    // ... and, for batches above 96 queries whose pmax is certified, GEMM-shaped passes (gscan_kernel.h) of up to 256 / 512 / 1024 queries: MFMA-bound
-    // instead of LDS-fed, one slab read from HBM per pass whatever its width.
+    // ... and GEMM-shaped passes (gscan_kernel.h) of up to 128 / 192 / 256 / 384 / 512 / 1024 queries (GS_WIDTH, GS_COSTS above) for batches above 96
+    // queries -- above 64 on shards of GS_SMALL_BATCH_MIN_ROWS rows or more --: MFMA-bound instead of LDS-fed, one slab read from HBM per pass
+    // whatever its width; both twins (pmax trusted / every row norm measured).
     struct Pass { int nq, nq2; bool wide; bool gemm; };
     std::vector<Pass> passes;
     ScanPlan pp = pl;                           // the half-chip plan of paired passes
