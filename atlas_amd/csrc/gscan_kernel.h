@@ -490,37 +490,51 @@ gscan_kernel(const GScanParams p) {
         // go to scratch)
         asm volatile("" : "+s"(a_due));
         if (a_due != 0) { epilogue(ti - 1); a_due = 0; }
+        // MODE 2: row sums of squares of this wave's two of the eight fragments of its slab rows, 2 wj and 2 wj + 1 (the lane holds 8 + 8 of a
+        // row's 64 elements of this k-tile), in SIXTEEN units of 3 v_cndmask + 1 v_dot2, one behind every group of FB MFMAs. The fragments
+        // are picked with v_cndmask under wave-uniform masks, not with branches on wj (an if-chain behind the MFMA block: 2-3 taken branches
+        // per k-tile). What the certifying twin costs, 4M rows x 512 queries (tools/batch_gemm_ab.py --certify, tools/gscan_phases.py
+        // --certify: profiles/r04/gscan_certifying_twin.txt): 3.43 ms against the trusting twin's 2.77 on the same box (the if-chain: 3.59;
+        // branch-free but behind the MFMA block: 3.42) -- the 64 VALU instructions do NOT vanish in the MFMAs' shadow: the multiply phase
+        // grows by 100-170 cycles and the partner's read phase by as much (2 670 instead of 2 060 cycles per k-tile, at 1.97 instead of
+        // 1.75 GHz). Three quarters of them are the selects: the data a wave squares depends on wj, and registers cannot be indexed.
+        const unsigned long long m0 = (wj & 1) ? ~0ull : 0ull, m1 = (wj & 2) ? ~0ull : 0ull;
+        auto cert_unit = [&](const gs_u4 (&f)[8], auto uc) __attribute__((always_inline)) {        // unit u: dword u & 3 of fragment 2 wj + ((u >> 2) & 1)
+            if constexpr (CERT) {
+                constexpr int u = decltype(uc)::value, e = (u >> 2) & 1, d = u & 3;
+                uint32_t x, y, w;
+                asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(x) : "v"(f[0 + e][d]), "v"(f[2 + e][d]), "s"(m0));
+                asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(y) : "v"(f[4 + e][d]), "v"(f[6 + e][d]), "s"(m0));
+                asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(w) : "v"(x), "v"(y), "s"(m1));
+                const f16x2 h = __builtin_bit_cast(f16x2, w);
+                if (e == 0) nrm0 = __builtin_amdgcn_fdot2(h, h, nrm0, false); else nrm1 = __builtin_amdgcn_fdot2(h, h, nrm1, false);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
         if (kt == 0) {                                 // a tile's first k-tile starts from C = 0 (an inline constant: no 128 v_mov per tile)
-#pragma unroll
-            for (int a = 0; a < 8; ++a)
+            gs_static_for<0, 8>([&](auto ac) __attribute__((always_inline)) {
+                constexpr int a = decltype(ac)::value;
 #pragma unroll
                 for (int b = 0; b < FB; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fs0[a]), __builtin_bit_cast(f16x8, fq0[b]), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                cert_unit(fs0, ac);
+            });
         } else {
-#pragma unroll
-            for (int a = 0; a < 8; ++a)
+            gs_static_for<0, 8>([&](auto ac) __attribute__((always_inline)) {
+                constexpr int a = decltype(ac)::value;
 #pragma unroll
                 for (int b = 0; b < FB; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fs0[a]), __builtin_bit_cast(f16x8, fq0[b]), acc[a][b], 0, 0, 0);
+                cert_unit(fs0, ac);
+            });
         }
-#pragma unroll
-        for (int a = 0; a < 8; ++a)
+        gs_static_for<0, 8>([&](auto ac) __attribute__((always_inline)) {
+            constexpr int a = decltype(ac)::value;
 #pragma unroll
             for (int b = 0; b < FB; ++b)
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fs1[a]), __builtin_bit_cast(f16x8, fq1[b]), acc[a][b], 0, 0, 0);
-        if (CERT) {
-            // row sums of squares: this wave's two of the eight fragments of its slab rows (the lane holds 8 + 8 of a row's 64 elements of this k-tile)
-            auto sq = [](const gs_u4& f, float acc2) {
-                const uint32_t w[4] = {f.x, f.y, f.z, f.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { const f16x2 h = __builtin_bit_cast(f16x2, w[i]); acc2 = __builtin_amdgcn_fdot2(h, h, acc2, false); }
-                return acc2;
-            };
-            if (wj == 0) { nrm0 = sq(fs1[0], sq(fs0[0], nrm0)); nrm1 = sq(fs1[1], sq(fs0[1], nrm1)); }
-            else if (wj == 1) { nrm0 = sq(fs1[2], sq(fs0[2], nrm0)); nrm1 = sq(fs1[3], sq(fs0[3], nrm1)); }
-            else if (wj == 2) { nrm0 = sq(fs1[4], sq(fs0[4], nrm0)); nrm1 = sq(fs1[5], sq(fs0[5], nrm1)); }
-            else { nrm0 = sq(fs1[6], sq(fs0[6], nrm0)); nrm1 = sq(fs1[7], sq(fs0[7], nrm1)); }
-        }
+            cert_unit(fs1, ac);
+        });
         __builtin_amdgcn_sched_barrier(0);
         GS_STAMP(5);
         // A: its QUERY pieces of k-tile it + 1 (issued first; read in the next phase) have landed, the four slab pieces may still fly

@@ -1,6 +1,6 @@
 """Batches above 96 queries: the streaming passes of round 3 (64 / 96-query passes, single or paired) vs the GEMM-shaped passes (gscan_kernel.h), same
 process (tuning build), results compared bit for bit.
-    python tools/batch_gemm_ab.py [rows, default 4000000 and 32000000] [--k K] [--batches 97,128,...] [--modes 0,1]"""
+    python tools/batch_gemm_ab.py [rows, default 4000000 and 32000000] [--k K] [--batches 97,128,...] [--modes 0,1] [--certify]"""
 import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
 from _tune import L  # noqa: E402
 import sys, time
@@ -16,6 +16,9 @@ if "--k" in args:
 modes = (0, 1)
 if "--modes" in args:      # 0 = streaming passes, 1 = gscan_kernel (one mode: timing only, e.g. for library variants via ATLAS_HIP_SO)
     i = args.index("--modes"); modes = tuple(int(x) for x in args[i + 1].split(",")); del args[i:i + 2]
+flags = _lib.SCAN_TRUST_PMAX
+if "--certify" in args:    # the C-ABI's default contract: every row norm measured beside the MFMAs (gscan_kernel<2, .>)
+    args.remove("--certify"); flags = 0
 batches = (64, 96, 128, 192, 256, 384, 512, 1024)
 if "--batches" in args:
     i = args.index("--batches"); batches = tuple(int(x) for x in args[i + 1].split(",")); del args[i:i + 2]
@@ -39,7 +42,7 @@ for N in sizes:
                 L.atlas_tune_set_scan_gemm(mode)
                 def call():
                     rc = L.atlas_scan_topk_flags(q.data_ptr(), _lib.DT_F16, slab.data_ptr(), N, B, D, k, 1.002, out_s.data_ptr(), out_i.data_ptr(), out_st.data_ptr(),
-                                                 ws.data_ptr(), ws.numel(), stream, None, None, _lib.SCAN_TRUST_PMAX)
+                                                 ws.data_ptr(), ws.numel(), stream, None, None, flags)
                     assert rc == 0, rc
                 for _ in range(2): call()
                 torch.cuda.synchronize(); t = time.perf_counter()

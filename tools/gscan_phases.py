@@ -1,11 +1,14 @@
 """Shader-clock stamps of workgroup 0 of the GEMM-shaped scan (tuning build): what a k-tile's two phases are made of.
-    python tools/gscan_phases.py [rows] [queries]"""
+    python tools/gscan_phases.py [rows] [queries] [--certify]"""
 import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
 from _tune import L  # noqa: E402
 import sys
 import torch
 from atlas_amd import _lib
 
+FLAGS = _lib.SCAN_TRUST_PMAX
+if "--certify" in sys.argv:      # the twin that measures every row norm (gscan_kernel<2, .>)
+    sys.argv.remove("--certify"); FLAGS = 0
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 k, D = 40, 768
@@ -22,7 +25,7 @@ IT = 32
 dbg = torch.zeros(8 * IT * 8 + 8 * 8 * 4 + 4, dtype=torch.int64, device="cuda")
 def call():
     rc = L.atlas_scan_topk_flags(q.data_ptr(), _lib.DT_F16, slab.data_ptr(), N, B, D, k, 1.002, out_s.data_ptr(), out_i.data_ptr(), out_st.data_ptr(),
-                                 ws.data_ptr(), ws.numel(), stream, None, None, _lib.SCAN_TRUST_PMAX)
+                                 ws.data_ptr(), ws.numel(), stream, None, None, FLAGS)
     assert rc == 0, rc
 for _ in range(3): call()
 torch.cuda.synchronize()
