@@ -599,6 +599,38 @@ def test_duplicated_passages_at_1m_stay_bounded(big, gpu_index_cls):
     assert dt < 0.25, f"{dt:.3f} s for a search with {st['fallback_queries']} flagged queries"
 
 
+def test_gemm_shaped_passes_random_cases_equal_the_exact_path(gpu_index_cls):
+    """random shard sizes (incl. the 65 536-row minimum and ragged last tiles), batch sizes through every column-tile width and into a second
+    pass, k, score scales, duplicated rows, both twins -- against the MFMA-free exact path on the device (tools/gscan_fuzz.py runs more of them:
+    profiles/r04/gscan_fuzz_48_cases.txt)"""
+    rng = np.random.default_rng(77)
+    g = torch.Generator(device="cuda").manual_seed(78)
+    for c in range(16):
+        N = int(rng.choice([65536, 65536 + int(rng.integers(1, 256)), int(rng.integers(66000, 400000)), int(rng.integers(400000, 1200000))]))
+        B = int([rng.integers(97, 129), rng.integers(129, 193), rng.integers(193, 257), rng.integers(257, 385), rng.integers(385, 513),
+                 rng.integers(513, 1025), rng.integers(1025, 1300)][c % 7])
+        k = int(rng.choice([1, 5, 40, 40, 100, 256]))
+        scale = float(rng.choice([1.0, 1.0, 0.05, 4.0]))
+        slab = torch.empty((N, 768), dtype=torch.float16, device="cuda")
+        for r0 in range(0, N, 200_000):
+            n = min(200_000, N - r0)
+            x = torch.randn((n, 768), generator=g, device="cuda")
+            slab[r0 : r0 + n] = (x / x.norm(dim=1, keepdim=True) * scale).half()
+        if c % 3 == 0:
+            slab[N // 2 : N // 2 + 1000] = slab[:1000]
+        q = torch.randn((B, 768), generator=g, device="cuda") * float(rng.choice([1.0, 0.3, 3.0]))
+        idx = gpu_index_cls(certify_every=1 if c % 2 else 64)
+        idx.init_embeddings([None] * 0)
+        idx._set_slab(slab)
+        idx.doc_map = {}
+        s, i = idx._compute_scores_and_indices(q, k)
+        st = dict(idx.last_search_stats)
+        assert st["path"] == "scan" and st["plan"]["gemm_passes"] >= 1 and st["pmax_trusted"] is (c % 2 == 0), (c, st)
+        es, ei = idx._exact_topk(q, k)
+        assert torch.equal(s, es) and torch.equal(i, ei), (c, N, B, k, scale, st)
+        del idx, slab
+
+
 def test_batches_of_65_to_96_queries_on_a_large_shard_take_the_gemm_shaped_pass_and_agree_with_the_streaming_passes(gpu_index_cls):
     """from 6M rows on a batch of 65..96 queries is one 128-wide GEMM-shaped pass (atlas_hip.hip: GS_SMALL_BATCH_MIN_ROWS); its results must be
     those of the two halves searched on their own (64-query streaming passes) and of the MFMA-free exact path -- a size-independent property"""
