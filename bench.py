@@ -457,6 +457,24 @@ def main():
             # the passes the library made of this batch, as IT reports them (ATLAS_ST_PLAN); every launch -- a single pass, a pair, a
             # GEMM-shaped pass of up to 1024 queries -- reads the slab from HBM about once (an estimate for pairs / column tiles: the second
             # reader of a row is served by the L2 / Infinity Cache, not measured here)
+            # the certifying twin of the same batch (the C-ABI's default contract: every row norm measured beside the MFMAs) at the sizes of an
+            # 8-GPU and a 2-GPU search: what trusting the certified pmax is worth there
+            cert_ms = None
+            if Bb in (128, 512):
+                def c_step():
+                    rc = L.atlas_scan_topk_flags(qb.data_ptr(), _lib.DT_F32, slab.data_ptr(), n_b, Bb, D, k, pm_b, o_s.data_ptr(), o_i.data_ptr(),
+                                                 o_st.data_ptr(), ws_b.data_ptr(), ws_b.numel(), stream, None, None, 0)
+                    assert rc == 0, rc
+                for _ in range(2):
+                    c_step()
+                fence()
+                tc = time.perf_counter()
+                for _ in range(10):
+                    c_step()
+                fence()
+                cert_ms = (time.perf_counter() - tc) / 10 * 1e3
+                assert int(o_st.cpu()[_lib.ST_FLAGS]) == 0 and torch.equal(o_s, sb) and torch.equal(o_i, ib)
+                b_step(); fence()                                        # (the status word below is the trusting call's)
             plan_b = _lib.decode_plan(int(o_st.cpu()[_lib.ST_PLAN]))
             launches = sum(plan_b.values())
             flops = 2.0 * Bb * n_b * D
@@ -466,6 +484,8 @@ def main():
                                     "tflops": flops / dtb / 1e12, "frac_of_mfma_peak": flops / dtb / 1e12 / MFMA_PEAK_TFLOPS,
                                     "bound": "mfma" if Bb > 312 else "hbm",      # arithmetic intensity B flop/B against the ridge ~312
                                     "parity_checked": {"rows": n_b, "queries_exact": int(sel_b.numel())}}
+            if cert_ms is not None:
+                batch_sweep[str(Bb)]["certifying_ms_per_step"] = cert_ms
         del subb
 
     cpu = None

@@ -10,7 +10,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LINES = ["r01/bench_default_32m.json", "r01/bench_4m.json", "r01/bench_1m.json", "r02/bench_default_32m_sessionM.json",
-         "r03/bench_default_32m_sessionAC.json", "r04/bench_default_32m_sessionS1.json", "r04/bench_default_32m_sessionF3.json"]
+         "r03/bench_default_32m_sessionAC.json", "r04/bench_default_32m_sessionS1.json", "r04/bench_default_32m_sessionF3.json",
+         "r04/bench_default_32m_sessionF10.json"]
 
 
 @pytest.mark.parametrize("name", LINES)
@@ -140,6 +141,18 @@ def test_round4_final_line_has_the_tile_widths_the_traffic_and_the_refresh():
     rf = d["refresh"]
     assert rf["ms_per_batch"] <= 13.5 and 0.34 <= rf["roofline"]["frac"] < 0.37          # VERDICT r03 #2's 0.37 is NOT met: DESIGN.md §4.4, §7
     assert abs(rf["roofline"]["frac"] - rf["value"] * rf["roofline"]["flops_per_passage"] / 2.5e15) < 1e-6
+
+
+def test_line_with_the_certifying_twin_of_the_big_batches():
+    """bench.py's last line of the round (another box: HBM side slower, MFMA side faster than F3's) times the certifying twin of the GEMM-shaped
+    pass beside the trusting one at 128 and 512 queries: the default C-ABI contract costs 6-12 % there on fp32 queries"""
+    d = _line(LINES[7])
+    bs = d["batch_sweep"]
+    for b in ("128", "512"):
+        c = bs[b]["certifying_ms_per_step"]
+        assert bs[b]["ms_per_step"] < c < 1.3 * bs[b]["ms_per_step"], (b, c, bs[b]["ms_per_step"])
+    assert all("certifying_ms_per_step" not in v for b, v in bs.items() if b not in ("128", "512"))
+    assert bs["512"]["frac_of_mfma_peak"] >= 0.45 and d["roofline"]["traffic"] is not None and d["refresh"]["roofline"]["frac"] >= 0.34
 
 
 def test_bench_refuses_to_run_without_a_gpu():
