@@ -498,9 +498,13 @@ scan_kernel(const ScanParams pk) {
     for (int pf = 0; pf < PF; ++pf)
 #pragma unroll
         for (int qf = 0; qf < NQF; ++qf) acc[pf][qf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float nrm[PF];
+    // row norms of the certifying twin: the GRAM matrix of the wave's 16 rows, one more MFMA per k-step with the slab fragment as BOTH
+    // operands (A[i][k] and B[k][j] of v_mfma_16x16x32 have the same register layout: D = A A^T) -- its diagonal is the rows' sums of
+    // squares, accumulated in fp32 like everything else. It replaces 4 dependent v_dot2 per k-step, which cost the kernel 7.5 % (0.724 vs
+    // 0.782 of the HBM peak at 32M rows) although the matrix pipe is only ~20 % busy: it is the wave's instruction stream that is full.
+    f32x4 gram[PF];
 #pragma unroll
-    for (int pf = 0; pf < PF; ++pf) nrm[pf] = 0.f;
+    for (int pf = 0; pf < PF; ++pf) gram[pf] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float pm = 0.0f;   // running max of row sum-of-squares seen by this lane's row group
 
     // rows relative to r_begin fit 32 bits (plan guarantees rows_per_wg * 1536 < 2^32)
@@ -710,18 +714,8 @@ scan_kernel(const ScanParams pk) {
                 for (int qf = 0; qf < NQF; ++qf)
                     acc[pf][qf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
                         av, __builtin_bit_cast(f16x8, b[qf]), acc[pf][qf], 0, 0, 0);
-                // row sum of squares (certifies pmax_hint): 4 x v_dot2_f32_f16
-                // (element copies first: __builtin_bit_cast straight on an ext-vector element
-                //  reads element 0 for every swizzle on ROCm 7.2's clang)
-                const unsigned ax = a.x, ay = a.y, az = a.z, aw = a.w;
-                const f16x2 h0 = __builtin_bit_cast(f16x2, ax), h1 = __builtin_bit_cast(f16x2, ay);
-                const f16x2 h2 = __builtin_bit_cast(f16x2, az), h3 = __builtin_bit_cast(f16x2, aw);
-                if constexpr (!(AUX & 64)) {
-                nrm[pf] = __builtin_amdgcn_fdot2(h0, h0, nrm[pf], false);
-                nrm[pf] = __builtin_amdgcn_fdot2(h1, h1, nrm[pf], false);
-                nrm[pf] = __builtin_amdgcn_fdot2(h2, h2, nrm[pf], false);
-                nrm[pf] = __builtin_amdgcn_fdot2(h3, h3, nrm[pf], false);
-                }
+                // row sums of squares (certifies pmax_hint): the diagonal of the fragment's Gram matrix
+                if constexpr (!(AUX & 64)) gram[pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, av, gram[pf], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -732,13 +726,15 @@ scan_kernel(const ScanParams pk) {
         cstep = 0;
         const bool have_rows = row0 < nrows;        // wave-uniform
         if (have_rows) {
-            // full row norms: the 4 lanes {l, l+16, l+32, l+48} hold the 4 k-groups of row l&15
+            // full row norms: lane (column lrow, rows 4 lgrp + r) of the Gram matrix holds the diagonal element of row lrow iff lgrp == lrow >> 2
+            if constexpr (!(AUX & 64)) {
 #pragma unroll
-            for (int pf = 0; pf < PF; ++pf) {
-                float x = nrm[pf];
-                x += __shfl_xor(x, 16);
-                x += __shfl_xor(x, 32);
-                pm = fmaxf(pm, x);
+                for (int pf = 0; pf < PF; ++pf) {
+                    const f32x4 gm = gram[pf];
+                    const int r = lrow & 3;
+                    const float x = r == 0 ? gm[0] : r == 1 ? gm[1] : r == 2 ? gm[2] : gm[3];
+                    pm = fmaxf(pm, lgrp == (lrow >> 2) ? x : 0.f);
+                }
             }
         }
         // rows past the end of this workgroup's range never become candidates (a per-row flag that the maxima and the filter look at: writing
@@ -818,7 +814,7 @@ scan_kernel(const ScanParams pk) {
         }
 #pragma unroll
         for (int pf = 0; pf < PF; ++pf) {
-            nrm[pf] = 0.f;
+            gram[pf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int qf = 0; qf < NQF; ++qf) acc[pf][qf] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }

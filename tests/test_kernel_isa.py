@@ -54,6 +54,8 @@ def test_scan_has_no_scratch_and_a_clean_loop():
     assert len(fns) == 4, sorted(fns)                        # 64 / 96 queries per pass x the certifying twin and the one that trusts pmax
     for name, body in fns.items():
         nmf = 48 if "ELi6EEE" in name else 32                # MFMAs of a ring revolution: 8 k-steps x 4 (6) query fragments
+        if "ELi8ELi0ELi" in name:                            # + the certifying twin's Gram MFMA per k-step (row norms = its diagonal)
+            nmf += 8
         lines = [l.strip() for l in body.split("\n")]
         mf = [i for i, l in enumerate(lines) if l.startswith("v_mfma")]
         first = next(i for i in mf if sum(1 for j in mf if i <= j < i + 600) >= nmf)
