@@ -157,3 +157,21 @@ def torch_dtype_code(dtype):
     if dtype == torch.bfloat16:
         return DT_BF16
     return None
+
+
+def scan_sources_sha256() -> str:
+    """sha256 of the CODE of csrc/scan_kernel.h + merge_kernel.h + atlas_hip.hip (the 64-query scan AND its launch plan), comments and blank lines
+    stripped: what profiles/pmc_traffic.json is keyed on -- bench.py quotes its PMC traffic only for exactly this code, and an edited comment
+    does not invalidate a measurement"""
+    import hashlib
+    import re
+
+    h = hashlib.sha256()
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    for f in ("scan_kernel.h", "merge_kernel.h", "atlas_hip.hip"):
+        text = open(os.path.join(here, f), encoding="utf-8").read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)                 # block comments
+        text = re.sub(r"//[^\n]*", "", text)                             # line comments (no string literal of these files holds //)
+        lines = [" ".join(l.split()) for l in text.split("\n")]
+        h.update("\n".join(l for l in lines if l).encode())
+    return h.hexdigest()

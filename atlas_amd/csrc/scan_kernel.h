@@ -276,8 +276,8 @@ struct ScanSmemT {  // byte offsets into dynamic LDS; NQ = queries per slab pass
 typedef ScanSmemT<64> ScanSmem;
 
 // AUX & 31 = cache-policy bits of the slab loads (0 = default, 2 = nt: rows are read once by one CU)
-// AUX & 64 = the caller's pmax is certified (ATLAS_SCAN_TRUST_PMAX): the row norms are not measured (4 v_dot2 per MFMA less; the
-//            kernel runs at the board's power limit and that VALU work was 4.6 % of its time, profiles/r02/scan_power.txt)
+// AUX & 64 = the caller's pmax is certified (ATLAS_SCAN_TRUST_PMAX): the row norms are not measured (one Gram MFMA per k-step less -- see
+//            `gram` below; as 4 v_dot2 per k-step, rounds 2-3, the measurement was 4.6-7.5 % of the kernel's time, now ~3 %)
 // NQF = 16-query fragments per slab k-step: 4 (64 queries per pass: every search of up to 64 queries) or 6 (96 queries per pass, round 3:
 //       batches above 64 queries -- a rank of an N-GPU search scores ALL gathered queries -- read the slab once per 96 instead of once
 //       per 64. The stream is 10 % slower under 6 MFMAs + 6 LDS reads per 16-byte load -- the kernel sits at the board's power limit --
@@ -860,7 +860,7 @@ scan_kernel(const ScanParams pk) {
             const uint32_t gs = atomicAdd(&s_cnt[qq], 1u);
             if (gs < (uint32_t)p.cap) my_lists[qq * qstride + gs] = make_uint2(e.x, global_row(e.y & ROWMASK));
         }
-        // largest row norm^2 of the workgroup (x1.001: v_dot2 accumulates in fp32): waves -> LDS -> one word
+        // largest row norm^2 of the workgroup (x1.001: the Gram MFMA accumulates in fp32): waves -> LDS -> one word
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) pm = fmaxf(pm, __shfl_xor(pm, o));
         float* s_pm = (float*)(smem + ScanSmem::aux_off);

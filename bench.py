@@ -623,7 +623,7 @@ def main():
             import hashlib
 
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            src = hashlib.sha256(b"".join(open(os.path.join(ROOT, "atlas_amd", "csrc", f), "rb").read() for f in ("scan_kernel.h", "merge_kernel.h", "atlas_hip.hip"))).hexdigest()
+            src = _lib.scan_sources_sha256()          # (code only: comments and blank lines stripped)
             # only a PMC pass of THESE sources counts (the kernel and the launch plan that decides its grid and tile pool): a pass of an
             # older build says nothing about this one's re-reads
             if pmc.get("sources_sha256") == src:

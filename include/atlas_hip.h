@@ -89,7 +89,7 @@ const char* atlas_build_info(void);          /* "gfx950 <compile date> ..." */
  *   pmax_hint  upper bound on the L2 norm of any slab row (the certified error margin
  *              scales with it); if a larger row is met, ATLAS_F_PMAX_VIOLATION is raised
  *              and the measured maximum is reported so the caller can re-run once. Measuring every row's norm inside
- *              the scan is not free (4 v_dot2 per MFMA: 4.6 % of the scan time on a power-limited MI355X): a caller that KNOWS
+ *              the scan is not free (one Gram MFMA per k-step: ~3 % of the scan time; 4 v_dot2 per k-step before round 4: 4.6-7.5 %): a caller that KNOWS
  *              its bound -- atlas_slab_pmax() taken after the last write to the slab -- passes ATLAS_SCAN_TRUST_PMAX to
  *              atlas_scan_topk_flags() and the scan takes pmax_hint as certified (ATLAS_ST_PMAX_BITS then reads 0)
  *   out_score  [B x k] fp16, canonical scores, descending

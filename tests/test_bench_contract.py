@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LINES = ["r01/bench_default_32m.json", "r01/bench_4m.json", "r01/bench_1m.json", "r02/bench_default_32m_sessionM.json",
          "r03/bench_default_32m_sessionAC.json", "r04/bench_default_32m_sessionS1.json", "r04/bench_default_32m_sessionF3.json",
-         "r04/bench_default_32m_sessionF10.json"]
+         "r04/bench_default_32m_sessionF10.json", "r04/bench_default_32m_sessionF12.json"]
 
 
 @pytest.mark.parametrize("name", LINES)
@@ -153,6 +153,28 @@ def test_line_with_the_certifying_twin_of_the_big_batches():
         assert bs[b]["ms_per_step"] < c < 1.3 * bs[b]["ms_per_step"], (b, c, bs[b]["ms_per_step"])
     assert all("certifying_ms_per_step" not in v for b, v in bs.items() if b not in ("128", "512"))
     assert bs["512"]["frac_of_mfma_peak"] >= 0.45 and d["roofline"]["traffic"] is not None and d["refresh"]["roofline"]["frac"] >= 0.34
+
+
+def test_final_code_line_certifying_twin_within_five_per_cent_of_the_trusting_one():
+    """the line of the round's final code (a middling box): with the row norms taken from the Gram MFMA the certifying twin of the 64-query scan --
+    the C-ABI's default contract -- is 0.74 of the HBM peak where the trusting one is 0.775 (round 3: 0.714 / 0.777)"""
+    d = _line(LINES[8])
+    r = d["roofline"]
+    assert r["traffic"] is not None and r["frac"] >= 0.77 and r["certifying"]["frac"] >= 0.735
+    assert r["certifying"]["frac"] >= 0.95 * r["frac"]
+    assert d["batch_sweep"]["512"]["frac_of_mfma_peak"] >= 0.45
+
+
+def test_committed_pmc_traffic_belongs_to_the_committed_scan_code():
+    """profiles/pmc_traffic.json is keyed on the CODE of the scan sources (comments and blank lines stripped): bench.py quotes `roofline.traffic`
+    only when the key matches, so a code change without a new PMC pass must turn this red here, not null on the driver's box"""
+    sys.path.insert(0, ROOT)
+    from atlas_amd import _lib
+
+    j = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert j["sources_sha256"] == _lib.scan_sources_sha256()
+    for n, v in j["per_rows"].items():
+        assert 0.97 <= v["ratio_to_algorithmic"] < 1.06 and v["calib_bytes"] == int(n) * 1536, (n, v)
 
 
 def test_bench_refuses_to_run_without_a_gpu():

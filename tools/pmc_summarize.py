@@ -2,19 +2,21 @@
 roofline.traffic). FETCH_SIZE on gfx950 under-reports wide reads ~2x (MI355X_MICROARCH.md §HBM), so the scan's counter is calibrated
 against stream_kernel<1,..> in the SAME pass, which reads exactly rows x 1536 bytes with the scan's access pattern:
     traffic = FETCH_SIZE(scan) x known_bytes / FETCH_SIZE(stream).
-The file records the sha256 of csrc/scan_kernel.h + csrc/merge_kernel.h + csrc/atlas_hip.hip (the kernel AND its launch plan: pool split, grid): bench.py only
-quotes a traffic figure measured on the sources it runs.
+The file records the sha256 of the CODE of csrc/scan_kernel.h + csrc/merge_kernel.h + csrc/atlas_hip.hip (the kernel AND its launch plan: pool split, grid;
+comments and blank lines stripped: atlas_amd._lib.scan_sources_sha256): bench.py only quotes a traffic figure measured on the code it runs.
 
     python tools/pmc_summarize.py gpurun_out/r02p/pmc_1000000 gpurun_out/r02p/pmc_4000000 gpurun_out/r02p/pmc_32000000
 """
-import csv, glob, hashlib, json, os, sys
+import csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from atlas_amd import _lib  # noqa: E402
 out = {"note": "HBM read traffic of ONE scan_kernel launch from rocprofv3 --pmc FETCH_SIZE (own pass, --kernel-trace only), calibrated in the same pass "
                "against stream_kernel<1,4,8> (exactly rows*1536 B, the scan's access pattern): traffic = FETCH_SIZE_scan * known_bytes / FETCH_SIZE_stream. "
-               "Raw CSVs under profiles/r03/pmc/.",
+               "Raw CSVs: profiles/r04/pmc_*_fetch_counter_collection.csv.",
        "kernel": "scan_kernel<16,1,8>",
-       "sources_sha256": hashlib.sha256(b"".join(open(os.path.join(ROOT, "atlas_amd", "csrc", f), "rb").read() for f in ("scan_kernel.h", "merge_kernel.h", "atlas_hip.hip"))).hexdigest(),
+       "sources_sha256": _lib.scan_sources_sha256(),
        "per_rows": {}}
 for d in sys.argv[1:]:
     fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
