@@ -737,7 +737,91 @@ __global__ void __launch_bounds__(1024) atlas_spin_kernel(unsigned long long tic
 }
 #endif
 
+// The passes a batch of B queries is made of (pure host arithmetic: CPU tests call it through atlas_test_plan_word). `ws_bytes` = the caller's
+// workspace (what does not fit is not planned).
+struct Pass { int nq, nq2; bool wide; bool gemm; };
+struct BatchPlan { int rc; ScanPlan single, pair; bool wide_ok; std::vector<Pass> passes; int plan_word; };
+static BatchPlan plan_batch(const int64_t N, const int B, const int d, const int k, const int cus, const size_t ws_bytes, const ScanVariant& var) {
+    // Wide (96-query) passes need the coop exchange (one granule slot per query and workgroup) and the production shape.
+    BatchPlan bp{};
+    ScanPlan pl = make_plan(N, d, k, cus, var);
+    const bool wide_ok = B > QCHUNK && scan_variant_index() == 0 && pl.S > 0 && pl.G >= QWIDE && pl.G <= 256 && scan_coop_enabled() &&
+                         scan_wide_enabled() && scan_plan_supported(pl, 25);
+    if (wide_ok) pl = make_plan(N, d, k, cus, var, QWIDE);
+    if (!scan_plan_supported(pl)) { bp.rc = ATLAS_E_UNSUPPORTED; return bp; }
+    if (ws_bytes < pl.total) { bp.rc = ATLAS_E_WORKSPACE; return bp; }
+    // Passes of the batch, in order. Items: one 64-query pass (cost 1), one 96-query pass (1.11), a PAIR of 64-query passes run concurrently
+    // on half the chip each (1.62 for up to 128 queries: the second reader of a slab row hits the Infinity Cache), a pair of 96-query
+    // passes (1.89 for up to 192); f(n) = min over the items of cost + f(n - size): 128 -> a pair of 64, 192 -> a pair of 96,
+    // 512 -> 2 pairs of 96 + a pair of 64.
+    // ... and GEMM-shaped passes (gscan_kernel.h) of up to 128 / 192 / 256 / 384 / 512 / 1024 queries (GS_WIDTH, GS_COSTS above) for batches above 96
+    // queries -- above 64 on shards of GS_SMALL_BATCH_MIN_ROWS rows or more --: MFMA-bound instead of LDS-fed, one slab read from HBM per pass
+    // whatever its width; both twins (pmax trusted / every row norm measured).
+    std::vector<Pass>& passes = bp.passes;
+    ScanPlan pp = pl;                           // the half-chip plan of paired passes
+    const int half = cus / 2;
+    bool pair_ok = B > QCHUNK && scan_variant_index() == 0 && scan_pair_enabled() && scan_coop_enabled() && half % 8 == 0 && half >= QCHUNK && half <= 256;
+    if (pair_ok) {
+        pp = make_plan(N, d, k, half, var, wide_ok ? QWIDE : QCHUNK);
+        pair_ok = pp.S > 0 && pp.G == half && scan_plan_supported(pp, wide_ok ? 25 : 26) && ws_bytes >= pp.bulk_begin + 2 * pp.bulk_size;
+    }
+    const bool pair_wide_ok = pair_ok && wide_ok && half >= QWIDE;
+    bool gemm_ok[GS_NW] = {}, any_gemm = false;
+    if ((B > QWIDE || (B > QCHUNK && N >= GS_SMALL_BATCH_MIN_ROWS)) && scan_variant_index() == 0 && scan_gemm_enabled()) {
+        for (int i = 0; i < GS_NW; ++i) {
+            const GPlan g = make_gplan(N, GS_WIDTH[i], cus);
+            gemm_ok[i] = g.ok && ws_bytes >= g.total;
+            any_gemm = any_gemm || gemm_ok[i];
+        }
+    }
+    if (B <= QCHUNK || (!wide_ok && !pair_ok && !any_gemm)) {
+        for (int r = B; r > 0; r -= QCHUNK) passes.push_back({r < QCHUNK ? r : QCHUNK, 0, false, false});
+    } else {
+        // costs in units of one 64-query pass (measured at 4M and 32M rows: profiles/r03/batch_paired_pass_ab.txt, profiles/r04/batch_gemm_pass_ab.txt)
+        constexpr int NI = 4 + GS_NW;
+        const float gcost[GS_NW] = GS_COSTS;
+        float cost[NI] = {1.0f, 1.11f, 1.62f, 1.89f};
+        int size[NI] = {QCHUNK, QWIDE, 2 * QCHUNK, 2 * QWIDE};
+        bool ok[NI] = {true, wide_ok, pair_ok, pair_wide_ok};
+        for (int i = 0; i < GS_NW; ++i) { cost[4 + i] = gcost[i]; size[4 + i] = GS_WIDTH[i]; ok[4 + i] = gemm_ok[i]; }
+        std::vector<float> f((size_t)B + 1, 0.f);
+        std::vector<unsigned char> take((size_t)B + 1, 0);
+        for (int n = 1; n <= B; ++n) {
+            float best = 1e30f;
+            for (int it = 0; it < NI; ++it) {
+                if (!ok[it]) continue;
+                if ((it == 2 || it == 3) && n <= size[it - 2]) continue;     // a pair needs more queries than one pass of its kind takes
+                if (it > 4 && ok[it - 1] && n <= size[it - 1]) continue;     // a wider pass than the queries need
+                if (it == 4 && n <= QWIDE && wide_ok && N < GS_SMALL_BATCH_MIN_ROWS) continue;   // (up to 96 queries on a small shard: the streaming pass)
+                const float c = cost[it] + f[n > size[it] ? n - size[it] : 0];
+                if (c < best) { best = c; take[n] = (unsigned char)it; }
+            }
+            f[n] = best;
+        }
+        for (int r = B; r > 0;) {
+            const int it = take[r], m = r < size[it] ? r : size[it];
+            if (it < 2) passes.push_back({m, 0, it == 1, false});
+            else if (it < 4) passes.push_back({(m + 1) / 2, m / 2, it == 3, false});
+            else passes.push_back({m, 0, false, true});
+            r -= m;
+        }
+    }
+    for (const Pass& ps : passes)
+        bp.plan_word += ps.gemm ? (1 << 24) : ps.nq2 > 0 ? (ps.wide ? (1 << 20) : (1 << 16)) : (ps.wide ? (1 << 8) : 1);
+    bp.single = pl; bp.pair = pp; bp.wide_ok = wide_ok;
+    return bp;
+}
+
 extern "C" {
+
+// test hook, deliberately not in include/atlas_hip.h: the ATLAS_ST_PLAN word a batch of B queries on N rows would report on a device of `cus`
+// compute units with a workspace of atlas_scan_topk_workspace_bytes' size (negative: the error atlas_scan_topk would return); no device needed
+int atlas_test_plan_word(int64_t N, int B, int k, int cus) {
+    if (B <= 0 || k <= 0 || N < 0) return ATLAS_E_BADARG;
+    if (k > K_FAST_MAX || N >= (int64_t)0xffffffffll) return ATLAS_E_UNSUPPORTED;
+    const BatchPlan bp = plan_batch(N, B, D_FAST, k, cus, (size_t)-1, kTrusted);
+    return bp.rc != 0 ? bp.rc : bp.plan_word;
+}
 
 // test hook, deliberately not in include/atlas_hip.h: the device's double -> fp16 conversions, elementwise
 // (out[2i] = software single-rounding path, out[2i+1] = hardware round-to-odd path)
@@ -839,78 +923,16 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
     // same shape, same plan; the trusted twin exists for the production variant only
     const bool trusted = (flags & ATLAS_SCAN_TRUST_PMAX) && scan_variant_index() == 0;
     const ScanVariant& var = trusted ? kTrusted : kVariants[scan_variant_index()];
-    // Batches above 64 queries: which passes take 96 queries? A 96-query pass costs ~1.10 of a 64-query pass (profiles/r03/
-    // scan_96_query_proxy.txt); f(n) = min(1 + f(n - 64), 1.10 + f(n - 96)) picks e.g. 64 + 64 for 128, 96 + 96 for 192, 5 x 96 + 32 for 512.
-    // Wide passes need the coop exchange (one granule slot per query and workgroup) and the production shape.
-    ScanPlan pl = make_plan(N, d, k, device_cus(), var);
-    const bool wide_ok = B > QCHUNK && scan_variant_index() == 0 && pl.S > 0 && pl.G >= QWIDE && pl.G <= 256 && scan_coop_enabled() &&
-                         scan_wide_enabled() && scan_plan_supported(pl, 25);
-    if (wide_ok) pl = make_plan(N, d, k, device_cus(), var, QWIDE);
-    if (!scan_plan_supported(pl)) return ATLAS_E_UNSUPPORTED;
-    if (ws_bytes < pl.total) return ATLAS_E_WORKSPACE;
+    const BatchPlan bp = plan_batch(N, B, d, k, device_cus(), ws_bytes, var);
+    if (bp.rc != 0) return bp.rc;
+    const ScanPlan& pl = bp.single;
+    const ScanPlan& pp = bp.pair;                // the half-chip plan of paired passes
+    const bool wide_ok = bp.wide_ok;
+    const std::vector<Pass>& passes = bp.passes;
+    const int plan_word = bp.plan_word;
+    const ScanVariant& wide = trusted ? kWideTrusted : kWide;
     hipStream_t stream = (hipStream_t)stream_;
     unsigned char* w = (unsigned char*)ws;
-    // Passes of the batch, in order. Items: one 64-query pass (cost 1), one 96-query pass (1.11), a PAIR of 64-query passes run concurrently
-    // on half the chip each (1.62 for up to 128 queries: the second reader of a slab row hits the Infinity Cache), a pair of 96-query
-    // passes (1.89 for up to 192); f(n) = min over the items of cost + f(n - size): 128 -> a pair of 64, 192 -> a pair of 96,
-    // 512 -> 2 pairs of 96 + a pair of 64.
-    // ... and GEMM-shaped passes (gscan_kernel.h) of up to 128 / 192 / 256 / 384 / 512 / 1024 queries (GS_WIDTH, GS_COSTS above) for batches above 96
-    // queries -- above 64 on shards of GS_SMALL_BATCH_MIN_ROWS rows or more --: MFMA-bound instead of LDS-fed, one slab read from HBM per pass
-    // whatever its width; both twins (pmax trusted / every row norm measured).
-    struct Pass { int nq, nq2; bool wide; bool gemm; };
-    std::vector<Pass> passes;
-    ScanPlan pp = pl;                           // the half-chip plan of paired passes
-    const int half = device_cus() / 2;
-    bool pair_ok = B > QCHUNK && scan_variant_index() == 0 && scan_pair_enabled() && scan_coop_enabled() && half % 8 == 0 && half >= QCHUNK && half <= 256;
-    if (pair_ok) {
-        pp = make_plan(N, d, k, half, var, wide_ok ? QWIDE : QCHUNK);
-        pair_ok = pp.S > 0 && pp.G == half && scan_plan_supported(pp, wide_ok ? 25 : 26) && ws_bytes >= pp.bulk_begin + 2 * pp.bulk_size;
-    }
-    const bool pair_wide_ok = pair_ok && wide_ok && half >= QWIDE;
-    bool gemm_ok[GS_NW] = {}, any_gemm = false;
-    if ((B > QWIDE || (B > QCHUNK && N >= GS_SMALL_BATCH_MIN_ROWS)) && scan_variant_index() == 0 && scan_gemm_enabled()) {
-        for (int i = 0; i < GS_NW; ++i) {
-            const GPlan g = make_gplan(N, GS_WIDTH[i], device_cus());
-            gemm_ok[i] = g.ok && ws_bytes >= g.total;
-            any_gemm = any_gemm || gemm_ok[i];
-        }
-    }
-    if (B <= QCHUNK || (!wide_ok && !pair_ok && !any_gemm)) {
-        for (int r = B; r > 0; r -= QCHUNK) passes.push_back({r < QCHUNK ? r : QCHUNK, 0, false, false});
-    } else {
-        // costs in units of one 64-query pass (measured at 4M and 32M rows: profiles/r03/batch_paired_pass_ab.txt, profiles/r04/batch_gemm_pass_ab.txt)
-        constexpr int NI = 4 + GS_NW;
-        const float gcost[GS_NW] = GS_COSTS;
-        float cost[NI] = {1.0f, 1.11f, 1.62f, 1.89f};
-        int size[NI] = {QCHUNK, QWIDE, 2 * QCHUNK, 2 * QWIDE};
-        bool ok[NI] = {true, wide_ok, pair_ok, pair_wide_ok};
-        for (int i = 0; i < GS_NW; ++i) { cost[4 + i] = gcost[i]; size[4 + i] = GS_WIDTH[i]; ok[4 + i] = gemm_ok[i]; }
-        std::vector<float> f((size_t)B + 1, 0.f);
-        std::vector<unsigned char> take((size_t)B + 1, 0);
-        for (int n = 1; n <= B; ++n) {
-            float best = 1e30f;
-            for (int it = 0; it < NI; ++it) {
-                if (!ok[it]) continue;
-                if ((it == 2 || it == 3) && n <= size[it - 2]) continue;     // a pair needs more queries than one pass of its kind takes
-                if (it > 4 && ok[it - 1] && n <= size[it - 1]) continue;     // a wider pass than the queries need
-                if (it == 4 && n <= QWIDE && wide_ok && N < GS_SMALL_BATCH_MIN_ROWS) continue;   // (up to 96 queries on a small shard: the streaming pass)
-                const float c = cost[it] + f[n > size[it] ? n - size[it] : 0];
-                if (c < best) { best = c; take[n] = (unsigned char)it; }
-            }
-            f[n] = best;
-        }
-        for (int r = B; r > 0;) {
-            const int it = take[r], m = r < size[it] ? r : size[it];
-            if (it < 2) passes.push_back({m, 0, it == 1, false});
-            else if (it < 4) passes.push_back({(m + 1) / 2, m / 2, it == 3, false});
-            else passes.push_back({m, 0, false, true});
-            r -= m;
-        }
-    }
-    const ScanVariant& wide = trusted ? kWideTrusted : kWide;
-    int plan_word = 0;
-    for (const Pass& ps : passes)
-        plan_word += ps.gemm ? (1 << 24) : ps.nq2 > 0 ? (ps.wide ? (1 << 20) : (1 << 16)) : (ps.wide ? (1 << 8) : 1);
 
     auto merge = merge_rescore_kernel<MERGE_NT>;
     allow_lds(var.kern);

@@ -43,6 +43,43 @@ def test_abi_version_and_bad_args(so):
     assert L.atlas_merge_packed(None, 1, 1, 1, None, None) == -1
 
 
+def _plan(L, N, B, k=40, cus=256):
+    from atlas_amd import _lib
+
+    w = L.atlas_test_plan_word(ctypes.c_int64(N), B, k, cus)
+    assert w >= 0, (N, B, w)
+    return _lib.decode_plan(w)
+
+
+def test_pass_planner_without_a_device(so):
+    """the passes a batch is made of (atlas_hip.hip::plan_batch, pure host arithmetic behind a test hook; ATLAS_ST_PLAN reports the same word from
+    a real call): one streaming pass up to 64 / 96 queries, GEMM-shaped passes of 128 / 192 / 256 / 384 / 512 / 1024 queries above that -- from 65
+    queries on shards of >= 6M rows --, the streaming passes of round 3 on shards below 65 536 rows, and never more slab reads than queries / 64"""
+    L = ctypes.CDLL(so)
+    L.atlas_test_plan_word.restype = ctypes.c_int
+    one = lambda **kw: dict({"passes_64": 0, "passes_96": 0, "pairs_64": 0, "pairs_96": 0, "gemm_passes": 0}, **kw)
+    for N in (10_000, 1_000_000, 4_000_000, 32_000_000):
+        for B in (1, 7, 64):
+            assert _plan(L, N, B) == one(passes_64=1), (N, B)
+    assert _plan(L, 4_000_000, 96) == one(passes_96=1) and _plan(L, 1_000_000, 65) == one(passes_96=1)
+    assert _plan(L, 6_000_000, 96) == one(gemm_passes=1) and _plan(L, 32_000_000, 65) == one(gemm_passes=1)      # GS_SMALL_BATCH_MIN_ROWS
+    for B in (97, 128, 129, 192, 193, 256, 257, 384, 385, 512, 1024):
+        for N in (65_536, 1_000_000, 4_000_000, 32_000_000):
+            assert _plan(L, N, B) == one(gemm_passes=1), (N, B)                                                   # one slab read whatever the width
+    assert _plan(L, 4_000_000, 513) == one(gemm_passes=2)                                                         # 384 + 192 (3.62) beats 512 + 64 (3.69) and 1024 (5.02)
+    assert _plan(L, 4_000_000, 640) == one(gemm_passes=2) and _plan(L, 4_000_000, 768) == one(gemm_passes=2)     # 512 + 128, 512 + 256
+    assert _plan(L, 4_000_000, 1100) == one(gemm_passes=2) and _plan(L, 4_000_000, 2048) == one(gemm_passes=2)
+    p = _plan(L, 4_000_000, 320)                                                                                  # 384-wide, or 256 + 64
+    assert p in (one(gemm_passes=1), one(gemm_passes=1, passes_64=1)), p
+    # below 65 536 rows no GEMM-shaped pass: round 3's streaming passes (single, wide, paired)
+    p = _plan(L, 60_000, 512)
+    assert p["gemm_passes"] == 0 and sum(p.values()) >= 3, p
+    # a smaller device (a partition of 64 CUs): plans exist, nothing asks for more workgroups than CUs
+    assert sum(_plan(L, 4_000_000, 512, cus=64).values()) >= 1
+    # k beyond the fast path / a negative row count: the error codes of atlas_scan_topk
+    assert L.atlas_test_plan_word(ctypes.c_int64(1000), 64, 300, 256) == -3 and L.atlas_test_plan_word(ctypes.c_int64(-1), 64, 40, 256) == -1
+
+
 def test_gfx950_code_object(so):
     """the shared library embeds a gfx950 code object and nothing else"""
     data = open(so, "rb").read()
