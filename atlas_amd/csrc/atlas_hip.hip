@@ -667,12 +667,12 @@ constexpr int GS_MAXQ = 1024;
 constexpr int GS_NW = 6;
 constexpr int GS_WIDTH[GS_NW] = {128, 192, 256, 384, 512, 1024};
 constexpr int GS_CW[GS_NW] = {128, 192, 256, 192, 256, 256};
-// Batches of 65..96 queries: the 96-query streaming pass and the 128-wide GEMM-shaped pass cost the same at 4M rows (1.165 / 1.158 ms); the
-// GEMM-shaped one is 5 % faster at 32M (8.83 / 9.29 ms) and carries ~0.1 ms of launches (sample, two threshold kernels, two scan launches) that
-// a small shard does not amortise (1M rows: 0.36 / 0.32 ms, 2M: 0.62 / 0.60, 8M: 2.13 / 2.29, 16M: 4.15 / 4.53: profiles/r04/batch_65_96_crossover.txt): from
-// GS_SMALL_BATCH_MIN_ROWS rows on.
+// Batches of 65..96 queries: the 96-query streaming pass and the 128-wide GEMM-shaped pass break even around 3-4M rows (4M: 1.173 / 1.156 ms,
+// profiles/r04/batch_gemm_pass_ab_4m.txt); the GEMM-shaped one is 7-9 % faster from 8M rows on (32M: 8.39 / 9.14 ms) and carries ~0.1 ms of launches
+// (sample, two threshold kernels, two scan launches) that a small shard does not amortise (1M rows: 0.36 / 0.32 ms, 2M: 0.62 / 0.60:
+// profiles/r04/batch_65_96_crossover.txt): from GS_SMALL_BATCH_MIN_ROWS rows on.
 #ifndef GS_SMALL_BATCH_MIN_ROWS
-#define GS_SMALL_BATCH_MIN_ROWS 6000000
+#define GS_SMALL_BATCH_MIN_ROWS 4000000
 #endif
 #ifndef GS_COSTS
 #define GS_COSTS {1.10f, 1.30f, 1.50f, 2.32f, 2.69f, 5.02f}
@@ -813,6 +813,15 @@ static BatchPlan plan_batch(const int64_t N, const int B, const int d, const int
 }
 
 extern "C" {
+
+// test hook, deliberately not in include/atlas_hip.h: the launch geometry and workspace layout of one GEMM-shaped pass of nq queries (make_gplan), as
+// 17 words {ok, G, ncol, cw, ldq, rows_per_range, s_tiles, s_stride, nmax, gcap, off_q16, off_theta, off_gcnt, off_wgstat, off_smax, off_lists, total}
+void atlas_test_gplan(int64_t N, int nq, int cus, int64_t* out) {
+    const GPlan g = make_gplan(N, nq, cus);
+    const int64_t v[17] = {g.ok ? 1 : 0, g.G, g.ncol, g.cw, g.ldq, g.rows_per_range, g.s_tiles, g.s_stride, g.nmax, g.gcap, (int64_t)g.off_q16,
+                           (int64_t)g.off_theta, (int64_t)g.off_gcnt, (int64_t)g.off_wgstat, (int64_t)g.off_smax, (int64_t)g.off_lists, (int64_t)g.total};
+    for (int i = 0; i < 17; ++i) out[i] = v[i];
+}
 
 // test hook, deliberately not in include/atlas_hip.h: the ATLAS_ST_PLAN word a batch of B queries on N rows would report on a device of `cus`
 // compute units with a workspace of atlas_scan_topk_workspace_bytes' size (negative: the error atlas_scan_topk would return); no device needed

@@ -419,7 +419,7 @@ def main():
             del sub
 
     # ---- larger query batches on the 4M-row prefix (the shard of an 8-GPU run): a rank of a distributed search scores ALL gathered
-    # queries (src/index.py:127-131), B_total = W x b_r: up to 96 in one streaming pass (65..96 on a shard of >= 6M rows: the 128-wide GEMM-shaped
+    # queries (src/index.py:127-131), B_total = W x b_r: up to 96 in one streaming pass (65..96 on a shard of >= 4M rows: the 128-wide GEMM-shaped
     # pass), above that in GEMM-shaped passes of up to 128 / 192 / 256 / 384 / 512 / 1024 queries (csrc/gscan_kernel.h), where the matrix pipe is
     # the bound: `frac_of_mfma_peak`
     batch_sweep = None

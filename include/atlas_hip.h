@@ -105,7 +105,7 @@ const char* atlas_build_info(void);          /* "gfx950 <compile date> ..." */
  * otherwise returns ATLAS_E_UNSUPPORTED (callers then use atlas_exact_topk).
  * Any B >= 1 is accepted: up to 64 queries are one slab pass; a larger batch is a sequence of passes chosen by measured cost
  * (ATLAS_ST_PLAN reports it). Up to 64 queries the slab BYTES are the bound and the pass streams. Above that the matrix pipe takes over and the
- * passes are GEMM-shaped (csrc/gscan_kernel.h; shards of >= 65 536 rows; 65..96 queries from 6M rows on, a 96-query streaming pass below):
+ * passes are GEMM-shaped (csrc/gscan_kernel.h; shards of >= 65 536 rows; 65..96 queries from 4M rows on, a 96-query streaming pass below):
  * 256 slab rows x a column tile of 128, 192 or 256 queries per workgroup tile, both operands staged through LDS, up to 128 / 192 / 256 / 384 /
  * 512 / 1024 queries per pass for ONE slab read from HBM (the workgroups that score the same rows against different query tiles share them
  * through the L2); a sample launch gives every query its first threshold, a second scan launch runs with thresholds tightened by the

@@ -11,7 +11,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LINES = ["r01/bench_default_32m.json", "r01/bench_4m.json", "r01/bench_1m.json", "r02/bench_default_32m_sessionM.json",
          "r03/bench_default_32m_sessionAC.json", "r04/bench_default_32m_sessionS1.json", "r04/bench_default_32m_sessionF3.json",
-         "r04/bench_default_32m_sessionF10.json", "r04/bench_default_32m_sessionF12.json"]
+         "r04/bench_default_32m_sessionF10.json", "r04/bench_default_32m_sessionF12.json",
+         "r04/bench_default_32m_sessionF15.json"]
 
 
 @pytest.mark.parametrize("name", LINES)
@@ -163,6 +164,23 @@ def test_final_code_line_certifying_twin_within_five_per_cent_of_the_trusting_on
     assert r["traffic"] is not None and r["frac"] >= 0.77 and r["certifying"]["frac"] >= 0.735
     assert r["certifying"]["frac"] >= 0.95 * r["frac"]
     assert d["batch_sweep"]["512"]["frac_of_mfma_peak"] >= 0.45
+
+
+def test_the_rounds_line_final_code():
+    """session F15: the final code (smoke + `pytest -m gpu` 122 passed + the PMC pass of these sources in the same session): batches of 65..96 queries
+    take the 128-wide GEMM-shaped pass from 4M rows on, so the sweep is GEMM-shaped from 96 queries up and monotone; certifying twin >= 0.75"""
+    d = _line(LINES[9])
+    r = d["roofline"]
+    assert r["traffic"] is not None and 1.0 <= r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.05
+    assert r["frac"] >= 0.77 and r["certifying"]["frac"] >= 0.75
+    bs = d["batch_sweep"]
+    for b, v in bs.items():
+        assert (v["plan"]["gemm_passes"] == 1) == (int(b) > 64) and sum(v["plan"].values()) == 1, (b, v["plan"])
+    q = [bs[b]["queries_per_s"] for b in ("64", "96", "128", "192", "256", "384", "512", "1024")]
+    assert all(q[i] < q[i + 1] for i in range(len(q) - 1)), q
+    assert bs["96"]["ms_per_step"] <= 1.15 and bs["512"]["ms_per_step"] <= 2.8 and bs["512"]["frac_of_mfma_peak"] >= 0.45
+    assert bs["512"]["ms_per_step"] < bs["512"]["certifying_ms_per_step"] < 1.25 * bs["512"]["ms_per_step"]
+    assert d["refresh"]["ms_per_batch"] <= 13.5 and d["refresh"]["roofline"]["frac"] >= 0.34
 
 
 def test_committed_pmc_traffic_belongs_to_the_committed_scan_code():

@@ -54,15 +54,15 @@ def _plan(L, N, B, k=40, cus=256):
 def test_pass_planner_without_a_device(so):
     """the passes a batch is made of (atlas_hip.hip::plan_batch, pure host arithmetic behind a test hook; ATLAS_ST_PLAN reports the same word from
     a real call): one streaming pass up to 64 / 96 queries, GEMM-shaped passes of 128 / 192 / 256 / 384 / 512 / 1024 queries above that -- from 65
-    queries on shards of >= 6M rows --, the streaming passes of round 3 on shards below 65 536 rows, and never more slab reads than queries / 64"""
+    queries on shards of >= 4M rows --, the streaming passes of round 3 on shards below 65 536 rows, and never more slab reads than queries / 64"""
     L = ctypes.CDLL(so)
     L.atlas_test_plan_word.restype = ctypes.c_int
     one = lambda **kw: dict({"passes_64": 0, "passes_96": 0, "pairs_64": 0, "pairs_96": 0, "gemm_passes": 0}, **kw)
     for N in (10_000, 1_000_000, 4_000_000, 32_000_000):
         for B in (1, 7, 64):
             assert _plan(L, N, B) == one(passes_64=1), (N, B)
-    assert _plan(L, 4_000_000, 96) == one(passes_96=1) and _plan(L, 1_000_000, 65) == one(passes_96=1)
-    assert _plan(L, 6_000_000, 96) == one(gemm_passes=1) and _plan(L, 32_000_000, 65) == one(gemm_passes=1)      # GS_SMALL_BATCH_MIN_ROWS
+    assert _plan(L, 3_999_999, 96) == one(passes_96=1) and _plan(L, 1_000_000, 65) == one(passes_96=1)
+    assert _plan(L, 4_000_000, 96) == one(gemm_passes=1) and _plan(L, 32_000_000, 65) == one(gemm_passes=1)      # GS_SMALL_BATCH_MIN_ROWS
     for B in (97, 128, 129, 192, 193, 256, 257, 384, 385, 512, 1024):
         for N in (65_536, 1_000_000, 4_000_000, 32_000_000):
             assert _plan(L, N, B) == one(gemm_passes=1), (N, B)                                                   # one slab read whatever the width
@@ -78,6 +78,41 @@ def test_pass_planner_without_a_device(so):
     assert sum(_plan(L, 4_000_000, 512, cus=64).values()) >= 1
     # k beyond the fast path / a negative row count: the error codes of atlas_scan_topk
     assert L.atlas_test_plan_word(ctypes.c_int64(1000), 64, 300, 256) == -3 and L.atlas_test_plan_word(ctypes.c_int64(-1), 64, 40, 256) == -1
+
+
+def test_gemm_shaped_pass_geometry_without_a_device(so):
+    """make_gplan (launch geometry + workspace layout of one GEMM-shaped pass) over random shard sizes, pass sizes and CU counts: the column tiles
+    hold the queries, the row ranges tile the slab in whole 256-row tiles below the 24-bit row field of a candidate entry, the sample's tiles lie
+    inside the slab, the workspace regions are aligned, ordered and big enough"""
+    import numpy as np
+
+    L = ctypes.CDLL(so)
+    out = (ctypes.c_int64 * 17)()
+    rng = np.random.default_rng(5)
+    seen_ok = 0
+    for _ in range(3000):
+        N = int(rng.choice([rng.integers(1, 70_000), rng.integers(65_536, 300_000), rng.integers(300_000, 40_000_000), rng.integers(40_000_000, 4_000_000_000)]))
+        nq = int(rng.integers(1, 1100))
+        cus = int(rng.choice([8, 32, 64, 104, 128, 256, 304]))
+        L.atlas_test_gplan(ctypes.c_int64(N), nq, cus, out)
+        ok, G, ncol, cw, ldq, rpr, s_tiles, s_stride, nmax, gcap, o_q16, o_th, o_cnt, o_st, o_sm, o_li, total = (int(x) for x in out)
+        if not ok:
+            assert nq > 1024 or N // 256 < 256 or G < 8 * ncol or (N + 255) // 256 / max(1, G // max(1, ncol)) * 256 >= (1 << 24) - 256, (N, nq, cus)
+            continue
+        seen_ok += 1
+        assert cw in (128, 192, 256) and ncol in (1, 2, 4) and ldq == ncol * cw >= nq and (ldq < 2 * nq or ldq == 128), (nq, cw, ncol)
+        assert G % (8 * ncol) == 0 and 8 * ncol <= G <= cus and G <= 1024
+        nranges = G // ncol
+        # (trailing ranges may be empty: their workgroups return at once) the ranges cover the slab with the fewest whole tiles per range
+        assert rpr % 256 == 0 and rpr < (1 << 24) and nranges * rpr >= N and (rpr // 256 - 1) * nranges < (N + 255) // 256
+        assert 128 <= s_tiles <= 2048 and nmax == 16 * s_tiles and s_stride % 256 == 0 and s_stride >= 256
+        assert (s_tiles - 1) * s_stride + 256 <= N                                       # every sampled tile is a whole tile inside the slab
+        assert gcap == 32768
+        offs = [o_q16, o_th, o_cnt, o_st, o_sm, o_li, total]
+        assert all(o % 256 == 0 for o in offs[:-1]) and all(a < b for a, b in zip(offs, offs[1:]))
+        assert o_th - o_q16 >= ldq * 768 * 2 and o_cnt - o_th >= ldq * 4 and o_st - o_cnt >= ldq * 4 and o_sm - o_st >= G * 8 * 2
+        assert o_li - o_sm >= nmax * ldq * 4 and total - o_li == ldq * gcap * 8
+    assert seen_ok > 1000
 
 
 def test_gfx950_code_object(so):

@@ -632,7 +632,7 @@ def test_gemm_shaped_passes_random_cases_equal_the_exact_path(gpu_index_cls):
 
 
 def test_batches_of_65_to_96_queries_on_a_large_shard_take_the_gemm_shaped_pass_and_agree_with_the_streaming_passes(gpu_index_cls):
-    """from 6M rows on a batch of 65..96 queries is one 128-wide GEMM-shaped pass (atlas_hip.hip: GS_SMALL_BATCH_MIN_ROWS); its results must be
+    """from 4M rows on a batch of 65..96 queries is one 128-wide GEMM-shaped pass (atlas_hip.hip: GS_SMALL_BATCH_MIN_ROWS); its results must be
     those of the two halves searched on their own (64-query streaming passes) and of the MFMA-free exact path -- a size-independent property"""
     g = torch.Generator(device="cuda").manual_seed(4321)
     N = 6_500_000
