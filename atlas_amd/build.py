@@ -71,8 +71,14 @@ def build_host(force=False, verbose=False):
 
 
 def build_all(force=False, verbose=False):
-    hip = build_hip(force, verbose)
-    build_hip(force, verbose, tuning=True)
+    """product + tuning builds (side by side: two hipcc processes) + the host helper library"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(2) as ex:
+        a = ex.submit(build_hip, force, verbose)
+        b = ex.submit(build_hip, force, verbose, True)
+        hip = a.result()
+        b.result()
     return hip, build_host(force, verbose)
 
 

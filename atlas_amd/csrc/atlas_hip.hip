@@ -737,7 +737,7 @@ __global__ void __launch_bounds__(1024) atlas_spin_kernel(unsigned long long tic
 }
 #endif
 
-// The passes a batch of B queries is made of (pure host arithmetic: CPU tests call it through atlas_test_plan_word). `ws_bytes` = the caller's
+// The passes a batch of B queries is made of (pure host arithmetic: CPU tests call it through the tuning build's atlas_test_plan_word). `ws_bytes` = the caller's
 // workspace (what does not fit is not planned).
 struct Pass { int nq, nq2; bool wide; bool gemm; };
 struct BatchPlan { int rc; ScanPlan single, pair; bool wide_ok; std::vector<Pass> passes; int plan_word; };
@@ -814,7 +814,10 @@ static BatchPlan plan_batch(const int64_t N, const int B, const int d, const int
 
 extern "C" {
 
-// test hook, deliberately not in include/atlas_hip.h: the launch geometry and workspace layout of one GEMM-shaped pass of nq queries (make_gplan), as
+#if ATLAS_TUNING
+// Test hooks and knobs: the TUNING build only. The product library exports exactly what include/atlas_hip.h declares (tests/test_capi_symbols.py
+// compares `nm -D` with the header, both ways).
+// test hook: the launch geometry and workspace layout of one GEMM-shaped pass of nq queries (make_gplan), as
 // 17 words {ok, G, ncol, cw, ldq, rows_per_range, s_tiles, s_stride, nmax, gcap, off_q16, off_theta, off_gcnt, off_wgstat, off_smax, off_lists, total}
 void atlas_test_gplan(int64_t N, int nq, int cus, int64_t* out) {
     const GPlan g = make_gplan(N, nq, cus);
@@ -823,7 +826,7 @@ void atlas_test_gplan(int64_t N, int nq, int cus, int64_t* out) {
     for (int i = 0; i < 17; ++i) out[i] = v[i];
 }
 
-// test hook, deliberately not in include/atlas_hip.h: the ATLAS_ST_PLAN word a batch of B queries on N rows would report on a device of `cus`
+// test hook: the ATLAS_ST_PLAN word a batch of B queries on N rows would report on a device of `cus`
 // compute units with a workspace of atlas_scan_topk_workspace_bytes' size (negative: the error atlas_scan_topk would return); no device needed
 int atlas_test_plan_word(int64_t N, int B, int k, int cus) {
     if (B <= 0 || k <= 0 || N < 0) return ATLAS_E_BADARG;
@@ -832,18 +835,17 @@ int atlas_test_plan_word(int64_t N, int B, int k, int cus) {
     return bp.rc != 0 ? bp.rc : bp.plan_word;
 }
 
-// test hook, deliberately not in include/atlas_hip.h: the device's double -> fp16 conversions, elementwise
+// test hook: the device's double -> fp16 conversions, elementwise
 // (out[2i] = software single-rounding path, out[2i+1] = hardware round-to-odd path)
 __global__ void dbg_f64_to_f16_kernel(const double* in, uint16_t* out, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) { out[2 * i] = f64_to_f16_bits(in[i]); out[2 * i + 1] = f64_to_f16_bits_rto(in[i]); }
 }
-extern "C" int atlas_dbg_f64_to_f16(const double* in, uint16_t* out, int n, void* stream) {
+int atlas_dbg_f64_to_f16(const double* in, uint16_t* out, int n, void* stream) {
     hipLaunchKernelGGL(dbg_f64_to_f16_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, out, n);
     return (int)hipGetLastError();
 }
 
-#if ATLAS_TUNING
 // tuning build only (not in include/atlas_hip.h): scan variant, device buffers for cycle stamps
 void atlas_tune_set_scan_variant(int v) { g_scan_variant = v; }
 void atlas_tune_set_scan_coop(int c) { g_scan_coop = c; }

@@ -31,3 +31,13 @@ def gpu_index_cls():
     from atlas_amd import HipDistributedIndex
 
     return HipDistributedIndex
+
+
+@pytest.fixture(autouse=True)
+def _no_reference_stubs_survive_a_test():
+    """VERDICT r04 weak #1c: a test that imports the reference through in-memory stubs (`faiss`, a fake `src.retrievers`) must take them out of
+    sys.modules again -- otherwise the suite is green only in alphabetical order. Checked after every test (set up first, so torn down after the
+    test's own monkeypatch)."""
+    yield
+    left = [m for m in sys.modules if m in ("src", "faiss") or m.startswith("src.") or m.startswith("faiss.")]
+    assert not left, f"reference modules / stubs left in sys.modules: {left}"

@@ -16,6 +16,14 @@ def so():
     return build.build_hip()
 
 
+@pytest.fixture(scope="module")
+def tune_so():
+    """the -DATLAS_TUNING=1 build of the same sources: the host-side test hooks (plan word, pass geometry) live there, not in the product"""
+    from atlas_amd import build
+
+    return build.build_hip(tuning=True)
+
+
 def test_header_symbols_exported(so):
     hdr = open(os.path.join(ROOT, "include", "atlas_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
@@ -27,6 +35,21 @@ def test_header_symbols_exported(so):
     from atlas_amd import _lib
 
     assert set(_lib.SYMBOLS) == declared
+
+
+def test_product_exports_are_exactly_the_header(so):
+    """the header's "no hooks in the product" is enforced -- every dynamic `atlas_*` symbol libatlas_hip.so defines is
+    declared in include/atlas_hip.h and vice versa (test hooks and tuning knobs exist in libatlas_hip_tune.so only)"""
+    import subprocess
+
+    hdr = open(os.path.join(ROOT, "include", "atlas_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(atlas_[a-z0-9_]+)\s*\(", hdr))
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-2] in ("T", "t", "D", "B", "R", "W")}
+    atlas = {s for s in exported if s.startswith("atlas_")}
+    assert atlas == declared, (sorted(atlas - declared), sorted(declared - atlas))
+    assert not [s for s in exported if "tune" in s or "test" in s or "dbg" in s], exported
 
 
 def test_abi_version_and_bad_args(so):
@@ -51,11 +74,11 @@ def _plan(L, N, B, k=40, cus=256):
     return _lib.decode_plan(w)
 
 
-def test_pass_planner_without_a_device(so):
+def test_pass_planner_without_a_device(tune_so):
     """the passes a batch is made of (atlas_hip.hip::plan_batch, pure host arithmetic behind a test hook; ATLAS_ST_PLAN reports the same word from
     a real call): one streaming pass up to 64 / 96 queries, GEMM-shaped passes of 128 / 192 / 256 / 384 / 512 / 1024 queries above that -- from 65
     queries on shards of >= 4M rows --, the streaming passes of round 3 on shards below 65 536 rows, and never more slab reads than queries / 64"""
-    L = ctypes.CDLL(so)
+    L = ctypes.CDLL(tune_so)
     L.atlas_test_plan_word.restype = ctypes.c_int
     one = lambda **kw: dict({"passes_64": 0, "passes_96": 0, "pairs_64": 0, "pairs_96": 0, "gemm_passes": 0}, **kw)
     for N in (10_000, 1_000_000, 4_000_000, 32_000_000):
@@ -80,13 +103,13 @@ def test_pass_planner_without_a_device(so):
     assert L.atlas_test_plan_word(ctypes.c_int64(1000), 64, 300, 256) == -3 and L.atlas_test_plan_word(ctypes.c_int64(-1), 64, 40, 256) == -1
 
 
-def test_gemm_shaped_pass_geometry_without_a_device(so):
+def test_gemm_shaped_pass_geometry_without_a_device(tune_so):
     """make_gplan (launch geometry + workspace layout of one GEMM-shaped pass) over random shard sizes, pass sizes and CU counts: the column tiles
     hold the queries, the row ranges tile the slab in whole 256-row tiles below the 24-bit row field of a candidate entry, the sample's tiles lie
     inside the slab, the workspace regions are aligned, ordered and big enough"""
     import numpy as np
 
-    L = ctypes.CDLL(so)
+    L = ctypes.CDLL(tune_so)
     out = (ctypes.c_int64 * 17)()
     rng = np.random.default_rng(5)
     seen_ok = 0

@@ -141,18 +141,21 @@ def reference_index_cls(monkeypatch):
     sys.path.insert(0, os.path.join(HERE, "golden"))
     import make_golden
 
-    cls = make_golden.import_reference_index()
+    cls = make_golden.import_reference_index()           # (leaves sys.modules as it found it; the class keeps its modules alive)
+    global _REF_DIST_UTILS
+    _REF_DIST_UTILS = cls.__init__.__globals__["dist_utils"]      # the reference's own src/dist_utils.py, as src/index.py imported it
     monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
     yield cls
-    for name in [m for m in sys.modules if m == "src" or m.startswith("src.") or m.startswith("faiss")]:
-        del sys.modules[name]
+
+
+_REF_DIST_UTILS = None
 
 
 def _as_rank(monkeypatch, rank, world):
     """both classes ask their dist_utils for the rank / world size: pose as rank `rank` of `world`"""
     import atlas_amd.dist_utils as mine
 
-    ref = sys.modules["src.dist_utils"]
+    ref = _REF_DIST_UTILS
     for m in (mine, ref):
         monkeypatch.setattr(m, "get_rank", lambda r=rank: r)
         monkeypatch.setattr(m, "get_world_size", lambda w=world: w)

@@ -59,6 +59,19 @@ def _loss(emb, seed):
     return (emb * w).sum()
 
 
+def _reference_set_dropout():
+    """src/util.py:161-164, imported from the reference checkout; sys.modules / sys.path are left as they were found (tests/conftest.py checks)"""
+    before = set(sys.modules)
+    sys.path.insert(0, REF)
+    try:
+        from src.util import set_dropout
+    finally:
+        sys.path.remove(REF)
+        for name in [m for m in sys.modules if m not in before and (m == "src" or m.startswith("src."))]:
+            del sys.modules[name]
+    return set_dropout
+
+
 @pytest.fixture(scope="module")
 def ref_mod():
     if not os.path.exists(os.path.join(REF, "src", "retrievers.py")):
@@ -87,8 +100,7 @@ def test_train_mode_forward_and_gradients_equal_the_reference_module_bit_for_bit
     mine = R.Contriever(_cfg(layers), pooling=pooling)
     mine.load_state_dict(theirs.state_dict(), strict=True)
     mine = mine.to(dtype).train()
-    sys.path.insert(0, REF)
-    from src.util import set_dropout                         # the reference's own helper has to find our dropout modules
+    set_dropout = _reference_set_dropout()                   # the reference's own helper has to find our dropout modules
 
     set_dropout(theirs, 0.15)
     set_dropout(mine, 0.15)
