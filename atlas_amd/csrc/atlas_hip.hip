@@ -806,8 +806,12 @@ static BatchPlan plan_batch(const int64_t N, const int B, const int d, const int
             r -= m;
         }
     }
-    for (const Pass& ps : passes)
-        bp.plan_word += ps.gemm ? (1 << 24) : ps.nq2 > 0 ? (ps.wide ? (1 << 20) : (1 << 16)) : (ps.wide ? (1 << 8) : 1);
+    // ATLAS_ST_PLAN: five counters in one word, each SATURATING at its field's width (8 | 8 | 4 | 4 | 8 bits): a very large batch on a shard the
+    // GEMM-shaped pass does not take must not carry into the next field
+    int cnt[5] = {0, 0, 0, 0, 0};       // 64-query passes | 96-query passes | pairs of 64 | pairs of 96 | GEMM-shaped passes
+    for (const Pass& ps : passes) ++cnt[ps.gemm ? 4 : ps.nq2 > 0 ? (ps.wide ? 3 : 2) : (ps.wide ? 1 : 0)];
+    const int sat[5] = {255, 255, 15, 15, 255}, shift[5] = {0, 8, 16, 20, 24};
+    for (int i = 0; i < 5; ++i) bp.plan_word |= (cnt[i] < sat[i] ? cnt[i] : sat[i]) << shift[i];
     bp.single = pl; bp.pair = pp; bp.wide_ok = wide_ok;
     return bp;
 }
@@ -895,9 +899,17 @@ size_t atlas_scan_topk_workspace_bytes(int64_t N, int B, int d, int k) {
             mx = t2 > mx ? t2 : mx;
         }
     }
-    if (B > QCHUNK) {                  // GEMM-shaped passes (gscan_kernel.h)
-        const GPlan g = make_gplan(N, B < GS_MAXQ ? B : GS_MAXQ, device_cus());
-        if (g.ok && g.total > mx) mx = g.total;
+    if (B > QCHUNK && d == D_FAST && k <= K_FAST_MAX) {
+        // GEMM-shaped passes (gscan_kernel.h): sized from the passes plan_batch really makes of this batch with room for all of them (the
+        // widest pass it chose) -- not from "B > 64": 65..96 queries on a shard below GS_SMALL_BATCH_MIN_ROWS rows never take one, and the
+        // 1024-wide layout (~128 MiB of sample maxima + 256 MiB of lists, zero-filled by the caller) is only paid by batches that use it
+        const BatchPlan bp = plan_batch(N, B, d, k, device_cus(), (size_t)-1, kTrusted);
+        if (bp.rc == 0)
+            for (const Pass& ps : bp.passes)
+                if (ps.gemm) {
+                    const GPlan g = make_gplan(N, ps.nq, device_cus());
+                    if (g.ok && g.total > mx) mx = g.total;
+                }
     }
     return mx;
 }

@@ -76,6 +76,47 @@ def merge_packed_host(gathered: np.ndarray, k: int) -> np.ndarray:
     return -np.sort(-flat, axis=1, kind="stable")[:, :k]
 
 
+class _DocMap(dict):
+    """the doc_map this class builds (init_embeddings / load_index): a plain dict for every caller, plus a counter of in-place changes so that
+    `index.doc_map[i] = passage` is seen by the id -> passage mirror of `_docs_of_rows` (the reference re-reads doc_map[x] on every search)"""
+    __slots__ = ("edits",)
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.edits = 0
+
+    def __setitem__(self, key, value):
+        self.edits += 1
+        dict.__setitem__(self, key, value)
+
+    def __delitem__(self, key):
+        self.edits += 1
+        dict.__delitem__(self, key)
+
+    def update(self, *a, **kw):
+        self.edits += 1
+        dict.update(self, *a, **kw)
+
+    def pop(self, *a):
+        self.edits += 1
+        return dict.pop(self, *a)
+
+    def popitem(self):
+        self.edits += 1
+        return dict.popitem(self)
+
+    def clear(self):
+        self.edits += 1
+        dict.clear(self)
+
+    def setdefault(self, *a):
+        self.edits += 1
+        return dict.setdefault(self, *a)
+
+    def __reduce__(self):                       # pickles (and deep-copies) as a plain dict's content
+        return (_DocMap, (dict(self),))
+
+
 class HipDistributedIndex(object):
     def __init__(self, certify_every: int = 64, exchange: str = "rccl"):
         """exchange: how the ranks' packed winners meet in a distributed search_knn: "rccl" = one all_gather_into_tensor + the W*k -> k
@@ -99,6 +140,7 @@ class HipDistributedIndex(object):
         self._ws_bytes_cache = {}
         self._host_out = None                # pinned D2H buffer of the search results (reused)
         self._doc_arr, self._doc_arr_tag = None, None     # doc_map mirrored as a numpy object array (see _docs_of_rows)
+        self._min_shard_rows = None          # the smallest shard of the job (collective, taken at the first search after the slab was (re)bound)
         self._ws_exact = None
         self._last_packed = None
         self._gid_mode = "round_robin"  # how local rows map to global passage ids
@@ -131,10 +173,12 @@ class HipDistributedIndex(object):
         self.embeddings = slab.T
         self._pmax = None
         self._pmax_version = None
+        self._min_shard_rows = None
+        self._doc_arr, self._doc_arr_tag = None, None     # (a new slab comes with a new doc_map: never serve the old mirror -- ADVICE r04)
 
     def init_embeddings(self, passages, dim: Optional[int] = EMBEDDINGS_DIM):
         """index.py:48-53 — allocate a zeroed slab for `passages` and the local doc map."""
-        self.doc_map = {i: doc for i, doc in enumerate(passages)}
+        self.doc_map = _DocMap(enumerate(passages))
         self._set_slab(torch.zeros((len(passages), dim), dtype=torch.float16, device=self._device()))
         self._gid_mode = "round_robin"   # src/index_io.py:41: global line c -> rank c % W, slot c // W
 
@@ -213,7 +257,7 @@ class HipDistributedIndex(object):
             row += len(chunk)
         if slab is None:
             slab = torch.empty((0, dim), dtype=torch.float16, device=dev)
-        self.doc_map = dict(enumerate(p for chunk in chunks for p in chunk))
+        self.doc_map = _DocMap(enumerate(p for chunk in chunks for p in chunk))
         self._set_slab(slab)
         # saved shards are contiguous runs of passages: global id = offset of this rank + row
         self._gid_mode = "contiguous"
@@ -300,7 +344,10 @@ class HipDistributedIndex(object):
 
     def _local_topk(self, q: torch.Tensor, k: int, pack=None):
         """Fused scan + top-k over this shard. Returns device (scores fp16 [B,k], rows int64 [B,k])
-        and their host copies (numpy), after the status word has been checked.
+        and their host copies (numpy), after the status word has been checked. The host copies are VIEWS OF A REUSED PINNED BUFFER,
+        valid until the next `_local_topk` of this index (every caller in this file converts them to lists / packs them at once);
+        a caller that keeps them across searches copies them (tests/test_index_host.py::test_host_results_do_not_alias_across_searches
+        pins what search_knn hands out).
         pack = (id_mul, id_add): the merge kernel also emits the winners as cross-shard packed candidates (one launch less in front of
         the all-gather); they are left in `self._last_packed` ((B, k) int64, device), or None when a query took another path.
 
@@ -445,10 +492,18 @@ class HipDistributedIndex(object):
         Collective: every rank calls it the same number of times with the same topk.
         """
         self._check_slab()
+        # `topk > rows of a shard` is the reference's torch.topk error (index.py:118) -- raised there, and here until round 4, by whichever
+        # ranks own a short shard AFTER the query collective, while the others went on into the next collective and hung (shards that differ
+        # by one row are the normal case: N % W != 0). The smallest shard of the job is taken once per slab (one all_gather_object at the
+        # first search after init_embeddings / load_index, both of which re-bind the slab) and every rank raises, or none, BEFORE any
+        # collective of the search.
+        if self._min_shard_rows is None:
+            self._min_shard_rows = min(int(n) for n in dist_utils.all_gather_object(int(self._slab.shape[0])))
+        if topk > self._min_shard_rows:
+            raise RuntimeError(f"selected index k out of range (topk={topk} > {self._min_shard_rows} passages in the smallest shard; "
+                               f"this rank's shard holds {self._slab.shape[0]})")
         allqueries, allsizes = dist_utils.all_gather_queries(queries)
         bounds = np.cumsum([0] + list(allsizes))
-        if topk > self._slab.shape[0]:
-            raise RuntimeError(f"selected index k out of range (topk={topk} > {self._slab.shape[0]} passages in shard)")
         distributed = dist_utils.is_initialized()
         scores_d, rows_d, scores, rows = self._local_topk(allqueries, topk, pack=self._gid_params() if distributed else None)
         if not distributed:
@@ -490,13 +545,17 @@ class HipDistributedIndex(object):
     def _docs_of_rows(self, rows: np.ndarray):
         """[b][k] shard-local rows -> the passages (the SAME dict objects `doc_map[row]` returns, src/index.py:131). A dict doc_map with
         the dense keys 0..n-1 the reference builds (index.py:47, :106) is mirrored ONCE per (dict identity, length) into a numpy object
-        array: 2 560 lookups become one fancy-indexing take + tolist() in C (~25 us instead of ~250 us per batch of 64 x 40). A caller that
-        swaps single entries of the same dict in place calls `index.invalidate_doc_cache()`; anything that is not such a dict is looked
-        up entry by entry."""
+        array: 2 560 lookups become one fancy-indexing take + tolist() in C (~25 us instead of ~250 us per batch of 64 x 40). In-place
+        edits of a doc_map this class built (`index.doc_map[i] = p`) are seen through `_DocMap.edits`; a caller that assigned its OWN plain
+        dict and swaps entries of it in place (same length) calls `index.invalidate_doc_cache()`; anything that is not a dict is looked up
+        entry by entry."""
         dm = self.doc_map
-        if type(dm) is dict and len(dm) > 0:
-            tag = (id(dm), len(dm))
-            if self._doc_arr_tag != tag:
+        if isinstance(dm, dict) and len(dm) > 0:
+            # the tag holds the mirrored dict ITSELF (compared with `is`: a freed dict's id() may be reused), its length and -- for the
+            # dicts this class builds -- its edit counter
+            tag = self._doc_arr_tag
+            edits = getattr(dm, "edits", 0)
+            if tag is None or tag[0] is not dm or tag[1] != len(dm) or tag[2] != edits:
                 arr = None
                 n = len(dm)
                 if 0 in dm and (n - 1) in dm:
@@ -505,7 +564,7 @@ class HipDistributedIndex(object):
                         arr[:] = [dm[i] for i in range(n)]          # KeyError: the keys are not 0..n-1
                     except KeyError:
                         arr = None
-                self._doc_arr, self._doc_arr_tag = arr, tag
+                self._doc_arr, self._doc_arr_tag = arr, (dm, n, edits)
             if self._doc_arr is not None:
                 return self._doc_arr[rows].tolist()
         return [[dm[x] for x in sample] for sample in rows.tolist()]     # (tolist() converts in C: half the host time of per-element int())

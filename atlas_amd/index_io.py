@@ -76,6 +76,29 @@ def _corpus_signature(opt) -> str:
     return h.hexdigest()
 
 
+def _passage_store_path(opt, restored: bool):
+    """where the node-local passage store of this run lives, or None for the winners-only exchange. Collective when a process group exists
+    (one all_gather_object of the host names, at index construction)."""
+    import socket
+    import tempfile
+
+    explicit = getattr(opt, "passage_store_path", None)
+    if os.environ.get("ATLAS_PASSAGE_STORE", "").lower() in ("off", "0", "none"):
+        explicit = "off"
+    if explicit is not None:
+        return None if str(explicit).lower() in ("off", "none", "") else explicit
+    if dist_utils.get_world_size() < 2:
+        return None                                   # one process: doc_map resolves everything, nothing to exchange
+    if not restored and getattr(opt, "use_file_passages", False):
+        return None
+    hosts = dist_utils.all_gather_object(socket.gethostname())
+    if len(set(hosts)) != 1:
+        logger.info("ranks on %d hosts: no automatic passage store (set opt.passage_store_path to a node-local path to get one)", len(set(hosts)))
+        return None
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    return os.path.join(base, "atlas_amd_passages_" + _corpus_signature(opt)[:16])
+
+
 def load_or_initialize_index(opt):
     """src/index_io.py:72-93 with the flat index replaced by the HIP one: returns (index, this rank's passages)."""
     try:
@@ -95,9 +118,12 @@ def load_or_initialize_index(opt):
         passages = load_passages(opt.passages, opt.max_passages)
         index.init_embeddings(passages)
 
-    # optional, not a reference option: `opt.passage_store_path` = where the node-local passage store lives (e.g. under
-    # /dev/shm). With it search_knn resolves the winners' text locally instead of exchanging it.
-    store_path = getattr(opt, "passage_store_path", None)
+    # The node-local passage store: with it search_knn resolves the winners' text locally and is TWO collectives (queries,
+    # packed winners) instead of four. Not a reference option, so the default has to be right without one: when a process group of more
+    # than one rank runs on ONE host (the target: 8 x MI355X in one node) the store is built -- once, by the node's first rank -- and attached
+    # automatically under /dev/shm. `opt.passage_store_path` = an explicit location (multi-node jobs: a node-local path), or "off" to keep
+    # the winners-only text exchange (also: ATLAS_PASSAGE_STORE=off).
+    store_path = _passage_store_path(opt, restored)
     if store_path and (restored or not opt.use_file_passages):
         if restored:
             def make():

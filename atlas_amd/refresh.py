@@ -14,6 +14,7 @@ embeddings into `index.embeddings[:, a:b]`, one batch after the other, on every 
 `build_index_streamed` has the signature of `Atlas.build_index` and can be bound in its place.
 """
 import copy
+import time
 from typing import Iterable, Optional, Tuple
 
 import torch
@@ -62,12 +63,17 @@ class IndexRefresher:
         self._free = [torch.cuda.Event() for _ in range(depth)]       # encoder finished reading the slot
         self._used = [False] * depth
         self._turn = 0
+        # host-side seconds of the refreshes run so far: filling the pinned staging buffers from the token store, and blocked on a staging
+        # slot the encoder still reads (= the device is the bottleneck); bench.py's full-shard leg reports their share
+        self.host_seconds = {"fill": 0.0, "slot_wait": 0.0, "launch": 0.0}
 
     def _slot(self) -> int:
         s = self._turn % self.depth
         self._turn += 1
         if self._used[s]:
+            t = time.perf_counter()
             self._free[s].synchronize()                                # only when `depth` batches are already in flight
+            self.host_seconds["slot_wait"] += time.perf_counter() - t
         return s
 
     def _launch(self, s: int, n: int, L: int, rows: Optional[bool], row_offset: int = 0) -> None:
@@ -128,24 +134,27 @@ class IndexRefresher:
             for rows in plan:
                 s = self._slot()
                 pi, pm, pr = self._pin[s]
+                t0 = time.perf_counter()
                 L = store.fill(rows, pi, pm)
                 pr[: rows.shape[0]].copy_(torch.from_numpy(rows))
+                t1 = time.perf_counter()
                 self._launch(s, int(rows.shape[0]), L, rows=True)
+                self.host_seconds["fill"] += t1 - t0
+                self.host_seconds["launch"] += time.perf_counter() - t1
         self.index._pmax = None
         return len(store) * repeat
 
 
 def _passages_fingerprint(passages) -> int:
-    """a content fingerprint of a passage list: EVERY passage's id and text length (one cheap pass) plus ids, titles and texts of a few spread
-    entries (first, last, and up to 62 between). A HEURISTIC all the same: an in-place edit that keeps a passage's id and the length of its
-    text goes unnoticed unless it hits a sampled entry -- a caller that edits passages in place calls `invalidate_refresh_state(index)`."""
+    """a content fingerprint of a passage list from ~64 spread entries (first, last, and up to 62 between: id, title and text of each) -- O(1)
+    per refresh whatever the shard size (round 4 also hashed every passage's id and text length: seconds of python per refresh on a
+    multi-million-passage shard, and still blind to same-length edits -- ADVICE r04). A HEURISTIC: a caller that edits passages in place
+    calls `invalidate_refresh_state(index)`; a NEW list object (what `index_io.load_passages` returns) is always re-tokenised."""
     n = len(passages)
     if n == 0:
         return 0
     picks = sorted({0, n - 1, *range(0, n, max(1, n // 62))})
-    sample = tuple((passages[i].get("id"), passages[i].get("title"), passages[i].get("text")) for i in picks)
-    every = hash(tuple((p.get("id"), len(p.get("text") or "")) for p in passages))
-    return hash((sample, every))
+    return hash(tuple((passages[i].get("id"), passages[i].get("title"), passages[i].get("text")) for i in picks))
 
 
 def invalidate_refresh_state(index) -> None:
@@ -163,9 +172,10 @@ def build_index_streamed(self, index, passages, gpu_embedder_batch_size, logger=
     state = index.__dict__.setdefault("_refresh_state", {})
     # the token store is reused while `passages` is the same list with the same content at its ends and in its middle (a list edited
     # in place keeps its id and, often, its length: the fingerprint is what notices)
-    key = (id(passages), len(passages), _passages_fingerprint(passages))
-    if state.get("passages_key") != key:
+    key = (len(passages), _passages_fingerprint(passages))
+    if state.get("passages_ref") is not passages or state.get("passages_key") != key:      # (`is` on a held reference: a freed list's id() may be reused)
         state.clear()
+        state["passages_ref"] = passages
         state["store"] = TokenStore.from_passages(passages, self.retriever_tokenizer, self.opt.retriever_format, self.opt.text_maxlength,
                                                   gpu_embedder_batch_size)
         state["passages_key"] = key

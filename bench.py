@@ -112,6 +112,14 @@ def main():
     ap.add_argument("--exchange", choices=("rccl", "peer"), default="rccl",
                     help="N > 1: how the ranks' packed winners meet -- one RCCL all-gather + merge (default), or the peer-mapped exchange buffers "
                          "(atlas_xchg_*: push kernel + waiting merge kernel, no collective; experimental, never run across two devices)")
+    ap.add_argument("--emulate-ranks", type=str, default="2,4,8",
+                    help="N=1 only: the per-GPU step of a W-GPU run of the same corpus on ONE GPU -- scan of a 1/W contiguous shard with packed winners "
+                         "+ the device W x k -> k merge of all W shards' winners (scanned once, outside the timed region); labelled 'emulated, no RCCL' "
+                         "(SURVEY §8d): the ceiling the driver's real 1/2/4/8 curve is compared with ('' = skip)")
+    ap.add_argument("--refresh-full-shard", type=int, default=0,
+                    help="opt-in (about 2 min of GPU at 4000000): ONE streamed refresh of that many ragged passages (64..200 tokens) from a pinned TokenStore "
+                         "into the first rows of the slab = the per-GPU share of BASELINE configs[3]; reports passages/s, host-side shares, pinned bytes, "
+                         "power, and checks 4096 sampled rows against the position loop and one 64-query search against the exact path")
     ap.add_argument("--oracle-query", type=int, default=31, help="query of the batch held to the CPU oracle at full size in the cpu_baseline leg (-1 = skip)")
     args = ap.parse_args()
 
@@ -488,6 +496,62 @@ def main():
                 batch_sweep[str(Bb)]["certifying_ms_per_step"] = cert_ms
         del subb
 
+    # ---- the 1 / 2 / 4 / 8-GPU curve, EMULATED on one GPU ("emulated, no RCCL"; the driver's SCALE run is the real one). A rank of a
+    # W-GPU search scans rows / W rows and emits its packed (score, global id) winners; after the all-gather every rank merges W x k -> k.
+    # Here: the W contiguous shards of the slab are scanned once (outside the timed region) to get all W packed outputs -- their device merge
+    # must equal the one-GPU result (sharding invariance at the benchmark size) --, then K steps of [scan of shard 0 with packed output ->
+    # atlas_merge_packed over the W outputs] are timed like the headline. What is NOT in it: the all-gather itself (20 KiB per rank).
+    scale_emulated = None
+    if world == 1 and args.emulate_ranks:
+        from atlas_amd.index import pack_candidates_host
+        scale_emulated = {"label": "emulated, no RCCL", "how": "one GPU: scan of a contiguous 1/W shard with packed winners + device W x k -> k merge of the W "
+                          "shards' winners; the all-gather of 8*B*k bytes per rank is not included", "per_w": {
+                              "1": {"rows_per_gpu": rows, "ms_per_step": dt / args.steps * 1e3, "queries_per_s": B * args.steps / dt,
+                                    "step_frac": rows * D * 2 / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, "source": "the headline itself"}}}
+        want_packed = pack_candidates_host(s0.cpu().numpy(), i0.cpu().numpy(), 1, 0)              # the one-GPU result as packed candidates
+        for W_e in (int(x) for x in args.emulate_ranks.split(",")):
+            if W_e < 2 or rows // W_e < 100_000:
+                continue
+            bounds_e = [rows * r // W_e for r in range(W_e + 1)]
+            gathered_e = torch.empty((W_e * B, k), dtype=torch.int64, device=dev)
+            merged_e = torch.empty((B, k), dtype=torch.int64, device=dev)
+            for r in range(W_e):                                                                   # every shard once: its packed winners
+                n_r = bounds_e[r + 1] - bounds_e[r]
+                ws_e = torch.zeros(int(L.atlas_scan_topk_workspace_bytes(n_r, B, D, k)), dtype=torch.uint8, device=dev)    # (fresh: its head holds plan state)
+                rc = L.atlas_scan_topk_pack(q.data_ptr(), q_code, slab[bounds_e[r]:].data_ptr(), n_r, B, D, k, pmax, out_s.data_ptr(), out_i.data_ptr(),
+                                            out_st.data_ptr(), ws_e.data_ptr(), ws_e.numel(), stream, None, None, _lib.SCAN_TRUST_PMAX, 1, bounds_e[r],
+                                            gathered_e[r * B:(r + 1) * B].data_ptr())
+                assert rc == 0, rc
+                torch.cuda.synchronize()
+                assert int(out_st.cpu()[_lib.ST_FLAGS]) == 0
+            n_0 = bounds_e[1]
+            ws_0 = torch.zeros(int(L.atlas_scan_topk_workspace_bytes(n_0, B, D, k)), dtype=torch.uint8, device=dev)
+            packed_e = torch.empty((B, k), dtype=torch.int64, device=dev)
+
+            def e_step():
+                rc = L.atlas_scan_topk_pack(q.data_ptr(), q_code, slab.data_ptr(), n_0, B, D, k, pmax, out_s.data_ptr(), out_i.data_ptr(), out_st.data_ptr(),
+                                            ws_0.data_ptr(), ws_0.numel(), stream, None, None, _lib.SCAN_TRUST_PMAX, 1, 0, packed_e.data_ptr())
+                assert rc == 0, rc
+                rc = L.atlas_merge_packed(gathered_e.data_ptr(), W_e, B, k, merged_e.data_ptr(), stream)
+                assert rc == 0, rc
+
+            for _ in range(max(args.warmup, 5)):
+                e_step()
+            fence()
+            steps_e = max(args.steps, 50)
+            te = time.perf_counter()
+            for _ in range(steps_e):
+                e_step()
+            fence()
+            dte = (time.perf_counter() - te) / steps_e
+            assert torch.equal(packed_e, gathered_e[:B]), "timed shard-0 scan disagrees with its one-off run"
+            assert np.array_equal(merged_e.cpu().numpy(), want_packed), f"W={W_e}: merged shard winners differ from the one-GPU result"
+            scale_emulated["per_w"][str(W_e)] = {"rows_per_gpu": n_0, "ms_per_step": dte * 1e3, "queries_per_s": B / dte,
+                                                 "step_frac": n_0 * D * 2 / dte / 1e9 / HBM_PEAK_GBS, "steps": steps_e,
+                                                 "speedup_vs_1": (dt / args.steps) / dte, "efficiency_vs_1": (dt / args.steps) / dte / W_e,
+                                                 "merged_equals_one_gpu_result": True}
+            del ws_e, ws_0, gathered_e
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from oracle import oracle as oracle_checker, ref_port   # checker / baseline only; never on the product path
@@ -518,7 +582,14 @@ def main():
         from atlas_amd import retrievers
 
         torch.manual_seed(99)
-        enc = retrievers.Contriever(retrievers.BertConfigLite()).half().eval().to(dev).requires_grad_(False)
+        # ATLAS_CONTRIEVER_DIR = a local HF-layout directory (config.json + model.safetensors | pytorch_model.bin, e.g. facebook/contriever):
+        # the refresh legs then run on the real checkpoint; offline boxes have none, and the legs say which weights they used
+        ckpt_dir = os.environ.get("ATLAS_CONTRIEVER_DIR")
+        if ckpt_dir:
+            enc = retrievers.Contriever.from_pretrained(ckpt_dir).half().eval().to(dev).requires_grad_(False)
+            assert enc.config.num_hidden_layers == 12 and enc.config.hidden_size == 768, "the FLOP model of the refresh roofline is BERT-base's"
+        else:
+            enc = retrievers.Contriever(retrievers.BertConfigLite()).half().eval().to(dev).requires_grad_(False)
         Lr, nb = args.refresh_len, 512
         g = torch.Generator(device=dev).manual_seed(4321 + rank)
         ids = torch.randint(1000, 30522, (nb, Lr), generator=g, device=dev)
@@ -538,7 +609,7 @@ def main():
         flops_pp = 169.9e6 * Lr + 36864.0 * Lr * Lr
         refresh = {"metric": "index-refresh passages/sec (Contriever-base re-embed, fp16)", "value": pps, "unit": "passages/s",
                    "passage_len": Lr, "batch": nb, "batches": args.refresh_batches, "ms_per_batch": dtr / args.refresh_batches * 1e3,
-                   "data": "synthetic token ids, random-init BERT-base weights",
+                   "data": "synthetic token ids, " + (f"weights of the checkpoint {ckpt_dir}" if ckpt_dir else "random-init BERT-base weights"),
                    "roofline": {"bound": "mfma", "achieved": pps * flops_pp / world / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                                 "frac": pps * flops_pp / world / 1e12 / 2500.0, "flops_per_passage": flops_pp}}
         # SURVEY §8d variant (b): ragged passages, lengths uniform in 64..200 padded to the longest of the batch
@@ -612,6 +683,67 @@ def main():
                                    "vs_device_resident_ragged": (world * n_s * reps / dts) / refresh["ragged"]["value"],
                                    "power": power}
             del rf, sub, store
+        # ---- BASELINE configs[3]'s per-GPU share, for real (opt-in): ONE streamed refresh of --refresh-full-shard ragged passages from a pinned
+        # token store into the first rows of the slab (VERDICT r04 missing #2: the rate used to be an extrapolation from 16 384 passages)
+        if args.refresh_full_shard > 0:
+            from atlas_amd import refresh as refresh_mod
+            from atlas_amd.token_store import TokenStore
+
+            n_f = min(int(args.refresh_full_shard), rows)
+            t_b = time.perf_counter()
+            rs = np.random.default_rng(777 + rank)
+            lens_f = rs.integers(64, 201, size=n_f)
+            off_f = np.zeros(n_f + 1, dtype=np.int64)
+            np.cumsum(lens_f, out=off_f[1:])
+            toks = rs.integers(1000, 30522, size=int(off_f[-1]), dtype=np.int32)
+            store_f = TokenStore(torch.from_numpy(toks), off_f, 200)
+            t_build = time.perf_counter() - t_b
+            sub_f = HipDistributedIndex()
+            sub_f._set_slab(slab[:n_f])
+            rf_f = refresh_mod.IndexRefresher(sub_f, enc, max_batch=nb, max_len=200, depth=3)
+            pinned = store_f.tokens.numel() * 4 + sum(t.numel() * 8 for slot in rf_f._pin for t in slot)
+            plan_f = store_f.plan(nb, True, refresh_mod.TOKEN_BUDGET)
+            fence()
+            smi = _SmiSampler() if rank == 0 else None
+            if smi:
+                smi.start()
+            t_f = time.perf_counter()
+            rf_f.run_store(store_f, nb)
+            fence()
+            dt_f = time.perf_counter() - t_f
+            power_f = smi.finish() if smi else None
+            if world > 1:
+                dt_f = reduce_max(dt_f)
+            host_f = dict(rf_f.host_seconds)
+            lff = lens_f.astype(np.float64)
+            flops_f = float((169.9e6 * lff + 36864.0 * lff * lff).sum())
+            # 4 096 sampled rows against the POSITION loop (atlas.py:61-88's order: 512 consecutive passages per batch, padded to the longest)
+            ids_p = torch.empty((nb, 200), dtype=torch.int64).pin_memory()
+            msk_p = torch.empty((nb, 200), dtype=torch.int64).pin_memory()
+            scratch = torch.empty((nb, D), dtype=torch.float16, device=dev)
+            n_checked = 0
+            for a in np.linspace(0, n_f - nb, 8).astype(np.int64):
+                rows_p = np.arange(a, a + nb, dtype=np.int64)
+                Lp_ = store_f.fill(rows_p, ids_p, msk_p)
+                enc.embed_into(scratch, ids_p.view(-1)[: nb * Lp_].view(nb, Lp_).to(dev), msk_p.view(-1)[: nb * Lp_].view(nb, Lp_).to(dev))
+                torch.cuda.synchronize()
+                assert torch.equal(scratch, slab[a: a + nb]), f"streamed full-shard refresh: rows {a}..{a + nb} differ from the position loop"
+                n_checked += nb
+            # one 64-query search on the refreshed rows against the MFMA-free exact path (8 queries)
+            qf = torch.randn((64, D), generator=torch.Generator(device=dev).manual_seed(4242), device=dev)
+            sf, if_ = sub_f._compute_scores_and_indices(qf, k)
+            sel_f = torch.tensor([0, 9, 18, 27, 36, 45, 54, 63], device=dev)
+            esf, eif = sub_f._exact_topk(qf[sel_f], k)
+            assert torch.equal(sf[sel_f], esf) and torch.equal(if_[sel_f], eif), "search on the refreshed shard disagrees with the exact path"
+            refresh["full_shard"] = {"passages": n_f, "value": world * n_f / dt_f, "unit": "passages/s", "seconds": dt_f, "batches": len(plan_f),
+                                     "lengths": "uniform 64..200, length-bucketed batches of %d tokens" % refresh_mod.TOKEN_BUDGET,
+                                     "real_token_tflops": flops_f / dt_f / 1e12, "frac_of_mfma_peak": flops_f / dt_f / 1e12 / MFMA_PEAK_TFLOPS,
+                                     "vs_streamed_16k": ((world * n_f / dt_f) / refresh["streamed"]["value"]) if "streamed" in refresh else None,
+                                     "host_seconds": host_f, "host_fill_share": host_f["fill"] / dt_f, "host_slot_wait_share": host_f["slot_wait"] / dt_f,
+                                     "token_store_build_seconds": t_build, "pinned_bytes": int(pinned), "tokens": int(off_f[-1]), "power": power_f,
+                                     "rows_checked_against_position_loop": n_checked,
+                                     "search_after_refresh": {"queries_exact": 8, "fallback_queries": int(sub_f.last_search_stats.get("fallback_queries", 0))}}
+            del rf_f, sub_f, store_f
 
     if rank == 0:
         algo_bytes = rows * D * 2
@@ -631,6 +763,9 @@ def main():
         except Exception:
             traffic = None
         achieved = algo_bytes / (scan_ms * 1e-3) / 1e9
+        plan0 = stats0.get("plan") or {}
+        single_gemm = plan0.get("gemm_passes") == 1 and sum(plan0.values()) == 1
+        gemm_ms = scan_ms if single_gemm else dt / args.steps * 1e3
         line = {
             "metric": "queries/sec, exact MIPS d=768 top-40 (index search hot path)",
             "value": B * args.steps / dt,
@@ -656,19 +791,25 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch (PMC FETCH_SIZE, calibrated; from the committed pass of these sources, profiles/pmc_traffic.json)",
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_mean": scan_ms, "kernel_ms_min": scan_ms_min,
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
-                "certifying": certifying,
+                "certifying": certifying, "certifying_frac": certifying["frac"] if certifying else None,
             } if not (stats0.get("plan") or {}).get("gemm_passes") else {
                 # more than 96 queries per step (--distinct-queries at N > 1, or --queries): the GEMM-shaped pass, bounded by the matrix pipe
-                "kernel": "gscan_kernel<0> (two launches + the threshold update between them: the hipEvents bracket all three)", "bound": "mfma",
-                "achieved": 2.0 * B * rows * D / (scan_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": 2.0 * B * rows * D / (scan_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
-                "algorithmic_flops_per_launch": 2.0 * B * rows * D, "kernel_ms_mean": scan_ms, "kernel_ms_min": scan_ms_min,
-                "hbm_frac_of_one_slab_read": achieved / HBM_PEAK_GBS, "certifying": certifying,
+                # (the hipEvents bracket the FIRST pass of the plan only -- atlas_scan_topk_pack records them at q0 == 0 --, so the kernel-level
+                #  figure is quoted only when the plan IS one GEMM-shaped pass; a batch the planner splits (576 -> 512 + 64, > 1024 queries) is
+                #  priced on the whole step instead: ADVICE r04)
+                "kernel": "gscan_kernel<0> (the launches of one GEMM-shaped pass: the hipEvents bracket them)" if single_gemm else
+                          "whole step (the plan has several passes: %s)" % json.dumps(stats0.get("plan")), "bound": "mfma",
+                "achieved": 2.0 * B * rows * D / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": 2.0 * B * rows * D / (gemm_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
+                "algorithmic_flops_per_launch": 2.0 * B * rows * D, "kernel_ms_mean": gemm_ms, "kernel_ms_min": scan_ms_min if single_gemm else None,
+                "timed": "hipEvents around the pass" if single_gemm else "ms_per_step",
+                "hbm_frac_of_one_slab_read": algo_bytes / (gemm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "certifying": certifying,
             }),
             "cpu_baseline": cpu,
             "refresh": refresh,
             "shard_sweep": shard_sweep,
             "batch_sweep": batch_sweep,
+            "scale_emulated": scale_emulated,
             "detail": {
                 "parity_checked": parity_checked,
                 "sync_call_latency_ms": lat_ms, "search_knn_ms_per_batch": knn_ms, "search_knn_error": knn_err,

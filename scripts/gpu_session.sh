@@ -15,6 +15,8 @@
 #   host           tools/host_overhead.py 1M 4M
 #   refatlas       tests/test_gpu_reference_atlas.py (needs .refstage/: scripts/stage_reference.sh in the build container)
 #   gloo2          two ranks on one GPU over gloo: bench.py --gpus 2 logic check, replicated and --distinct-queries
+#   fullshard      BASELINE configs[3]'s per-GPU share: bench.py --refresh-full-shard 4000000 (one streamed refresh of 4M ragged passages, ~2 min), the
+#                  other legs cut short
 TAG=$1; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -83,6 +85,17 @@ gloo2)
     ATLAS_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --passages 2000003 --refresh-batches 0 --cpu-seconds 0 $extra > $OUT/bench_w2_gloo$extra.json 2> $OUT/bench_w2_gloo$extra.err; say "gloo2 $extra rc=$?"
     grep "^{" $OUT/bench_w2_gloo$extra.json | cut -c1-900 | tee -a $OUT/summary.log
   done ;;
+fullshard)
+  timeout 1500 python bench.py --passages 8000000 --steps 5 --warmup 2 --cpu-seconds 0 --shard-sweep '' --batch-sweep '' --emulate-ranks '' --refresh-batches 10 --refresh-stream-seconds 5 --refresh-full-shard 4000000 > $OUT/bench_refresh_full_shard.json 2> $OUT/bench_refresh_full_shard.err; say "fullshard rc=$?"
+  python - <<PY | tee -a $OUT/summary.log
+import json
+try:
+    d = json.loads(open("$OUT/bench_refresh_full_shard.json").read().strip().splitlines()[-1])["refresh"]
+    print("refresh: batch %.2f ms frac %.3f | ragged %.0f | streamed %.0f | full_shard %s" % (d["ms_per_batch"], d["roofline"]["frac"], d["ragged"]["value"], d["streamed"]["value"], json.dumps(d.get("full_shard"))))
+except Exception as e:
+    print("fullshard: no line", e); print(open("$OUT/bench_refresh_full_shard.err").read()[-1500:])
+PY
+  ;;
 *) say "unknown step $STEP" ;;
 esac
 done

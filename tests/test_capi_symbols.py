@@ -99,6 +99,12 @@ def test_pass_planner_without_a_device(tune_so):
     assert p["gemm_passes"] == 0 and sum(p.values()) >= 3, p
     # a smaller device (a partition of 64 CUs): plans exist, nothing asks for more workgroups than CUs
     assert sum(_plan(L, 4_000_000, 512, cus=64).values()) >= 1
+    # the counters of the plan word saturate at their field widths instead of carrying into the next field (a huge batch on a shard
+    # the GEMM-shaped pass does not take: thousands of streaming passes)
+    for B in (64 * 300, 96 * 700 + 5):
+        p = _plan(L, 60_000, B)
+        assert p["gemm_passes"] == 0 and p["passes_64"] <= 255 and p["passes_96"] <= 255 and p["pairs_64"] <= 15 and p["pairs_96"] <= 15, p
+        assert max(p["passes_64"], p["passes_96"]) == 255 or max(p["pairs_64"], p["pairs_96"]) == 15, p
     # k beyond the fast path / a negative row count: the error codes of atlas_scan_topk
     assert L.atlas_test_plan_word(ctypes.c_int64(1000), 64, 300, 256) == -3 and L.atlas_test_plan_word(ctypes.c_int64(-1), 64, 40, 256) == -1
 

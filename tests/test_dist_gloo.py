@@ -140,3 +140,102 @@ def test_query_block_grows_and_decays_on_every_rank_alike():
     """the fixed-size query collective's block grows for a large batch and falls back to 64 rows after a run of small ones -- decided
     from the gathered headers, so every rank takes the same decision at the same call"""
     mp.spawn(_cap_worker, args=(2, 29871), nprocs=2, join=True)
+
+
+def _default_worker(rank, W, port, out_dir, store_opt):
+    """the DEFAULT configuration of a one-host job, through the index factory: the node-local passage store is built and attached without any
+    option, a search is exactly two collectives, and `topk > smallest shard` raises on every rank before any of them"""
+    import json
+    import types
+
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.pop("ATLAS_PASSAGE_STORE", None)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    from atlas_amd import HipDistributedIndex, index_io
+    from oracle_backend import oracle_local_topk
+
+    HipDistributedIndex._local_topk = oracle_local_topk
+    HipDistributedIndex._device = lambda self: torch.device("cpu")
+    N, k = 301, 6                                          # odd: the shards differ by one row (151 / 150)
+    jsonl = os.path.join(out_dir, "passages.jsonl")
+    if rank == 0:
+        with open(jsonl, "w") as f:
+            for g in range(N):
+                f.write(json.dumps({"id": str(g), "title": f"t{g}", "text": f"p{g}"}) + "\n")
+    dist.barrier()
+    opt = types.SimpleNamespace(index_mode="flat", load_index_path=None, passages=[jsonl], use_file_passages=False, max_passages=-1,
+                                save_index_n_shards=2 * W)
+    if store_opt is not None:
+        opt.passage_store_path = store_opt
+    index, passages = index_io.load_or_initialize_index(opt)
+    assert len(passages) == (N - rank + W - 1) // W
+    P = synth.passages_f16(N, 768, 71)
+    index.embeddings[:, :] = torch.from_numpy(P[np.arange(rank, N, W)]).T
+    if store_opt == "off":
+        assert index._passage_store is None
+    else:
+        assert index._passage_store is not None and len(index._passage_store) == N
+        assert index._passage_store.path.startswith("/dev/shm" if os.path.isdir("/dev/shm") else "/")
+    # count every collective torch.distributed offers while a search runs
+    counts = {}
+    names = ["all_gather_into_tensor", "all_gather", "all_gather_object", "all_to_all_single", "all_to_all", "gather", "gather_object", "all_reduce",
+             "broadcast", "broadcast_object_list", "barrier", "reduce_scatter_tensor", "send", "recv", "scatter"]
+    real = {n: getattr(dist, n) for n in names}
+    for n in names:
+        def counted(*a, _n=n, **kw):
+            counts[_n] = counts.get(_n, 0) + 1
+            return real[_n](*a, **kw)
+        setattr(dist, n, counted)
+    Q = torch.from_numpy(synth.queries_f32(3 + rank, 768, 72 + rank))
+    docs0, scores0 = index.search_knn(Q, k)                 # (first search after init: + the one-off smallest-shard all_gather_object)
+    first = dict(counts)
+    counts.clear()
+    docs, scores = index.search_knn(Q, k)
+    steady = dict(counts)
+    for n in names:
+        setattr(dist, n, real[n])
+    assert docs == docs0 and scores == scores0 and all(d["text"] == f"p{d['id']}" for row in docs for d in row)
+    if store_opt == "off":
+        assert steady == {"all_gather_into_tensor": 2, "all_to_all_single": 2}, steady        # + the winners-only text exchange
+    else:
+        assert steady == {"all_gather_into_tensor": 2}, steady                                # queries, packed winners: nothing else
+        assert first == {"all_gather_into_tensor": 2, "all_gather_object": 1}, first
+    # topk beyond the SMALLEST shard (150 rows on rank 1, 151 on rank 0): every rank raises, before any collective -- nobody hangs
+    counts.clear()
+    for n in names:
+        def counted(*a, _n=n, **kw):
+            counts[_n] = counts.get(_n, 0) + 1
+            return real[_n](*a, **kw)
+        setattr(dist, n, counted)
+    with pytest.raises(RuntimeError, match="selected index k out of range"):
+        index.search_knn(Q, 151)
+    assert counts == {}, counts
+    for n in names:
+        setattr(dist, n, real[n])
+    docs3, _ = index.search_knn(Q, 150)                     # ... and the ranks are still in step afterwards
+    assert len(docs3) == Q.shape[0] and len(docs3[0]) == 150
+    np.savez(os.path.join(out_dir, f"d{rank}.npz"), ids=np.array([[int(d["id"]) for d in row] for row in docs], dtype=np.int64))
+    dist.barrier()
+    if rank == 0 and index._passage_store is not None:
+        for ext in (".bin", ".off.npy", ".meta.json"):
+            try:
+                os.remove(index._passage_store.path + ext)
+            except OSError:
+                pass
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("store_opt", [None, "off"])
+def test_default_one_host_search_is_two_collectives(store_opt, tmp_path, oracle_mod):
+    """on one host the node-local passage store is the default text path (index factory; `passage_store_path="off"` opts
+    out), so a search is the query gather + the packed-winner gather and nothing else; and the topk range check is collective"""
+    W = 2
+    mp.spawn(_default_worker, args=(W, 29911 + (store_opt is None), str(tmp_path), store_opt), nprocs=W, join=True)
+    N, k = 301, 6
+    P = synth.passages_f16(N, 768, 71)
+    Q = np.concatenate([synth.queries_f32(3 + r, 768, 72 + r) for r in range(W)])
+    s, i = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, k)
+    got = np.concatenate([np.load(os.path.join(tmp_path, f"d{r}.npz"))["ids"] for r in range(W)])
+    assert np.array_equal(got, i)

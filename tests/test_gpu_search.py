@@ -745,3 +745,43 @@ def test_search_beside_a_kernel_that_holds_part_of_the_chip(gpu_index_cls):
         report.append((held, busy / quiet))
     print("synchronous search at 2M rows: quiet %.3f ms; " % (quiet * 1e3) + "; ".join(f"{h} CUs held: {r:.2f}x" for h, r in report))
     assert all(r < 3.0 for _, r in report), report
+
+
+def test_host_results_do_not_alias_across_searches(gpu_index_cls):
+    """`_local_topk` hands out VIEWS of a reused pinned buffer (documented there); what the public calls return must not change when
+    the next search overwrites that buffer -- search_knn's lists and _compute_scores_and_indices' device tensors are kept across a second search"""
+    P = synth.passages_f16(30_000, 768, 301)
+    idx = _index(gpu_index_cls, P)
+    Q1 = torch.from_numpy(synth.queries_f32(8, 768, 302)).cuda()
+    Q2 = torch.from_numpy(synth.queries_f32(8, 768, 303)).cuda()
+    docs1, scores1 = idx.search_knn(Q1, 10)
+    s1, i1 = idx._compute_scores_and_indices(Q1, 10)
+    keep = ([[d["id"] for d in row] for row in docs1], [list(r) for r in scores1], s1.clone(), i1.clone())
+    _, _, h_s, h_i = idx._local_topk(Q1, 10)
+    h_before = h_s.copy()
+    docs2, scores2 = idx.search_knn(Q2, 10)
+    assert [[d["id"] for d in row] for row in docs1] == keep[0] and [list(r) for r in scores1] == keep[1]
+    assert torch.equal(s1, keep[2]) and torch.equal(i1, keep[3])
+    assert scores2 != scores1
+    assert not np.array_equal(h_s, h_before)            # ... while the documented views DO follow the buffer: callers copy them at once
+
+
+def test_workspace_of_a_65_to_96_query_batch_on_a_small_shard_is_small(gpu_index_cls):
+    """atlas_scan_topk_workspace_bytes sizes the GEMM-shaped layout only for batches whose plan has a GEMM-shaped pass: 80 queries on a
+    1M-row shard (one 96-query streaming pass) no longer reserve -- and zero-fill -- the 1024-wide layout"""
+    from atlas_amd import _lib
+
+    L = _lib.lib()
+    small = int(L.atlas_scan_topk_workspace_bytes(1_000_000, 80, 768, 40))
+    one = int(L.atlas_scan_topk_workspace_bytes(1_000_000, 64, 768, 40))
+    big = int(L.atlas_scan_topk_workspace_bytes(4_000_000, 80, 768, 40))          # from 4M rows on: the 128-wide GEMM-shaped pass
+    wide = int(L.atlas_scan_topk_workspace_bytes(1_000_000, 1024, 768, 40))
+    print("workspace bytes: 1M x 64:", one, " 1M x 80:", small, " 4M x 80:", big, " 1M x 1024:", wide)
+    assert small < 64 << 20 and small <= 4 * one and wide > small
+    P = synth.passages_f16(200_000, 768, 311)
+    idx = _index(gpu_index_cls, P)
+    Q = torch.from_numpy(synth.queries_f32(80, 768, 312)).cuda()
+    s, i = idx._compute_scores_and_indices(Q, 40)
+    assert idx.last_search_stats["plan"]["gemm_passes"] == 0
+    es, ei = idx._exact_topk(Q[:8], 40)
+    assert torch.equal(s[:8], es) and torch.equal(i[:8], ei)

@@ -206,3 +206,53 @@ def test_contriever_from_pretrained_local_dir(tmp_path):
     (tmp_path / "a" / "config.json").write_text(json.dumps({**cfg, "hidden_act": "relu"}))
     with pytest.raises(Exception, match="hidden_act"):
         retrievers.Contriever.from_pretrained(str(tmp_path / "a"))
+
+
+def test_doc_map_mirror_follows_in_place_edits_and_re_initialisation(monkeypatch, oracle_mod):
+    """the id -> passage mirror of `_docs_of_rows` (a) sees `index.doc_map[i] = p` like the reference, which re-reads doc_map[x]
+    on every search (src/index.py:133); (b) is dropped with the slab, so two re-initialisations with no search between never serve the first
+    corpus' passages, whatever id() the new dict gets; (c) holds for a caller's own plain dict too (new object, or invalidate_doc_cache)."""
+    from oracle_backend import oracle_local_topk
+
+    monkeypatch.setattr(HipDistributedIndex, "_local_topk", oracle_local_topk)
+    P = synth.passages_f16(50, 768, 3)
+    Q = torch.from_numpy(synth.queries_f32(2, 768, 4))
+    idx = HipDistributedIndex()
+    idx.is_in_gpu = False
+    idx.init_embeddings([{"id": str(i), "text": f"a{i}"} for i in range(50)])
+    idx.embeddings[:, :] = torch.from_numpy(P).T
+    docs, _ = idx.search_knn(Q, 3)
+    top = int(docs[0][0]["id"])
+    assert docs[0][0]["text"] == f"a{top}"
+    idx.doc_map[top] = {"id": str(top), "text": "edited"}                    # (a) in place, same dict, same length
+    assert idx.search_knn(Q, 3)[0][0][0]["text"] == "edited"
+    for tag in ("b", "c"):                                                   # (b) two re-inits, no search between
+        idx.init_embeddings([{"id": str(i), "text": f"{tag}{i}"} for i in range(50)])
+    idx.embeddings[:, :] = torch.from_numpy(P).T
+    assert idx.search_knn(Q, 3)[0][0][0]["text"] == f"c{top}"
+    idx.doc_map = {i: {"id": str(i), "text": f"d{i}"} for i in range(50)}     # (c) the caller's own plain dict
+    assert idx.search_knn(Q, 3)[0][0][0]["text"] == f"d{top}"
+    idx.doc_map[top] = {"id": str(top), "text": "plain-edit"}                # a plain dict cannot tell: the documented call
+    idx.invalidate_doc_cache()
+    assert idx.search_knn(Q, 3)[0][0][0]["text"] == "plain-edit"
+    import copy
+    import pickle
+
+    assert pickle.loads(pickle.dumps(idx.doc_map)) == idx.doc_map and copy.deepcopy(idx.doc_map) == idx.doc_map
+
+
+def test_topk_check_is_taken_from_the_smallest_shard(monkeypatch):
+    """the range check of search_knn uses the job's smallest shard (one collective per slab, cached): single process = this shard"""
+    from oracle_backend import oracle_local_topk
+
+    monkeypatch.setattr(HipDistributedIndex, "_local_topk", oracle_local_topk)
+    idx = HipDistributedIndex()
+    idx.is_in_gpu = False
+    idx.init_embeddings([{"id": str(i)} for i in range(5)])
+    idx.embeddings[:, :] = torch.from_numpy(synth.passages_f16(5, 768, 8)).T
+    Q = torch.from_numpy(synth.queries_f32(1, 768, 9))
+    with pytest.raises(RuntimeError, match="selected index k out of range"):
+        idx.search_knn(Q, 6)
+    assert len(idx.search_knn(Q, 5)[0][0]) == 5 and idx._min_shard_rows == 5
+    idx.init_embeddings([{"id": str(i)} for i in range(9)])                 # a new slab: the bound is taken again
+    assert idx._min_shard_rows is None
