@@ -104,8 +104,12 @@ static __device__ __forceinline__ void gs_ds_read(gs_u4& dst, const uint32_t add
 }
 
 // MODE 0 = scan (filter epilogue), 1 = sample (fragment maxima), 2 = scan that also MEASURES every row's norm (the certifying twin: the caller's
-// pmax is a hint, atlas_scan_topk's default contract). The four waves that share a slab fragment row split its eight fragments: 16 v_dot2
-// per k-tile and wave beside its 64 MFMAs.
+// pmax is a hint, atlas_scan_topk's default contract). The four waves that share a slab fragment row split its eight fragments, two each: 16
+// v_dot2 per k-tile and wave beside its 64 MFMAs. Round 5: WHICH two is decided by the wave's LDS read addresses, not by register selects --
+// wave wj reads slab fragment a ^ 2 wj into register slot a (an XOR permutation: slot a's address is one of FOUR per-wave base addresses +
+// the compile-time offset a * 2048), so every wave squares its slots 0 and 1 and they are fragments 2 wj, 2 wj + 1. Round 4 picked the two
+// fragments out of the eight slots with 3 v_cndmask per v_dot2 (64 VALU per k-tile: +10-12 % on the pass, profiles/r04/gscan_certifying_twin.txt);
+// the filter epilogue undoes the permutation in the row tag (one XOR).
 // FB = 16-query fragments per wave: 4 -> the column tile is 256 queries wide (a wave owns 128 rows x 64 queries); 3 -> 192 wide; 2 -> 128 wide
 // (128 x 32: half the MFMAs per k-tile and 48 instead of 64 LDS-DMA pieces). The narrower tiles serve the pass widths a 256-wide tile would
 // leave part empty at the full cost: 97..128 and 129..192 queries, and -- two or four column tiles of 192 -- 257..384 and 513..768.
@@ -283,6 +287,7 @@ gscan_kernel(const GScanParams p) {
                 // nothing here -- falls through, and NO branch inside a hit fragment: every lane stores, the lanes without a passing score
                 // into a dummy slot of their own behind the real ones.
                 const uint32_t dummy = wb + (uint32_t)(GS_WBUF_REAL + ln) * 8u;
+                const uint32_t rot16 = CERT ? (uint32_t)(wj * 32) : 0u;     // MODE 2: register slot a holds slab fragment a ^ 2 wj (rows (a * 16) ^ (2 wj * 16))
                 uint32_t lost = 0;                      // bit b: a passing score of the lane's query column b found no slot
 #pragma unroll
                 for (int b = 0; b < FB; ++b) {
@@ -311,7 +316,7 @@ gscan_kernel(const GScanParams p) {
                             if (pass && idx >= GS_WBUF_REAL - 1) lost |= 1u << b;
                             idx = idx < GS_WBUF_REAL - 1 ? idx : GS_WBUF_REAL - 1;
                             const unsigned long long e = (unsigned long long)f32_bits(v[r]) |
-                                                         ((unsigned long long)(tag0 + (((uint32_t)(b * 16) << 24) | (uint32_t)(a * 16 + r))) << 32);
+                                                         ((unsigned long long)(tag0 + (((uint32_t)(b * 16) << 24) | (((uint32_t)(a * 16) ^ rot16) + (uint32_t)r))) << 32);
                             // (asm: behind an LDS-DMA it cannot prove disjoint hipcc puts s_waitcnt vmcnt(0) in front of every LDS store)
                             asm volatile("ds_write_b64 %0, %1" :: "v"(pass ? wb + idx * 8u : dummy), "v"(e) : "memory");
                             cnt += (uint32_t)__popcll(mask);
@@ -364,6 +369,9 @@ gscan_kernel(const GScanParams p) {
         __builtin_amdgcn_s_barrier();
     }
     int kt = 0, ti = 0, a_due = 0;
+    // MODE 2: the four per-wave displacements of the slab slots (see `bs` in the loop), wave-uniform: +-u1 +-u2
+    const int u1 = (wj & 1) ? 4096 : 0, u2 = (wj & 2) ? 8192 : 0;
+    const int cperm[4] = {u1 + u2, u2 - u1, u1 - u2, -u1 - u2};
     float nrm0 = 0.f, nrm1 = 0.f, pm = 0.f;          // MODE 2: running sums of squares of two slab rows' elements, largest row sum seen
 #pragma unroll 1
     for (int it = 0; it < total_it; ++it) {
@@ -371,6 +379,29 @@ gscan_kernel(const GScanParams p) {
         GS_STAMP(0);
         gs_u4 fs0[8], fq0[FB], fs1[8], fq1[FB];
         const uint32_t s0 = as0 + buf * GS_STG, s1 = s0 ^ 64u, q0 = s0 + (uint32_t)(2 * GS_STG + (wj * QW - wi * 128) * 128), q1 = q0 ^ 64u;
+        // MODE 2: slot a holds slab fragment a ^ 2 wj: byte offset (a ^ 2 wj) * 2048 = a * 2048 -+ u1 -+ u2 with u1 = 4096 (wj & 1), u2 = 8192 (wj >> 1),
+        // the sign of u1 / u2 being MINUS where a has bit 1 / bit 2 -- compile-time per slot: four bases, slot a takes bs[a >> 1]. (The fragment
+        // field, address bits 11-13, is zero in s0: the stages are 32 KiB-aligned, wi sits at bit 14, the row and chunk bits below 11.)
+        uint32_t bs[4] = {s0, s0, s0, s0};
+        if constexpr (CERT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bs[j] = s0 + (uint32_t)cperm[j];
+        }
+        // slab fragment read of register slot k (k-step 0 | 1)
+        auto rd_s0 = [&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (CERT) gs_ds_read<k * 2048>(fs0[k], bs[k >> 1]); else gs_ds_read<k * 2048>(fs0[k], s0);
+        };
+        auto rd_s1 = [&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (CERT) {
+                if constexpr (k == 0) {                // (the step-0 slab reads have all been issued: the bases move on to k-step 1 in place)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bs[j] ^= 64u;
+                }
+                gs_ds_read<k * 2048>(fs1[k], bs[k >> 1]);
+            } else gs_ds_read<k * 2048>(fs1[k], s1);
+        };
         constexpr int NR = 16 + 2 * FB;                // fragment reads of a phase
         // (every fragment register is an in/out operand of the phase's last wait: nothing reads one in front of it)
 #define GS_FS_OPS "+v"(fs0[0]), "+v"(fs0[1]), "+v"(fs0[2]), "+v"(fs0[3]), "+v"(fs0[4]), "+v"(fs0[5]), "+v"(fs0[6]), "+v"(fs0[7]), \
@@ -389,9 +420,9 @@ gscan_kernel(const GScanParams p) {
                 __builtin_amdgcn_sched_barrier(0);
                 gs_static_for<i * NR / NPW, (i + 1) * NR / NPW>([&](auto kc) __attribute__((always_inline)) {
                     constexpr int k = decltype(kc)::value;
-                    if constexpr (k < 8) gs_ds_read<k * 2048>(fs0[k], s0);
+                    if constexpr (k < 8) rd_s0(std::integral_constant<int, k>{});
                     else if constexpr (k < 8 + FB) gs_ds_read<(k - 8) * 2048>(fq0[k - 8], q0);
-                    else if constexpr (k < 16 + FB) gs_ds_read<(k - 8 - FB) * 2048>(fs1[k - 8 - FB], s1);
+                    else if constexpr (k < 16 + FB) rd_s1(std::integral_constant<int, k - 8 - FB>{});
                     else gs_ds_read<(k - 16 - FB) * 2048>(fq1[k - 16 - FB], q1);
                 });
                 __builtin_amdgcn_sched_barrier(0);
@@ -412,7 +443,7 @@ gscan_kernel(const GScanParams p) {
                 __builtin_amdgcn_sched_barrier(0);
                 gs_static_for<i * 16 / NPW, (i + 1) * 16 / NPW>([&](auto kc) __attribute__((always_inline)) {
                     constexpr int k = decltype(kc)::value;
-                    if constexpr (k < 8) gs_ds_read<k * 2048>(fs0[k], s0); else gs_ds_read<(k - 8) * 2048>(fs1[k - 8], s1);
+                    if constexpr (k < 8) rd_s0(std::integral_constant<int, k>{}); else rd_s1(std::integral_constant<int, k - 8>{});
                 });
                 if constexpr (i == 3) {
                     constexpr int since = 4 * 16 / NPW;
@@ -426,7 +457,13 @@ gscan_kernel(const GScanParams p) {
         } else {
             __builtin_amdgcn_sched_barrier(0);
             // (inline asm: hipcc's wait insertion would drain vmcnt(0) in front of any ds_read it sees behind an LDS-DMA it cannot prove disjoint)
-            if constexpr (FB == 4) {
+            if constexpr (CERT) {                      // (the permuted slots: single reads, as in the staging phases)
+                gs_static_for<0, 8>([&](auto kc) __attribute__((always_inline)) { rd_s0(kc); });
+                gs_static_for<0, FB>([&](auto bc) __attribute__((always_inline)) { constexpr int b = decltype(bc)::value; gs_ds_read<b * 2048>(fq0[b], q0); });
+                gs_static_for<0, 8>([&](auto kc) __attribute__((always_inline)) { rd_s1(kc); });
+                gs_static_for<0, FB>([&](auto bc) __attribute__((always_inline)) { constexpr int b = decltype(bc)::value; gs_ds_read<b * 2048>(fq1[b], q1); });
+                GS_READS_DONE();
+            } else if constexpr (FB == 4) {
                 asm volatile(
                     "ds_read_b128 %0, %24\n ds_read_b128 %1, %24 offset:2048\n ds_read_b128 %2, %24 offset:4096\n ds_read_b128 %3, %24 offset:6144\n"
                     "ds_read_b128 %4, %24 offset:8192\n ds_read_b128 %5, %24 offset:10240\n ds_read_b128 %6, %24 offset:12288\n ds_read_b128 %7, %24 offset:14336\n"
@@ -498,15 +535,10 @@ gscan_kernel(const GScanParams p) {
         // branch-free but behind the MFMA block: 3.42) -- the 64 VALU instructions do NOT vanish in the MFMAs' shadow: the multiply phase
         // grows by 100-170 cycles and the partner's read phase by as much (2 670 instead of 2 060 cycles per k-tile, at 1.97 instead of
         // 1.75 GHz). Three quarters of them are the selects: the data a wave squares depends on wj, and registers cannot be indexed.
-        const unsigned long long m0 = (wj & 1) ? ~0ull : 0ull, m1 = (wj & 2) ? ~0ull : 0ull;
-        auto cert_unit = [&](const gs_u4 (&f)[8], auto uc) __attribute__((always_inline)) {        // unit u: dword u & 3 of fragment 2 wj + ((u >> 2) & 1)
+        auto cert_unit = [&](const gs_u4 (&f)[8], auto uc) __attribute__((always_inline)) {        // unit u of a k-step: dword u & 3 of slot u >> 2 (= fragment 2 wj + (u >> 2))
             if constexpr (CERT) {
                 constexpr int u = decltype(uc)::value, e = (u >> 2) & 1, d = u & 3;
-                uint32_t x, y, w;
-                asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(x) : "v"(f[0 + e][d]), "v"(f[2 + e][d]), "s"(m0));
-                asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(y) : "v"(f[4 + e][d]), "v"(f[6 + e][d]), "s"(m0));
-                asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(w) : "v"(x), "v"(y), "s"(m1));
-                const f16x2 h = __builtin_bit_cast(f16x2, w);
+                const f16x2 h = __builtin_bit_cast(f16x2, (uint32_t)f[e][d]);
                 if (e == 0) nrm0 = __builtin_amdgcn_fdot2(h, h, nrm0, false); else nrm1 = __builtin_amdgcn_fdot2(h, h, nrm1, false);
                 __builtin_amdgcn_sched_barrier(0);
             }

@@ -156,7 +156,10 @@ class HipDistributedIndex(object):
         The store must have been built in this index's global-id order: `PassageStore.iter_jsonl` for passages loaded
         round-robin by `index_io.load_passages`, `PassageStore.iter_saved_index` for an index loaded with `load_index`.
         Collective (every rank attaches): the store must hold exactly as many passages as all shards together."""
-        total = sum(int(n) for n in dist_utils.all_gather_object(len(self.doc_map)))
+        sizes = [int(n) for n in dist_utils.all_gather_object(len(self.doc_map))]
+        total = sum(sizes)
+        if self._slab is not None and len(self.doc_map) == int(self._slab.shape[0]):
+            self._min_shard_rows = min(sizes)          # (the shard sizes of the job, for free: search_knn's collective range check)
         if len(store) != total:
             raise ValueError(f"passage store holds {len(store)} passages, the index {total}: it was built from another corpus")
         self._passage_store = store
@@ -262,6 +265,7 @@ class HipDistributedIndex(object):
         # saved shards are contiguous runs of passages: global id = offset of this rank + row
         self._gid_mode = "contiguous"
         sizes = dist_utils.all_gather_object(n_rows)
+        self._min_shard_rows = min(int(s) for s in sizes)          # (search_knn's collective range check, for free)
         self._gid_bounds = np.cumsum([0] + [int(s) for s in sizes])
         self._gid_offset = int(self._gid_bounds[dist_utils.get_rank()])
 

@@ -199,9 +199,10 @@ def _default_worker(rank, W, port, out_dir, store_opt):
     assert docs == docs0 and scores == scores0 and all(d["text"] == f"p{d['id']}" for row in docs for d in row)
     if store_opt == "off":
         assert steady == {"all_gather_into_tensor": 2, "all_to_all_single": 2}, steady        # + the winners-only text exchange
+        assert first == {"all_gather_into_tensor": 2, "all_to_all_single": 2, "all_gather_object": 1}, first     # + once per slab: the smallest shard
     else:
         assert steady == {"all_gather_into_tensor": 2}, steady                                # queries, packed winners: nothing else
-        assert first == {"all_gather_into_tensor": 2, "all_gather_object": 1}, first
+        assert first == {"all_gather_into_tensor": 2}, first                                 # (the shard sizes came with attach_passage_store)
     # topk beyond the SMALLEST shard (150 rows on rank 1, 151 on rank 0): every rank raises, before any collective -- nobody hangs
     counts.clear()
     for n in names:
