@@ -107,7 +107,7 @@ static __device__ __forceinline__ void gs_ds_read(gs_u4& dst, const uint32_t add
 // pmax is a hint, atlas_scan_topk's default contract). The four waves that share a slab fragment row split its eight fragments, two each: 16
 // v_dot2 per k-tile and wave beside its 64 MFMAs. Round 5: WHICH two is decided by the wave's LDS read addresses, not by register selects --
 // wave wj reads slab fragment a ^ 2 wj into register slot a (an XOR permutation: slot a's address is one of FOUR per-wave base addresses +
-// the compile-time offset a * 2048), so every wave squares its slots 0 and 1 and they are fragments 2 wj, 2 wj + 1. Round 4 picked the two
+// the compile-time offset (a & 1) * 2048), so every wave squares its slots 0 and 1 and they are fragments 2 wj, 2 wj + 1. Round 4 picked the two
 // fragments out of the eight slots with 3 v_cndmask per v_dot2 (64 VALU per k-tile: +10-12 % on the pass, profiles/r04/gscan_certifying_twin.txt);
 // the filter epilogue undoes the permutation in the row tag (one XOR).
 // FB = 16-query fragments per wave: 4 -> the column tile is 256 queries wide (a wave owns 128 rows x 64 queries); 3 -> 192 wide; 2 -> 128 wide
@@ -369,9 +369,9 @@ gscan_kernel(const GScanParams p) {
         __builtin_amdgcn_s_barrier();
     }
     int kt = 0, ti = 0, a_due = 0;
-    // MODE 2: the four per-wave displacements of the slab slots (see `bs` in the loop), wave-uniform: +-u1 +-u2
-    const int u1 = (wj & 1) ? 4096 : 0, u2 = (wj & 2) ? 8192 : 0;
-    const int cperm[4] = {u1 + u2, u2 - u1, u1 - u2, -u1 - u2};
+    // MODE 2: the four per-wave displacements of the slab slot PAIRS (see `bs` in the loop), wave-uniform: slots 2 j, 2 j + 1 hold fragments
+    // (2 j) ^ 2 wj and + 1
+    const int cperm[4] = {((0 ^ (2 * wj)) & 7) * 2048, ((2 ^ (2 * wj)) & 7) * 2048, ((4 ^ (2 * wj)) & 7) * 2048, ((6 ^ (2 * wj)) & 7) * 2048};
     float nrm0 = 0.f, nrm1 = 0.f, pm = 0.f;          // MODE 2: running sums of squares of two slab rows' elements, largest row sum seen
 #pragma unroll 1
     for (int it = 0; it < total_it; ++it) {
@@ -379,9 +379,8 @@ gscan_kernel(const GScanParams p) {
         GS_STAMP(0);
         gs_u4 fs0[8], fq0[FB], fs1[8], fq1[FB];
         const uint32_t s0 = as0 + buf * GS_STG, s1 = s0 ^ 64u, q0 = s0 + (uint32_t)(2 * GS_STG + (wj * QW - wi * 128) * 128), q1 = q0 ^ 64u;
-        // MODE 2: slot a holds slab fragment a ^ 2 wj: byte offset (a ^ 2 wj) * 2048 = a * 2048 -+ u1 -+ u2 with u1 = 4096 (wj & 1), u2 = 8192 (wj >> 1),
-        // the sign of u1 / u2 being MINUS where a has bit 1 / bit 2 -- compile-time per slot: four bases, slot a takes bs[a >> 1]. (The fragment
-        // field, address bits 11-13, is zero in s0: the stages are 32 KiB-aligned, wi sits at bit 14, the row and chunk bits below 11.)
+        // MODE 2: slot a holds slab fragment a ^ 2 wj, at byte offset (a ^ 2 wj) * 2048 = ((a & 6) ^ 2 wj) * 2048 + (a & 1) * 2048: a wave-uniform
+        // displacement per slot PAIR (four bases, slot a takes bs[a >> 1]) plus the compile-time offset 0 | 2048
         uint32_t bs[4] = {s0, s0, s0, s0};
         if constexpr (CERT) {
 #pragma unroll
@@ -390,7 +389,7 @@ gscan_kernel(const GScanParams p) {
         // slab fragment read of register slot k (k-step 0 | 1)
         auto rd_s0 = [&](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
-            if constexpr (CERT) gs_ds_read<k * 2048>(fs0[k], bs[k >> 1]); else gs_ds_read<k * 2048>(fs0[k], s0);
+            if constexpr (CERT) gs_ds_read<(k & 1) * 2048>(fs0[k], bs[k >> 1]); else gs_ds_read<k * 2048>(fs0[k], s0);
         };
         auto rd_s1 = [&](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
@@ -399,7 +398,7 @@ gscan_kernel(const GScanParams p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) bs[j] ^= 64u;
                 }
-                gs_ds_read<k * 2048>(fs1[k], bs[k >> 1]);
+                gs_ds_read<(k & 1) * 2048>(fs1[k], bs[k >> 1]);
             } else gs_ds_read<k * 2048>(fs1[k], s1);
         };
         constexpr int NR = 16 + 2 * FB;                // fragment reads of a phase
@@ -527,17 +526,15 @@ gscan_kernel(const GScanParams p) {
         // go to scratch)
         asm volatile("" : "+s"(a_due));
         if (a_due != 0) { epilogue(ti - 1); a_due = 0; }
-        // MODE 2: row sums of squares of this wave's two of the eight fragments of its slab rows, 2 wj and 2 wj + 1 (the lane holds 8 + 8 of a
-        // row's 64 elements of this k-tile), in SIXTEEN units of 3 v_cndmask + 1 v_dot2, one behind every group of FB MFMAs. The fragments
-        // are picked with v_cndmask under wave-uniform masks, not with branches on wj (an if-chain behind the MFMA block: 2-3 taken branches
-        // per k-tile). What the certifying twin costs, 4M rows x 512 queries (tools/batch_gemm_ab.py --certify, tools/gscan_phases.py
-        // --certify: profiles/r04/gscan_certifying_twin.txt): 3.43 ms against the trusting twin's 2.77 on the same box (the if-chain: 3.59;
-        // branch-free but behind the MFMA block: 3.42) -- the 64 VALU instructions do NOT vanish in the MFMAs' shadow: the multiply phase
-        // grows by 100-170 cycles and the partner's read phase by as much (2 670 instead of 2 060 cycles per k-tile, at 1.97 instead of
-        // 1.75 GHz). Three quarters of them are the selects: the data a wave squares depends on wj, and registers cannot be indexed.
+        // MODE 2: row sums of squares of this wave's two of the eight fragments of its slab rows, 2 wj and 2 wj + 1 = its register slots 0 and 1
+        // (the lane holds 8 + 8 of a row's 64 elements of this k-tile), in SIXTEEN v_dot2 per k-tile: units 0..7 of each k-step, one behind
+        // every group of FB MFMAs. (Round 4: the wave picked the two fragments out of eight identical slots with 3 v_cndmask per v_dot2 -- 64 VALU
+        // instructions per k-tile that did NOT vanish in the MFMAs' shadow: multiply phase + 100-170 cycles, the partner's read phase as
+        // much, 3.43 ms against the trusting twin's 2.77 at 4M rows x 512 queries, profiles/r04/gscan_certifying_twin.txt.)
         auto cert_unit = [&](const gs_u4 (&f)[8], auto uc) __attribute__((always_inline)) {        // unit u of a k-step: dword u & 3 of slot u >> 2 (= fragment 2 wj + (u >> 2))
             if constexpr (CERT) {
                 constexpr int u = decltype(uc)::value, e = (u >> 2) & 1, d = u & 3;
+                __builtin_amdgcn_sched_barrier(0);         // (pinned between the MFMA groups on both sides: hipcc otherwise lifts the v_dot2 in front of the block)
                 const f16x2 h = __builtin_bit_cast(f16x2, (uint32_t)f[e][d]);
                 if (e == 0) nrm0 = __builtin_amdgcn_fdot2(h, h, nrm0, false); else nrm1 = __builtin_amdgcn_fdot2(h, h, nrm1, false);
                 __builtin_amdgcn_sched_barrier(0);
