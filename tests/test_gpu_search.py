@@ -788,3 +788,35 @@ def test_workspace_of_a_65_to_96_query_batch_on_a_small_shard_is_small(gpu_index
     assert idx.last_search_stats["plan"]["gemm_passes"] == 0
     es, ei = idx._exact_topk(Q[:8], 40)
     assert torch.equal(s[:8], es) and torch.equal(i[:8], ei)
+
+
+def test_gemm_shaped_certifying_twin_measures_every_fragment_of_a_tile(gpu_index_cls, oracle_mod):
+    """round 5: the certifying twin of the GEMM-shaped pass takes its row norms from the wave's register slots 0 and 1, which hold slab fragments
+    2 wj and 2 wj + 1 through an XOR permutation of the LDS read addresses (gscan_kernel.h) -- so EVERY one of a tile's 16 fragments (8 per
+    row half, two per wave) must be squared by somebody, and the filter epilogue must undo the permutation in the row it reports. A 3 x longer row
+    is planted at each of the 16 fragment positions in turn (different tiles, different rows inside the fragment): the measured pmax must be
+    that row's norm every time, and the results the oracle's (the long row is every query's best or worst passage: it is IN the results)."""
+    N, B, k = 70_000, 128, 40
+    P0 = synth.passages_f16(N, 768, 361)
+    Q = synth.queries_f32(B, 768, 362)
+    for width, nq in ((4, 256), (3, 150), (2, 128)):                      # FB = 4 | 3 | 2: column tiles of 256 | 192 | 128 queries
+        Qw = synth.queries_f32(nq, 768, 363 + width)
+        for pos in range(16):
+            if width != 4 and pos % 5 != 0:                                # (every position on the 256-wide tile, a sample of them on the others)
+                continue
+            P = P0.copy()
+            row = (37 + 11 * pos) * 256 + pos * 16 + (5 * pos + 3) % 16
+            P[row] = (P[row].astype(np.float32) * 3.0).astype(np.float16)
+            want = float(np.sqrt((P[row].astype(np.float64) ** 2).sum()))
+            idx = gpu_index_cls(certify_every=1)
+            idx.init_embeddings([{"id": str(i)} for i in range(N)], 768)
+            idx.embeddings[:, :] = torch.from_numpy(P).cuda().T
+            idx._pmax, idx._pmax_version = 1.002, idx._slab_version()      # a stale hint (the C-ABI caller without a certificate)
+            s, i = _search(idx, Qw, k)
+            st = idx.last_search_stats
+            assert st["plan"]["gemm_passes"] >= 1 and st["reruns"] == 1, (width, pos, st)
+            assert abs(st["pmax"] / want - 1.0) < 2e-3, (width, pos, st["pmax"], want)
+            if pos % 4 == 0:
+                es, ei = oracle_mod.search(oracle_mod.f32_to_f16(Qw), P, k)
+                parity.assert_identical(s, i, es, ei, f"long row at fragment position {pos}, column tile width {width}")
+                assert (i == row).any()
