@@ -534,9 +534,13 @@ gscan_kernel(const GScanParams p) {
         auto cert_unit = [&](const gs_u4 (&f)[8], auto uc) __attribute__((always_inline)) {        // unit u of a k-step: dword u & 3 of slot u >> 2 (= fragment 2 wj + (u >> 2))
             if constexpr (CERT) {
                 constexpr int u = decltype(uc)::value, e = (u >> 2) & 1, d = u & 3;
-                __builtin_amdgcn_sched_barrier(0);         // (pinned between the MFMA groups on both sides: hipcc otherwise lifts the v_dot2 in front of the block)
-                const f16x2 h = __builtin_bit_cast(f16x2, (uint32_t)f[e][d]);
-                if (e == 0) nrm0 = __builtin_amdgcn_fdot2(h, h, nrm0, false); else nrm1 = __builtin_amdgcn_fdot2(h, h, nrm1, false);
+                // (volatile asm between two scheduling barriers: as a builtin the v_dot2 is pure arithmetic, and hipcc gathered the sixteen of a
+                //  k-tile in front of and behind the MFMA block -- two dependent chains of eight in an idle matrix pipe -- instead of leaving one
+                //  behind every group of FB MFMAs)
+                __builtin_amdgcn_sched_barrier(0);
+                const uint32_t h = (uint32_t)f[e][d];
+                if (e == 0) asm volatile("v_dot2c_f32_f16_e32 %0, %1, %1" : "+v"(nrm0) : "v"(h));
+                else asm volatile("v_dot2c_f32_f16_e32 %0, %1, %1" : "+v"(nrm1) : "v"(h));
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
