@@ -120,6 +120,10 @@ def main():
                     help="opt-in (about 2 min of GPU at 4000000): ONE streamed refresh of that many ragged passages (64..200 tokens) from a pinned TokenStore "
                          "into the first rows of the slab = the per-GPU share of BASELINE configs[3]; reports passages/s, host-side shares, pinned bytes, "
                          "power, and checks 4096 sampled rows against the position loop and one 64-query search against the exact path")
+    ap.add_argument("--knn-leg", action="store_true",
+                    help="N > 1: also time the synchronous product call `search_knn` (query gather, scan, packed all-gather, merge, passage text) after the "
+                         "timed region. Off by default at N > 1: its text exchange (all_to_all_single with uneven splits on device tensors) has never run on "
+                         "RCCL with more than one rank, and a failure inside a collective would take the scaling measurement down with it; always on at N = 1")
     ap.add_argument("--oracle-query", type=int, default=31, help="query of the batch held to the CPU oracle at full size in the cpu_baseline leg (-1 = skip)")
     args = ap.parse_args()
 
@@ -331,7 +335,7 @@ def main():
     # (N > 1: a collective -- every rank brings ITS OWN B queries, so each rank scans its shard for N x B queries in ceil(N x B / 64)
     #  slab passes, then one all-gather of the packed winners, the W x k -> k merge and the personalised text exchange)
     knn_ms, knn_err = None, None
-    if world == 1 or backend == "nccl":            # (the gloo logic check keeps device tensors off the collectives)
+    if world == 1 or (backend == "nccl" and args.knn_leg):            # (the gloo logic check keeps device tensors off the collectives)
         # (a failure here fails the run loudly on every N: swallowed on one rank it would leave the others inside a collective)
         index.doc_map = _Docs()
         q_knn = q_own if distinct else q

@@ -204,3 +204,56 @@ def test_bench_refuses_to_run_without_a_gpu():
                        timeout=300)
     assert p.returncode != 0 and "MI355X" in (p.stderr + p.stdout)
     assert not any(line.startswith("{") for line in p.stdout.splitlines())      # no JSON line from a fallback
+
+
+R05_LINES = ["r05/bench_default_32m_sessionA.json", "r05/bench_default_32m_sessionB.json"]
+
+
+@pytest.mark.parametrize("name", R05_LINES)
+def test_round5_line_carries_the_emulated_scaling_curve_and_the_flat_certifying_fraction(name):
+    """round 5: `scale_emulated` -- the per-GPU step of a 1 / 2 / 4 / 8-GPU run of the same corpus on one GPU, labelled as what it is, with the
+    merged shard winners checked against the one-GPU result -- and `roofline.certifying_frac` as a flat field (the driver's parser dropped the
+    nested one)"""
+    d = _line(name)
+    r = d["roofline"]
+    assert abs(r["certifying_frac"] - r["certifying"]["frac"]) < 1e-12 and 0.70 <= r["certifying_frac"] < r["frac"]
+    se = d["scale_emulated"]
+    assert se["label"] == "emulated, no RCCL" and set(se["per_w"]) == {"1", "2", "4", "8"}
+    rows = d["config"]["passages_total"]
+    for w, v in se["per_w"].items():
+        W = int(w)
+        assert v["rows_per_gpu"] == rows // W
+        assert abs(v["step_frac"] - v["rows_per_gpu"] * 1536 / (v["ms_per_step"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+        assert abs(v["queries_per_s"] - 64 / (v["ms_per_step"] * 1e-3)) <= 1e-6 * v["queries_per_s"]
+        if W > 1:
+            assert v["merged_equals_one_gpu_result"] is True and v["steps"] >= 50
+            assert abs(v["efficiency_vs_1"] - se["per_w"]["1"]["ms_per_step"] / v["ms_per_step"] / W) < 1e-9
+    # the ceiling the real curve will be compared with: the 8-GPU step INCLUDING the device merge of 8 x 64 x 40 candidates stays above 0.70
+    assert se["per_w"]["8"]["step_frac"] >= 0.70 and se["per_w"]["8"]["efficiency_vs_1"] >= 0.93
+    assert se["per_w"]["2"]["efficiency_vs_1"] >= 0.98
+
+
+def test_round5_full_shard_refresh_was_run_at_its_stated_scale():
+    """VERDICT r04 missing #2 / next #3: BASELINE configs[3]'s per-GPU share -- ONE streamed refresh of 4M ragged passages from a 2.1 GB pinned token
+    store into a 4M-row slab -- measured, not extrapolated: within 5 % of (here: above) the 16k-passage streamed rate, host batch assembly under
+    5 % of the wall time, the device the bottleneck; 4 096 sampled rows equal the position loop bit for bit, a search on the result equals the
+    exact path"""
+    d = _line("r05/bench_refresh_full_shard_4m.json")
+    f = d["refresh"]["full_shard"]
+    assert f["passages"] == 4_000_000 and f["unit"] == "passages/s" and abs(f["value"] - f["passages"] / f["seconds"]) <= 1e-6 * f["value"]
+    assert f["value"] >= 0.95 * d["refresh"]["streamed"]["value"] and abs(f["vs_streamed_16k"] - f["value"] / d["refresh"]["streamed"]["value"]) < 1e-9
+    assert f["host_fill_share"] < 0.05 and f["host_slot_wait_share"] > 0.8            # the host waits for the device, not the other way round
+    assert 2.0e9 < f["pinned_bytes"] < 2.3e9 and f["tokens"] > 5e8 and f["batches"] > 7000
+    assert f["rows_checked_against_position_loop"] == 4096 and f["search_after_refresh"]["queries_exact"] == 8
+    assert 0.30 < f["frac_of_mfma_peak"] < 0.40 and f["power"]["watts_mean"] > 1000
+
+
+def test_round5_certifying_twin_of_the_big_batches_got_cheaper():
+    """round 5: the certifying twin of the GEMM-shaped pass takes its row norms from register slots its own LDS read addresses fill with the wave's two
+    fragments (no register selects): + 5 % / + 8 % at 128 / 512 queries on session B's box, where round 4's selects cost + 8 % / + 11 % on the same
+    box (session A, same code otherwise)"""
+    a, b = _line(R05_LINES[0])["batch_sweep"], _line(R05_LINES[1])["batch_sweep"]
+    for q, bound in (("128", 1.06), ("512", 1.09)):
+        before = a[q]["certifying_ms_per_step"] / a[q]["ms_per_step"]
+        after = b[q]["certifying_ms_per_step"] / b[q]["ms_per_step"]
+        assert after < before and after <= bound, (q, before, after)

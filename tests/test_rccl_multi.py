@@ -111,7 +111,8 @@ def test_bench_runs_under_torchrun(W):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={W}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(W), "--steps", "5", "--warmup", "2",
            "--passages", "1000003", "--refresh-batches", "0", "--cpu-seconds", "0"]
-    for extra in ([], ["--distinct-queries"]):                           # the metric step (replicated queries) and the API step (every rank its own 64)
+    # the metric step (replicated queries), the API step (every rank its own 64), and the metric step + the synchronous `search_knn` leg (opt-in at N > 1)
+    for extra in ([], ["--distinct-queries"], ["--knn-leg"]):
         p = subprocess.run(cmd + extra, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
         assert p.returncode == 0, p.stderr[-2000:]
         lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -119,8 +120,10 @@ def test_bench_runs_under_torchrun(W):
         d = json.loads(lines[0])
         assert d["n_gpus"] == W and d["config"]["passages_total"] == 1000003 and d["value"] > 0
         assert d["config"]["passages_per_gpu"] == len(range(0, 1000003, W))
-        assert d["config"]["distinct_queries"] is bool(extra) and d["config"]["queries"] == (64 * W if extra else 64)
+        distinct = "--distinct-queries" in extra
+        assert d["config"]["distinct_queries"] is distinct and d["config"]["queries"] == (64 * W if distinct else 64)
+        assert (d["detail"]["search_knn_ms_per_batch"] is not None) == ("--knn-leg" in extra)
         h = d["detail"]["hops"]
         assert h["all_gather_packed_ms"] > 0 and h["merge_packed_ms"] > 0 and h["bytes_per_rank_all_gather"] == d["config"]["queries"] * 40 * 8
-        if extra:
+        if distinct:
             assert d["roofline"]["bound"] == ("mfma" if 64 * W > 96 else "hbm")
