@@ -539,8 +539,17 @@ gscan_kernel(const GScanParams p) {
                 //  behind every group of FB MFMAs)
                 __builtin_amdgcn_sched_barrier(0);
                 const uint32_t h = (uint32_t)f[e][d];
-                if (e == 0) asm volatile("v_dot2c_f32_f16_e32 %0, %1, %1" : "+v"(nrm0) : "v"(h));
-                else asm volatile("v_dot2c_f32_f16_e32 %0, %1, %1" : "+v"(nrm1) : "v"(h));
+                // (hipcc's hazard recognizer does not look inside inline asm: a DOT's result read by a DIFFERENT VALU opcode needs 3 wait states
+                //  -- LLVM: DotWriteDifferentVALURead --, and the copies hipcc places where the two forms of the first k-step meet read the
+                //  accumulators right behind a block's last v_dot2. Found by test_gemm_shaped_certifying_twin_measures_every_fragment_of_a_tile:
+                //  fragment 2 wj + 1 lost one of its 96 v_dot2 per tile. The last unit of each accumulator per k-step carries the wait states.)
+                if (e == 0) {
+                    if constexpr (d == 3) asm volatile("v_dot2c_f32_f16_e32 %0, %1, %1\n\ts_nop 2" : "+v"(nrm0) : "v"(h));
+                    else asm volatile("v_dot2c_f32_f16_e32 %0, %1, %1" : "+v"(nrm0) : "v"(h));
+                } else {
+                    if constexpr (d == 3) asm volatile("v_dot2c_f32_f16_e32 %0, %1, %1\n\ts_nop 2" : "+v"(nrm1) : "v"(h));
+                    else asm volatile("v_dot2c_f32_f16_e32 %0, %1, %1" : "+v"(nrm1) : "v"(h));
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
