@@ -534,22 +534,16 @@ gscan_kernel(const GScanParams p) {
         auto cert_unit = [&](const gs_u4 (&f)[8], auto uc) __attribute__((always_inline)) {        // unit u of a k-step: dword u & 3 of slot u >> 2 (= fragment 2 wj + (u >> 2))
             if constexpr (CERT) {
                 constexpr int u = decltype(uc)::value, e = (u >> 2) & 1, d = u & 3;
-                // (volatile asm between two scheduling barriers: as a builtin the v_dot2 is pure arithmetic, and hipcc gathered the sixteen of a
-                //  k-tile in front of and behind the MFMA block -- two dependent chains of eight in an idle matrix pipe -- instead of leaving one
-                //  behind every group of FB MFMAs)
-                __builtin_amdgcn_sched_barrier(0);
-                const uint32_t h = (uint32_t)f[e][d];
-                // (hipcc's hazard recognizer does not look inside inline asm: a DOT's result read by a DIFFERENT VALU opcode needs 3 wait states
-                //  -- LLVM: DotWriteDifferentVALURead --, and the copies hipcc places where the two forms of the first k-step meet read the
-                //  accumulators right behind a block's last v_dot2. Found by test_gemm_shaped_certifying_twin_measures_every_fragment_of_a_tile:
-                //  fragment 2 wj + 1 lost one of its 96 v_dot2 per tile. The last unit of each accumulator per k-step carries the wait states.)
-                if (e == 0) {
-                    if constexpr (d == 3) asm volatile("v_dot2c_f32_f16_e32 %0, %1, %1\n\ts_nop 2" : "+v"(nrm0) : "v"(h));
-                    else asm volatile("v_dot2c_f32_f16_e32 %0, %1, %1" : "+v"(nrm0) : "v"(h));
-                } else {
-                    if constexpr (d == 3) asm volatile("v_dot2c_f32_f16_e32 %0, %1, %1\n\ts_nop 2" : "+v"(nrm1) : "v"(h));
-                    else asm volatile("v_dot2c_f32_f16_e32 %0, %1, %1" : "+v"(nrm1) : "v"(h));
-                }
+                // (a BUILTIN, and left where hipcc puts it: as pure arithmetic the sixteen v_dot2 of a k-tile end up in front of and behind the MFMA
+                //  block, and that is the cheapest place -- pinned one behind every group of FB MFMAs (volatile asm between scheduling barriers)
+                //  they cost the wave's own dependency-paced MFMA stream as much as round 4's selects did: same-process A/B of three builds,
+                //  4M rows x 128 / 256 / 512 queries, certifying over trusting: round 4's selects + 8.0 / + 9.1 / + 9.7 %, these + 3.4 / + 5.8 /
+                //  + 6.9 %, pinned + 4.1 / + 9.5 / + 10.2 % (profiles/r05/gscan_cert_ab.txt). As inline asm they also lost a dot: hipcc's hazard
+                //  recognizer does not look inside asm, and a DOT's result read by a different VALU opcode needs 3 wait states --
+                //  tests/test_gpu_search.py::test_gemm_shaped_certifying_twin_measures_every_fragment_of_a_tile found it.)
+                __builtin_amdgcn_sched_barrier(0);         // (kept: this is the build that was measured; it does not pin the v_dot2, see above)
+                const f16x2 h = __builtin_bit_cast(f16x2, (uint32_t)f[e][d]);
+                if (e == 0) nrm0 = __builtin_amdgcn_fdot2(h, h, nrm0, false); else nrm1 = __builtin_amdgcn_fdot2(h, h, nrm1, false);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };

@@ -113,29 +113,22 @@ def test_no_unpadded_overwrite_of_store_data():
         assert not bad, bad[:3]
 
 
-def test_certifying_gemm_shaped_scan_has_no_scratch_and_pads_its_inline_asm_dots():
-    """gscan_kernel<2, FB> (round 5): 0 B of scratch at the register cap, 24 v_dot2 per k-tile body (8 per form of the first k-step + 8), and the
-    wait states hipcc cannot see: its hazard recognizer does not look inside inline asm, and a DOT's result read by a DIFFERENT VALU opcode needs
-    3 wait states (LLVM GCNHazardRecognizer: DotWriteDifferentVALURead) -- the copy hipcc places where the two forms of the first k-step meet read
-    an accumulator right behind the block's last v_dot2 and lost it (found on the GPU by the fragment-coverage test)"""
-    fns = {k: v for k, v in _functions(_asm("atlas_hip")).items() if "gscan_kernelILi2E" in k}
-    assert len(fns) == 3, sorted(fns)
-    for name, body in fns.items():
+def test_certifying_gemm_shaped_scan_has_no_scratch_and_no_inline_asm_dots():
+    """gscan_kernel<2, FB> (round 5): 0 B of scratch at the register cap; its v_dot2 are compiler-visible instructions, not inline asm. hipcc's
+    hazard recognizer does not look inside inline asm, and a DOT's result read by a DIFFERENT VALU opcode needs 3 wait states (LLVM
+    GCNHazardRecognizer: DotWriteDifferentVALURead): an asm-volatile version of the certifier lost one of a fragment's 96 dots per tile on the
+    GPU (found by the fragment-coverage test) -- and, pinned between the MFMA groups, was slower than leaving the placement to hipcc. The
+    round-4 selects are gone: at most a handful more v_cndmask than the trusting twin has (they belong to the filter epilogue)."""
+    fns = _functions(_asm("atlas_hip"))
+    cert = {k: v for k, v in fns.items() if "gscan_kernelILi2E" in k}
+    assert len(cert) == 3, sorted(cert)
+    for name, body in cert.items():
         assert _scratch_bytes(body) == 0, f"{name} spills {_scratch_bytes(body)} bytes"
         lines = [l.strip() for l in body.split("\n")]
-        ins = [l for l in lines if l and not l.startswith((";", ".", "//"))]
-        dots = [i for i, l in enumerate(ins) if l.startswith("v_dot2c_f32_f16")]
-        assert len(dots) == 24, (name, len(dots))
+        ins = [l for l in lines if l and not l.startswith((".", "//"))]
+        dots = [i for i, l in enumerate(ins) if l.startswith("v_dot2")]
+        assert len(dots) >= 16, (name, len(dots))
         for i in dots:
-            dst = ins[i].split()[1].rstrip(",")
-            waited = 0
-            for nxt in ins[i + 1: i + 6]:
-                if waited >= 3:
-                    break
-                op = nxt.split()[0]
-                if op == "s_nop":
-                    waited += int(nxt.split()[1]) + 1
-                    continue
-                reads = re.search(r"\b" + dst + r"\b", nxt.split(None, 1)[1] if " " in nxt else "") is not None
-                assert not (reads and not op.startswith("v_dot2c")), f"{name}: `{nxt}` reads {dst} {waited} wait states behind `{ins[i]}`"
-                waited += 1
+            assert not ins[i - 1].startswith(";;#ASMSTART"), f"{name}: an inline-asm v_dot2 (invisible to the hazard recognizer)"
+        twin = fns[name.replace("gscan_kernelILi2E", "gscan_kernelILi0E")]
+        assert body.count("v_cndmask") <= twin.count("v_cndmask") + 16, (name, body.count("v_cndmask"), twin.count("v_cndmask"))
