@@ -59,33 +59,6 @@ class PassageStore:
         os.replace(tmp_off, path + ".off.npy")
 
     @staticmethod
-    def build_from_jsonl(path: str, filenames, maxload: int = -1) -> None:
-        """the store of `iter_jsonl(filenames, maxload)` without parsing what needs no parsing: a line that cannot trigger the title / section
-        join of index_io.parse_passage_line (no "section" key in it) is stored as its own bytes -- `get()` parses it on demand to the very dict
-        `load_passages` builds from it --, every other line goes through parse + dump as in `build_from_items`. About 5 x faster than
-        `build_from_items(path, iter_jsonl(...))` on a corpus of plain lines (the default store of a one-host job is built by ONE rank while the
-        others wait: 32M passages in about a minute instead of several)."""
-        from . import index_io
-
-        offs = [0]
-        tmp_bin = path + ".bin.tmp%d" % os.getpid()
-        with open(tmp_bin, "wb") as fb:
-            for _, line in index_io.iter_passage_lines(filenames, maxload):
-                stripped = line.strip()
-                if stripped:
-                    if '"section"' in stripped or not stripped.startswith("{"):
-                        it = index_io.parse_passage_line(line)
-                        fb.write(json.dumps(it, ensure_ascii=False, separators=(",", ":")).encode("utf-8"))
-                    else:
-                        assert '"id"' in stripped, "a passage without an id (src/index_io.py:27)"
-                        fb.write(stripped.encode("utf-8"))
-                offs.append(fb.tell())
-        tmp_off = path + ".off.tmp%d.npy" % os.getpid()
-        np.save(tmp_off, np.asarray(offs, dtype=np.int64))
-        os.replace(tmp_bin, path + ".bin")
-        os.replace(tmp_off, path + ".off.npy")
-
-    @staticmethod
     def iter_jsonl(filenames, maxload: int = -1):
         """every line of the passage files, parsed exactly like index_io.load_passages (title/section join, None for blank
         lines) but for ALL ranks: item c is global passage c"""
@@ -134,11 +107,7 @@ class PassageStore:
                     os.remove(meta_path)
                 except OSError:
                     pass
-                made = make_items()
-                if isinstance(made, tuple) and len(made) == 3 and made[0] == "jsonl":       # ("jsonl", filenames, maxload): the raw-line fast path
-                    cls.build_from_jsonl(path, made[1], made[2])
-                else:
-                    cls.build_from_items(path, made)
+                cls.build_from_items(path, make_items())
                 tmp = meta_path + ".tmp%d" % os.getpid()
                 with open(tmp, "w") as f:
                     json.dump({"signature": signature}, f)

@@ -256,32 +256,3 @@ def test_topk_check_is_taken_from_the_smallest_shard(monkeypatch):
     assert len(idx.search_knn(Q, 5)[0][0]) == 5 and idx._min_shard_rows == 5
     idx.init_embeddings([{"id": str(i)} for i in range(9)])                 # a new slab: the bound is taken again
     assert idx._min_shard_rows is None
-
-
-def test_passage_store_raw_line_builder_equals_the_parsing_one(tmp_path):
-    """round 5: the default store of a one-host job is built from the jsonl files by ONE rank; lines that cannot trigger the title / section join are
-    stored as their own bytes (PassageStore.build_from_jsonl). Same passages as the parsing builder and as index_io.load_passages, entry by entry:
-    sections (joined), empty sections (kept), blank lines (None), unicode, odd spacing, maxload"""
-    import json
-    from atlas_amd.passage_store import PassageStore
-
-    lines = [json.dumps({"id": "0", "title": "A", "section": "s", "text": "x"}), "", '  {"id": "2",   "title": "B",  "text": "é ü 漢 \\u00e9"}  ',
-             json.dumps({"id": "3", "title": "C", "section": "", "text": "empty section stays"}), json.dumps({"id": "4", "text": 'quote " and \\\\ backslash'}),
-             json.dumps({"id": "5", "title": "section", "text": "the word section in a value"})]
-    f = tmp_path / "p.jsonl"
-    f.write_text("\n".join(lines) + "\n")
-    a, b = str(tmp_path / "parsed"), str(tmp_path / "raw")
-    PassageStore.build_from_items(a, PassageStore.iter_jsonl([str(f)]))
-    PassageStore.build_from_jsonl(b, [str(f)])
-    sa, sb = PassageStore(a), PassageStore(b)
-    want = load_passages([str(f)])
-    assert len(sa) == len(sb) == len(want) == 6
-    for i in range(6):
-        assert sa.get(i) == sb.get(i) == want[i], i
-    assert sb.get(0)["title"] == "A: s" and sb.get(1) is None and sb.get(3)["section"] == ""
-    c = str(tmp_path / "raw_max")
-    PassageStore.build_from_jsonl(c, [str(f)], maxload=3)
-    assert len(PassageStore(c)) == 3
-    # open_shared takes the raw-line builder through the ("jsonl", files, maxload) form the index factory passes
-    st = PassageStore.open_shared(str(tmp_path / "shared"), lambda: ("jsonl", [str(f)], -1), signature="t")
-    assert [st.get(i) for i in range(6)] == want
