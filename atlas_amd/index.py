@@ -526,7 +526,7 @@ class HipDistributedIndex(object):
         lo, hi = int(bounds[rank]), int(bounds[rank + 1])
         if self._passage_store is not None:
             # node-local passage store: ids resolve locally, no text collective at all
-            docs = [[self._passage_store.get(int(g)) for g in m_gid[b] if g >= 0] for b in range(lo, hi)]
+            docs = [self._passage_store.get_many(m_gid[b][m_gid[b] >= 0]) for b in range(lo, hi)]
             out_scores = [[float(s) for s, g in zip(m_scores[b], m_gid[b]) if g >= 0] for b in range(lo, hi)]
             return docs, out_scores
         owner, local = self._gid_owner(np.maximum(m_gid, 0))

@@ -133,5 +133,9 @@ def load_or_initialize_index(opt):
                 return PassageStore.iter_jsonl(opt.passages, opt.max_passages)
         store = PassageStore.open_shared(store_path, make, signature=_corpus_signature(opt), local_rank=getattr(opt, "local_rank", None))
         index.attach_passage_store(store)
+        if dist_utils.get_rank() == 0:
+            # (an automatic store stays under /dev/shm -- RAM -- for the next job on the same corpus, keyed by what it was built from; remove
+            #  <path>.bin / .off.npy / .meta.json to free it)
+            logger.info("node-local passage store %s: %d passages, %.1f MB", store_path, len(store), os.path.getsize(store_path + ".bin") / 1e6)
 
     return index, passages

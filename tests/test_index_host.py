@@ -256,3 +256,27 @@ def test_topk_check_is_taken_from_the_smallest_shard(monkeypatch):
     assert len(idx.search_knn(Q, 5)[0][0]) == 5 and idx._min_shard_rows == 5
     idx.init_embeddings([{"id": str(i)} for i in range(9)])                 # a new slab: the bound is taken again
     assert idx._min_shard_rows is None
+
+
+def test_passage_store_payload_is_pickled_and_old_json_stores_still_read(tmp_path):
+    """round 5: the store's payload is one pickle per passage (0.6 us per lookup against 3.3 us for JSON: 2 560 winners per search and rank);
+    a store of the older JSON format is still READ entry by entry (first byte), and REBUILT by open_shared when a signature is given"""
+    import json
+    from atlas_amd.passage_store import PassageStore
+
+    items = [{"id": "0", "title": "A", "text": "x é 漢"}, None, {"id": "2", "text": "y"}]
+    new = str(tmp_path / "new")
+    PassageStore.build_from_items(new, items)
+    st = PassageStore(new)
+    assert [st.get(i) for i in range(3)] == items and st.get_many([2, 0, 1, 2]) == [items[2], items[0], None, items[2]]
+    assert open(new + ".bin", "rb").read(1) == b"\x80"
+    # an old-format store, written by hand
+    old = str(tmp_path / "old")
+    blobs = [json.dumps(it, ensure_ascii=False).encode() if it is not None else b"" for it in items]
+    open(old + ".bin", "wb").write(b"".join(blobs))
+    np.save(old + ".off.npy", np.cumsum([0] + [len(b) for b in blobs]).astype(np.int64))
+    assert [PassageStore(old).get(i) for i in range(3)] == items and PassageStore(old).get_many([0, 1, 2]) == items
+    json.dump({"signature": "s"}, open(old + ".meta.json", "w"))            # (no "format": rounds 2-4)
+    rebuilt = PassageStore.open_shared(old, lambda: iter(items), signature="s")
+    assert open(old + ".bin", "rb").read(1) == b"\x80" and [rebuilt.get(i) for i in range(3)] == items
+    assert json.load(open(old + ".meta.json"))["format"] == 2
