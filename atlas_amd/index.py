@@ -526,8 +526,11 @@ class HipDistributedIndex(object):
         lo, hi = int(bounds[rank]), int(bounds[rank + 1])
         if self._passage_store is not None:
             # node-local passage store: ids resolve locally, no text collective at all
-            docs = [self._passage_store.get_many(m_gid[b][m_gid[b] >= 0]) for b in range(lo, hi)]
-            out_scores = [[float(s) for s, g in zip(m_scores[b], m_gid[b]) if g >= 0] for b in range(lo, hi)]
+            mine_g, mine_s = m_gid[lo:hi], m_scores[lo:hi]
+            if bool((mine_g >= 0).all()):                  # (the common case: every query has k real winners -- lists built in C)
+                return [self._passage_store.get_many(row) for row in mine_g], mine_s.astype(np.float64).tolist()
+            docs = [self._passage_store.get_many(row[row >= 0]) for row in mine_g]
+            out_scores = [[float(s) for s, g in zip(srow, grow) if g >= 0] for srow, grow in zip(mine_s, mine_g)]
             return docs, out_scores
         owner, local = self._gid_owner(np.maximum(m_gid, 0))
         # passage text: for every rank, the winners of ITS queries that live in this shard (k per query and destination, not
