@@ -11,7 +11,7 @@ import os
 
 from . import dist_utils
 from .index import HipDistributedIndex
-from .passage_store import PassageStore
+from .passage_store import PassageStore, PassageStoreError
 
 logger = logging.getLogger(__name__)
 
@@ -91,12 +91,22 @@ def _passage_store_path(opt, restored: bool):
         return None                                   # one process: doc_map resolves everything, nothing to exchange
     if not restored and getattr(opt, "use_file_passages", False):
         return None
-    hosts = dist_utils.all_gather_object(socket.gethostname())
-    if len(set(hosts)) != 1:
-        logger.info("ranks on %d hosts: no automatic passage store (set opt.passage_store_path to a node-local path to get one)", len(set(hosts)))
+    # /dev/shm if it has room for the corpus text (containers often mount 64 MiB there), else the temporary directory (a file the page cache
+    # serves). Every rank proposes, rank 0's proposal is taken: the ranks must agree on the path
+    import shutil
+
+    if restored:
+        need = sum(os.path.getsize(os.path.join(opt.load_index_path, f"passages.{s}.pt")) for s in range(opt.save_index_n_shards))
+    else:
+        need = sum(os.path.getsize(f) for f in opt.passages)
+    base = tempfile.gettempdir()
+    if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) and shutil.disk_usage("/dev/shm").free > 1.5 * need + (64 << 20):
+        base = "/dev/shm"
+    hosts = dist_utils.all_gather_object((socket.gethostname(), base))
+    if len({h for h, _ in hosts}) != 1:
+        logger.info("ranks on %d hosts: no automatic passage store (set opt.passage_store_path to a node-local path to get one)", len({h for h, _ in hosts}))
         return None
-    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
-    return os.path.join(base, "atlas_amd_passages_" + _corpus_signature(opt)[:16])
+    return os.path.join(hosts[0][1], "atlas_amd_passages_" + _corpus_signature(opt)[:16])
 
 
 def load_or_initialize_index(opt):
@@ -131,7 +141,15 @@ def load_or_initialize_index(opt):
         else:
             def make():
                 return PassageStore.iter_jsonl(opt.passages, opt.max_passages)
-        store = PassageStore.open_shared(store_path, make, signature=_corpus_signature(opt), local_rank=getattr(opt, "local_rank", None))
+        explicit = getattr(opt, "passage_store_path", None) is not None
+        try:
+            store = PassageStore.open_shared(store_path, make, signature=_corpus_signature(opt), local_rank=getattr(opt, "local_rank", None))
+        except PassageStoreError as e:
+            if explicit:
+                raise                                   # the caller asked for a store at that path: say so (on every rank alike)
+            # the AUTOMATIC store is an optimisation: without it the search keeps the winners-only text exchange (every rank gets here together)
+            logger.warning("%s; searching with the winners-only text exchange instead", e)
+            return index, passages
         index.attach_passage_store(store)
         if dist_utils.get_rank() == 0:
             # (an automatic store stays under /dev/shm -- RAM -- for the next job on the same corpus, keyed by what it was built from; remove

@@ -110,26 +110,44 @@ class PassageStore:
         (what it was built from: index_io._corpus_signature) is already there; everyone maps it after a barrier. A store built from
         another corpus / max_passages / shard count is rebuilt, never reused: its ids would resolve to the wrong text."""
         meta_path = path + ".meta.json"
+        failure = None
         if cls.node_local_rank(local_rank) == 0:
-            fresh = os.path.exists(path + ".off.npy") and os.path.exists(path + ".bin")
-            if fresh and signature is not None:
-                try:
-                    with open(meta_path) as f:
-                        meta = json.load(f)
-                    fresh = meta.get("signature") == signature and meta.get("format") == FORMAT
-                except (OSError, ValueError):
-                    fresh = False
-            if not fresh:
-                # the old signature goes FIRST: a crash between here and the new meta file must not leave it next to new content
-                try:
-                    os.remove(meta_path)
-                except OSError:
-                    pass
-                cls.build_from_items(path, make_items())
-                tmp = meta_path + ".tmp%d" % os.getpid()
-                with open(tmp, "w") as f:
-                    json.dump({"signature": signature, "format": FORMAT}, f)
-                os.replace(tmp, meta_path)
+            # (a failure of the builder -- no space under /dev/shm, an unreadable corpus file -- must not leave the other ranks in the barrier:
+            #  it is caught, every rank learns of it in the one collective below, and every rank raises the same PassageStoreError)
+            try:
+                fresh = os.path.exists(path + ".off.npy") and os.path.exists(path + ".bin")
+                if fresh and signature is not None:
+                    try:
+                        with open(meta_path) as f:
+                            meta = json.load(f)
+                        fresh = meta.get("signature") == signature and meta.get("format") == FORMAT
+                    except (OSError, ValueError):
+                        fresh = False
+                if not fresh:
+                    # the old signature goes FIRST: a crash between here and the new meta file must not leave it next to new content
+                    try:
+                        os.remove(meta_path)
+                    except OSError:
+                        pass
+                    cls.build_from_items(path, make_items())
+                    tmp = meta_path + ".tmp%d" % os.getpid()
+                    with open(tmp, "w") as f:
+                        json.dump({"signature": signature, "format": FORMAT}, f)
+                    os.replace(tmp, meta_path)
+            except Exception as e:              # noqa: BLE001  (whatever it was: the verdict has to reach every rank)
+                failure = f"{type(e).__name__}: {e}"
+                for leftover in (path + ".bin.tmp%d" % os.getpid(), path + ".off.tmp%d.npy" % os.getpid()):
+                    try:
+                        os.remove(leftover)
+                    except OSError:
+                        pass
         if dist_utils.is_initialized():
-            dist_utils.barrier()
+            verdicts = [v for v in dist_utils.all_gather_object(failure) if v is not None]        # (also the barrier the mapping below needs)
+            failure = verdicts[0] if verdicts else None
+        if failure is not None:
+            raise PassageStoreError(f"passage store {path} could not be built: {failure}")
         return cls(path)
+
+
+class PassageStoreError(RuntimeError):
+    """raised by `PassageStore.open_shared` on EVERY rank when the node's builder failed"""

@@ -177,7 +177,8 @@ def _default_worker(rank, W, port, out_dir, store_opt):
         assert index._passage_store is None
     else:
         assert index._passage_store is not None and len(index._passage_store) == N
-        assert index._passage_store.path.startswith("/dev/shm" if os.path.isdir("/dev/shm") else "/")
+        import tempfile
+        assert os.path.dirname(index._passage_store.path) in ("/dev/shm", tempfile.gettempdir())
     # count every collective torch.distributed offers while a search runs
     counts = {}
     names = ["all_gather_into_tensor", "all_gather", "all_gather_object", "all_to_all_single", "all_to_all", "gather", "gather_object", "all_reduce",
@@ -240,3 +241,54 @@ def test_default_one_host_search_is_two_collectives(store_opt, tmp_path, oracle_
     s, i = oracle_mod.search(oracle_mod.f32_to_f16(Q), P, k)
     got = np.concatenate([np.load(os.path.join(tmp_path, f"d{r}.npz"))["ids"] for r in range(W)])
     assert np.array_equal(got, i)
+
+
+def _store_failure_worker(rank, W, port, out_dir):
+    """the node's builder fails (here: the factory's builder is made to raise on the building rank): every rank learns of it in the one collective
+    of open_shared, the AUTOMATIC store is given up with a warning on every rank alike and the search keeps the winners-only exchange; an
+    EXPLICIT store path raises PassageStoreError on every rank -- nobody is left in a barrier"""
+    import json
+    import types
+
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.pop("ATLAS_PASSAGE_STORE", None)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    from atlas_amd import HipDistributedIndex, index_io, passage_store
+    from oracle_backend import oracle_local_topk
+
+    HipDistributedIndex._local_topk = oracle_local_topk
+    HipDistributedIndex._device = lambda self: torch.device("cpu")
+    N, k = 90, 4
+    jsonl = os.path.join(out_dir, "passages.jsonl")
+    if rank == 0:
+        with open(jsonl, "w") as f:
+            for g in range(N):
+                f.write(json.dumps({"id": str(g), "text": f"p{g}"}) + "\n")
+    dist.barrier()
+    real_build = passage_store.PassageStore.build_from_items
+
+    def failing_build(path, items):
+        raise OSError(28, "No space left on device (test)")
+
+    passage_store.PassageStore.build_from_items = staticmethod(failing_build)
+    opt = types.SimpleNamespace(index_mode="flat", load_index_path=None, passages=[jsonl], use_file_passages=False, max_passages=-1, save_index_n_shards=2 * W)
+    index, passages = index_io.load_or_initialize_index(opt)                 # automatic store: given up, on every rank
+    assert index._passage_store is None
+    P = synth.passages_f16(N, 768, 81)
+    index.embeddings[:, :] = torch.from_numpy(P[np.arange(rank, N, W)]).T
+    docs, scores = index.search_knn(torch.from_numpy(synth.queries_f32(2, 768, 82 + rank)), k)
+    assert len(docs) == 2 and all(d["text"] == f"p{d['id']}" for row in docs for d in row)
+    opt.passage_store_path = os.path.join(out_dir, "explicit_store")          # explicit: the error reaches the caller, on every rank
+    with pytest.raises(passage_store.PassageStoreError, match="No space left"):
+        index_io.load_or_initialize_index(opt)
+    passage_store.PassageStore.build_from_items = real_build
+    index2, _ = index_io.load_or_initialize_index(opt)                        # ... and the same call succeeds once the builder does
+    assert index2._passage_store is not None and len(index2._passage_store) == N
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failing_store_builder_reaches_every_rank(tmp_path):
+    mp.spawn(_store_failure_worker, args=(2, 29947, str(tmp_path)), nprocs=2, join=True)
