@@ -334,4 +334,4 @@ def test_retrieval_level_agreement_of_refreshed_slabs(gpu_index_cls):
           f"median {float(np.median(gap_ulps)):.0f} ulps, zero on {float(np.mean(gap_ulps == 0)):.2f} of the queries")
     assert emb_err <= 2e-3
     assert top1 >= 0.95 and abs(src_top1[0] - src_top1[1]) <= 0.05
-    assert overlap.mean() >= 0.80 and float(np.mean(ulps <= 2)) >= 0.99
+    assert overlap.mean() >= 0.95 and float(np.mean(ulps <= 2)) >= 0.99            # (measured: 0.987 mean, 0.95 minimum, every common id within 1 ulp)
