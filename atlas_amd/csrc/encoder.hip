@@ -1641,8 +1641,8 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
         hipLaunchKernelGGL(kern, dim3((mtiles + 7) / 8 * 8 * (N / bcol)), dim3(nthreads), lds, stream, A, W, bias, R, C, VT,
                            cu, n, tokinfo, N, K, Lp);
     };
-    if (cfg == 9 && sizeof(typename T::elem) != 2) cfg = 4;                 // the persistent kernel serves the 16-bit dtypes
-    if (cfg == 9) {
+    if ((cfg == 9 || cfg == 10) && sizeof(typename T::elem) != 2) cfg = 4;   // the persistent kernel serves the 16-bit dtypes
+    if (cfg == 9 || cfg == 10) {              // 10 (tuning build only): rounds 3-4's two-launch QKV with the V^T epilogue, the A/B reference of 9
         if constexpr (sizeof(typename T::elem) == 2) {
             // one workgroup per CU, a multiple of 8 so that workgroup b's tiles are those of XCD b % 8; workgroups without a tile exit
             const unsigned grid = (unsigned)(encoder_device_cus() / 8 * 8);
@@ -1654,9 +1654,17 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
 #endif
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 160 * 1024, stream, A, Wp, bp, R, C, VT, cu, n, tokinfo, Np, K, Lp, g_gemm_diag, dbg);
             };
-            if constexpr (EPI == 3) {        // QKV projection: q | k columns -> [M, 1536], then the v columns -> V^T
-                go_pt(gemm_pt_kernel<T, 3>, W, bias, 2 * HID);
-                go_pt(gemm_pt_kernel<T, 4>, W + (size_t)2 * HID * K, bias + 2 * HID, HID);
+            if constexpr (EPI == 3) {
+                // QKV projection: ONE launch, all 2304 columns row-major into [M, 2304] (round 5: attention_kernel<.., VROW> takes V from there;
+                // rounds 3-4: q | k -> [M, 1536], then a second launch with the V^T epilogue, EPI 4 -- 31 us per V tile against 25.5 for a
+                // q | k tile, and one more kernel fill + drain per layer)
+#if ATLAS_TUNING
+                if (cfg == 10) {
+                    go_pt(gemm_pt_kernel<T, 3>, W, bias, 2 * HID);
+                    go_pt(gemm_pt_kernel<T, 4>, W + (size_t)2 * HID * K, bias + 2 * HID, HID);
+                } else
+#endif
+                go_pt(gemm_pt_kernel<T, 3>, W, bias, 3 * HID);
             } else {
                 go_pt(gemm_pt_kernel<T, EPI>, W, bias, N);
             }
@@ -1720,7 +1728,13 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
 //   transposition of V here (the QKV GEMM epilogue wrote V^T).
 // L <= 512; Lp = L rounded up to 32; MAXKF = compile-time bound on Lp/16.
 // ------------------------------------------------------------------------------------------
-template <class T, int MAXKF>
+// VROW (round 5, the 16-bit bulk path): the QKV projection is ONE GEMM launch that leaves q | k | v row-major in `qk` ([M][2304]; `vt` unused). V is
+// staged like K -- coalesced 16-byte chunks, rows of 64 dims at a 144-byte pitch -- and the P.V B operand (4 consecutive KEYS of one dim per
+// lane) comes out of that row-major tile through gfx950's transposing LDS read: `ds_read_b64_tr_b16` with lane s of a 16-lane group pointing at
+// key 4 g + (s >> 2), dims 16 df + 4 (s & 3) .. + 3 returns V[4 g + j][16 df + (lane & 15)], j = 0..3, to lane (lane & 15, g) -- checked element
+// by element on the hardware (tools/tr_probe.hip, profiles/r05/tr_probe.txt). The same values in the same registers as the V^T path: results
+// are bit-identical (tools/lib_ab.py compares the builds' outputs). What it buys is on the GEMM side: no V^T epilogue, one launch less per layer.
+template <class T, int MAXKF, bool VROW = false>
 __global__ void __launch_bounds__(256)
 attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ vt, const int* __restrict__ cu, int LpMax,
                  uint16_t* __restrict__ ctx) {
@@ -1739,17 +1753,20 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
     const int Lp = (L + 31) & ~31;
     uint4* sK = (uint4*)smem;                                  // [Lp][8]
     const int vstride = Lp + 8;                                // halfs
-    uint16_t* sVt = (uint16_t*)(sK + (size_t)Lp * 8);          // [64][Lp + 8]
-    float* sMask = (float*)(sVt + 64 * vstride);               // [Lp] 0 for keys < L, -inf beyond
-    const uint16_t* Qb = qk + (size_t)tb * (2 * HID) + h * DHEAD;
+    uint16_t* sVt = (uint16_t*)(sK + (size_t)Lp * 8);          // [64][Lp + 8]   (VROW: [Lp][72]: the same bytes at Lp = 64, 9 / 8.5 of them above)
+    constexpr int VPITCH = 144;                                // VROW: bytes per key row of the V tile (64 dims + 16 B: the 4 rows of a tr read hit 4 different bank windows)
+    float* sMask = VROW ? (float*)((unsigned char*)sVt + (size_t)Lp * VPITCH) : (float*)(sVt + 64 * vstride);      // [Lp] 0 for keys < L, -inf beyond
+    constexpr int QLD = VROW ? 3 * HID : 2 * HID;              // row pitch of `qk`
+    const uint16_t* Qb = qk + (size_t)tb * QLD + h * DHEAD;
     const uint16_t* Kb = Qb + HID;
-    const uint16_t* Vt = vt + ((size_t)b * HID + h * DHEAD) * LpMax + (tb & 7);     // the passage's keys start tb & 7 columns into its rows (layout note)
+    const uint16_t* Vb = Qb + 2 * HID;                         // VROW: this head's V rows, [key][64] at pitch QLD
+    const uint16_t* Vt = VROW ? nullptr : vt + ((size_t)b * HID + h * DHEAD) * LpMax + (tb & 7);     // the passage's keys start tb & 7 columns into its rows (layout note)
     // the first query fragment of this wave is requested before K / V^T are staged (its latency runs under the staging), the
     // next one before the current one is computed
     auto load_q = [&](const int qf, uint4& qa, uint4& qb) {
         int qrow = qf * 16 + lr; if (qrow >= L) qrow = L - 1;
-        qa = *(const uint4*)(Qb + (size_t)qrow * (2 * HID) + lg * 8);
-        qb = *(const uint4*)(Qb + (size_t)qrow * (2 * HID) + 32 + lg * 8);
+        qa = *(const uint4*)(Qb + (size_t)qrow * QLD + lg * 8);
+        qb = *(const uint4*)(Qb + (size_t)qrow * QLD + 32 + lg * 8);
     };
     uint4 q0n = make_uint4(0, 0, 0, 0), q1n = q0n;
     if (wave * 16 < L) load_q(wave, q0n, q1n);
@@ -1765,14 +1782,19 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
         for (int i = 0; i < 4; ++i) {
             const int idx = base + i * 256 + tid;
             const int key = idx >> 3, ch = idx & 7;
-            kv[i] = *(const uint4*)(Kb + (size_t)(key < L ? key : L - 1) * (2 * HID) + ch * 8);   // unconditional (clamped): no branch, all in flight
+            kv[i] = *(const uint4*)(Kb + (size_t)(key < L ? key : L - 1) * QLD + ch * 8);   // unconditional (clamped): no branch, all in flight
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = base + i * 256 + tid;              // V^T has 64 * cpr = Lp * 8 chunks as well
-            const int idc = idx < Lp * 8 ? idx : Lp * 8 - 1;
-            const int dim = idc / cpr, c = idc - dim * cpr;
-            vv[i] = *(const uint4_a2*)(Vt + (size_t)dim * LpMax + c * 8);     // 2-byte aligned for ragged batches: one global_load_dwordx4 all the same
+            if constexpr (VROW) {                              // the same (key, chunk) walk as K
+                const int key = idx >> 3, ch = idx & 7;
+                vv[i] = *(const uint4*)(Vb + (size_t)(key < L ? key : L - 1) * QLD + ch * 8);
+            } else {
+                const int idc = idx < Lp * 8 ? idx : Lp * 8 - 1;
+                const int dim = idc / cpr, c = idc - dim * cpr;
+                vv[i] = *(const uint4_a2*)(Vt + (size_t)dim * LpMax + c * 8);     // 2-byte aligned for ragged batches: one global_load_dwordx4 all the same
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1784,6 +1806,11 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
         for (int i = 0; i < 4; ++i) {
             const int idx = base + i * 256 + tid;
             if (idx >= Lp * 8) continue;
+            if constexpr (VROW) {                              // key rows of 144 B; rows >= L (another passage's tokens) are zero
+                const int key = idx >> 3, ch = idx & 7;
+                *(uint4*)((unsigned char*)sVt + key * VPITCH + ch * 16) = (key < L) ? vv[i] : make_uint4(0, 0, 0, 0);
+                continue;
+            }
             const int dim = idx / cpr, c = idx - dim * cpr;
             uint4 v = vv[i];
             const int left = L - c * 8;                        // columns >= L were never written: force them to 0
@@ -1923,11 +1950,29 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
         for (int ks = 0; ks < NKF / 2; ++ks)
             if (!GUARD || FULL || 2 * ks < nkf) {
                 const uint4 pa = make_uint4(pk[2 * ks][0], pk[2 * ks][1], pk[2 * ks + 1][0], pk[2 * ks + 1][1]);
+                if constexpr (VROW) {
+                    // keys 32 ks + 4 lg .. + 3 (v0) and + 16 (v1) of dim 16 df + lr, out of the row-major tile: the lane's address selects key
+                    // 4 lg + (lr >> 2) and dims 4 (lr & 3) .. + 3, the instruction transposes inside the 16-lane group (header note)
+                    const uint32_t va = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)sVt +
+                                        (uint32_t)((32 * ks + 4 * lg + (lr >> 2)) * VPITCH + 8 * (lr & 3));
+                    unsigned long long t0, t1, t2, t3, t4, t5, t6, t7;
+                    asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:2304\n\t"
+                                 "ds_read_b64_tr_b16 %2, %8 offset:32\n\tds_read_b64_tr_b16 %3, %8 offset:2336\n\t"
+                                 "ds_read_b64_tr_b16 %4, %8 offset:64\n\tds_read_b64_tr_b16 %5, %8 offset:2368\n\t"
+                                 "ds_read_b64_tr_b16 %6, %8 offset:96\n\tds_read_b64_tr_b16 %7, %8 offset:2400\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7) : "v"(va) : "memory");
+                    const unsigned long long tv[4][2] = {{t0, t1}, {t2, t3}, {t4, t5}, {t6, t7}};
 #pragma unroll
-                for (int df = 0; df < 4; ++df) {
-                    const uint16_t* vrow = sVt + (df * 16 + lr) * vstride + ks * 32 + lg * 4;
-                    const uint2 v0 = *(const uint2*)vrow, v1 = *(const uint2*)(vrow + 16);
-                    o[df] = T::mma(pa, make_uint4(v0.x, v0.y, v1.x, v1.y), o[df]);
+                    for (int df = 0; df < 4; ++df)
+                        o[df] = T::mma(pa, make_uint4((uint32_t)tv[df][0], (uint32_t)(tv[df][0] >> 32), (uint32_t)tv[df][1], (uint32_t)(tv[df][1] >> 32)), o[df]);
+                } else {
+#pragma unroll
+                    for (int df = 0; df < 4; ++df) {
+                        const uint16_t* vrow = sVt + (df * 16 + lr) * vstride + ks * 32 + lg * 4;
+                        const uint2 v0 = *(const uint2*)vrow, v1 = *(const uint2*)(vrow + 16);
+                        o[df] = T::mma(pa, make_uint4(v0.x, v0.y, v1.x, v1.y), o[df]);
+                    }
                 }
             }
         // context_layer.permute(0,2,1,3).view(.., 768): [token][h*64 + dim]
@@ -2146,12 +2191,20 @@ int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int
             else
                 hipLaunchKernelGGL(attention_f32_kernel<32>, dim3((unsigned)n * NHEAD), dim3(256), 0, stream, qk, vt, cu, LpS, ctx);
         } else {
-            const size_t att_lds = (size_t)Lp * 128 + (size_t)64 * (Lp + 8) * 2 + (size_t)Lp * 4;
+            // (the persistent bulk GEMM -- cfg 9, 16-bit -- left q | k | v row-major in [M, 2304] starting at `qk`: the V^T region behind it is
+            //  part of that buffer then; every other configuration keeps q | k [M, 1536] + V^T)
+            const bool vrow = (cfg == 9);
+            const size_t att_lds = vrow ? (size_t)Lp * 128 + (size_t)Lp * 144 + (size_t)Lp * 4
+                                        : (size_t)Lp * 128 + (size_t)64 * (Lp + 8) * 2 + (size_t)Lp * 4;
             auto att = [&](auto kern) {
                 (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 hipLaunchKernelGGL(kern, dim3((unsigned)n * NHEAD), dim3(256), att_lds, stream, qk, vt, cu, LpS, ctx);
             };
-            if (Lp <= 128) att(attention_kernel<T, 8>);
+            if (vrow) {
+                if (Lp <= 128) att(attention_kernel<T, 8, true>);
+                else if (Lp <= 256) att(attention_kernel<T, 16, true>);
+                else att(attention_kernel<T, 32, true>);
+            } else if (Lp <= 128) att(attention_kernel<T, 8>);
             else if (Lp <= 256) att(attention_kernel<T, 16>);
             else att(attention_kernel<T, 32>);
         }

@@ -179,7 +179,7 @@ def test_product_library_carries_no_tuning_only_kernels(so):
 
     names = subprocess.run(["nm", "-C", so], capture_output=True, text=True, check=True).stdout
     stubs = [ln.split("__device_stub__", 1)[1] for ln in names.splitlines() if "__device_stub__" in ln]
-    assert 40 <= len(stubs) <= 80, len(stubs)
+    assert 40 <= len(stubs) <= 90, len(stubs)             # (round 5: 82 -- six row-major-V attention instantiations in, the two V^T-epilogue GEMMs out)
     banned = ("gemm_co_kernel", "gemm_wr_kernel", "atlas_spin_kernel", "gemm_pp_kernel<F16", "gemm_pp_kernel<BF16", ", 256, 256, 2, 4>", ", 64, 64, 2, 2>",
               "scan_kernel<8,", "scan_kernel<12,", "scan_kernel<16, 2,")
     bad = [s for s in stubs if any(b in s for b in banned)]

@@ -209,11 +209,11 @@ def test_bulk_gemm_kernels_agree_bit_for_bit(dtype, gpu_index_cls, monkeypatch):
     ids_f, mask_f = ids_f.cuda(), mask_f.cuda()
     base_f = mine(ids_f, mask_f)
     try:
-        for cfg in (9, 4, 6, 7, 8, 2, 0, 3):
+        for cfg in (9, 10, 4, 6, 7, 8, 2, 0, 3):            # (10 = rounds 3-4's persistent GEMM with the two-launch QKV and the V^T epilogue)
             T.atlas_tune_set_gemm_cfg(cfg)
             assert torch.equal(mine(ids, mask), base), f"cfg {cfg} differs from the product library's default configuration"
             assert torch.equal(mine(ids, mask), base), f"cfg {cfg}: second run differs"
-            if cfg in (9, 4, 0):
+            if cfg in (9, 10, 4, 0):
                 assert torch.equal(mine(ids_f, mask_f), base_f), f"cfg {cfg} differs on the full-length batch"
     finally:
         T.atlas_tune_set_gemm_cfg(-1)
@@ -335,3 +335,40 @@ def test_retrieval_level_agreement_of_refreshed_slabs(gpu_index_cls):
     assert emb_err <= 2e-3
     assert top1 >= 0.95 and abs(src_top1[0] - src_top1[1]) <= 0.05
     assert overlap.mean() >= 0.95 and float(np.mean(ulps <= 2)) >= 0.99            # (measured: 0.987 mean, 0.95 minimum, every common id within 1 ulp)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n,L", [(70, 256), (36, 512), (200, 96)])
+def test_row_major_v_attention_agrees_with_the_transposed_path_at_every_length(n, L, dtype, gpu_index_cls):
+    """round 5: in the 16-bit bulk configuration (cfg 9) the QKV projection is ONE GEMM launch that leaves V row-major, and attention_kernel<.., VROW>
+    takes the P.V operand out of a row-major LDS tile with gfx950's transposing read (ds_read_b64_tr_b16). Same values in the same registers as the
+    V^T path (cfg 10, tuning build: two launches, V^T epilogue) and as the launch-per-tile kernels (cfg 4): bit-identical embeddings, for passages of
+    up to 128 / 256 / 512 tokens (the three compiled key-fragment bounds), ragged and full-length, and against the torch restatement."""
+    from atlas_amd import _lib, retrievers
+    from oracle.contriever_ref import BertConfigLite, ContrieverRef
+
+    ref = ContrieverRef(BertConfigLite(num_hidden_layers=2), seed=18).randomize_affine().to(dtype).eval()
+    mine = retrievers.Contriever(retrievers.BertConfigLite(num_hidden_layers=2))
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine = mine.to(dtype).eval().cuda().requires_grad_(False)
+    T = _lib.lib(tuning=True)
+    mine._library = T
+    try:
+        for full in (False, True):
+            ids, mask = _batch(n, L, seed=n + L)
+            if full:
+                mask = torch.ones_like(mask)
+            ids, mask = ids.cuda(), mask.cuda()
+            outs = {}
+            for cfg in (9, 10, 4):
+                T.atlas_tune_set_gemm_cfg(cfg)
+                outs[cfg] = mine(ids, mask)
+                assert torch.equal(mine(ids, mask), outs[cfg]), f"cfg {cfg}: second run differs"
+            assert torch.equal(outs[9], outs[10]) and torch.equal(outs[9], outs[4]), (n, L, full)
+            if not full:
+                want = ref.cuda()(ids, mask).float().cpu()
+                err = (outs[9].float().cpu() - want).abs().max() / want.abs().max()
+                assert err <= (2e-3 if dtype == torch.float16 else 1.2e-2), float(err)
+    finally:
+        T.atlas_tune_set_gemm_cfg(-1)
+        mine._library = None

@@ -40,7 +40,7 @@ def _scratch_bytes(body):
 
 def test_persistent_gemm_has_no_scratch_and_a_clean_loop():
     fns = {k: v for k, v in _functions(_asm("encoder")).items() if "gemm_pt_kernel" in k}
-    assert len(fns) == 8, sorted(fns)                        # fp16 / bf16 x EPI 1, 2, 3, 4
+    assert len(fns) == 6, sorted(fns)                        # fp16 / bf16 x EPI 1, 2, 3 (EPI 4, the V^T epilogue of rounds 3-4, lives on in the tuning build: cfg 10)
     for name, body in fns.items():
         assert _scratch_bytes(body) == 0, f"{name} spills {_scratch_bytes(body)} bytes"
         assert "scratch_" not in body, name
