@@ -73,8 +73,8 @@ PY
 enc_pmc)
   (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $R/$OUT/enc -o pmc -- python $R/tools/enc_pmc_run.py 2 > $R/$OUT/enc_pmc.log 2>&1); say "encoder pmc rc=$?"
   python tools/pmc_mfma_summarize.py $OUT/enc | tee $OUT/mfma_util_encoder.txt | tee -a $OUT/summary.log; rm -rf $OUT/enc
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/$OUT/gdiag -o t -- python $R/tools/gemm_diag.py 9:0 > $R/$OUT/gemm_diag.log 2>&1); say "gemm_diag rc=$?"
-  python tools/gemm_layer_report.py $(find $OUT/gdiag -name "*kernel_trace.csv" | head -1) 9:0 | tee $OUT/gemm_layer_report.txt | tee -a $OUT/summary.log; rm -rf $OUT/gdiag ;;
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/$OUT/gdiag -o t -- python $R/tools/gemm_diag.py 9:0 10:0 > $R/$OUT/gemm_diag.log 2>&1); say "gemm_diag rc=$?"
+  python tools/gemm_layer_report.py $(find $OUT/gdiag -name "*kernel_trace.csv" | head -1) 9:0 10:0 | tee $OUT/gemm_layer_report.txt | tee -a $OUT/summary.log; rm -rf $OUT/gdiag ;;
 host)
   timeout 600 python tools/host_overhead.py 1000000 4000000 > $OUT/host_overhead.txt 2>&1; say "host rc=$?"; grep "^N=" $OUT/host_overhead.txt | tee -a $OUT/summary.log ;;
 refatlas)

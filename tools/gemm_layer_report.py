@@ -10,7 +10,9 @@ assert len(starts) == 4 * len(modes), (len(starts), modes)
 for mi, md in enumerate(modes):
     seg = ev[starts[4 * mi + 1]: starts[4 * mi + 4] if 4 * mi + 4 < len(starts) else len(ev)]     # passes 2-4
     g = [(n, d) for n, d in seg if "gemm_" in n]
-    per_layer = 5 if any("gemm_pt" in n for n, _ in g) else 4
+    # the persistent kernel of rounds 3-4 (and tuning cfg 10) launched the QKV projection twice (q|k, then V with the V^T epilogue: an EPI 4 kernel
+    # in the trace); round 5's cfg 9 launches it once
+    per_layer = 5 if any("gemm_pt" in n and ", 4>" in n for n, _ in g) else 4
     names = ["q|k", "V", "out-proj", "FFN-1", "FFN-2"] if per_layer == 5 else ["QKV", "out-proj", "FFN-1", "FFN-2"]
     med = [st.median([d for _, d in g[j::per_layer]]) for j in range(per_layer)]
     oth = {}
