@@ -277,3 +277,16 @@ def test_the_rounds_lines_final_code(name):
     assert d["shard_sweep"]["4000000"]["step_frac"] >= 0.715 and d["shard_sweep"]["1000000"]["step_frac"] >= 0.64
     assert d["refresh"]["roofline"]["frac"] >= 0.335 and d["refresh"]["streamed"]["value"] >= 34000
     assert d["detail"]["parity_checked"] == {"rows": 32000000, "queries_exact": 8, "queries_oracle": 1}
+
+
+def test_final_code_line_and_full_shard_refresh_with_the_one_launch_qkv():
+    """session L: the round's final code (the encoder's QKV projection as one launch, V transposed by the attention kernel's LDS reads) on the slowest box of
+    the round, smoke + `pytest -m gpu` 132 passed in the same session; the streamed refresh legs are faster than any V^T session's in spite of the box"""
+    d = _line("r05/bench_default_32m_sessionL.json")
+    r = d["roofline"]
+    assert r["traffic"] is not None and r["frac"] >= 0.75 and r["certifying_frac"] >= 0.71
+    old = max(_line(n)["refresh"]["streamed"]["value"] for n in R05_LINES)
+    assert d["refresh"]["streamed"]["value"] > old and d["refresh"]["streamed"]["value"] >= 36000
+    assert d["refresh"]["ragged"]["value"] >= 34000
+    f = _line("r05/bench_refresh_full_shard_4m.json")["refresh"]["full_shard"]
+    assert f["passages"] == 4_000_000 and f["value"] >= 35000 and f["rows_checked_against_position_loop"] == 4096
