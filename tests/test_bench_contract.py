@@ -290,3 +290,19 @@ def test_final_code_line_and_full_shard_refresh_with_the_one_launch_qkv():
     assert d["refresh"]["ragged"]["value"] >= 34000
     f = _line("r05/bench_refresh_full_shard_4m.json")["refresh"]["full_shard"]
     assert f["passages"] == 4_000_000 and f["value"] >= 35000 and f["rows_checked_against_position_loop"] == 4096
+
+
+def test_the_rounds_line_session_m():
+    """THE line of round 5 (final code, typical box; smoke + `pytest -m gpu` 132 passed in the same session): refresh at 0.357 of the MFMA peak with the
+    one-launch QKV, streamed refresh above 37k passages/s, the search side as in sessions D / E"""
+    d = _line("r05/bench_default_32m_sessionM.json")
+    r = d["roofline"]
+    assert r["traffic"] is not None and 1.0 <= r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.05
+    assert r["frac"] >= 0.775 and r["certifying_frac"] >= 0.745 and d["value"] >= 8000
+    assert d["refresh"]["roofline"]["frac"] >= 0.355 and d["refresh"]["ms_per_batch"] <= 12.9
+    assert d["refresh"]["streamed"]["value"] >= 37000 and d["refresh"]["ragged"]["value"] >= 35000
+    se = d["scale_emulated"]["per_w"]
+    assert se["8"]["step_frac"] >= 0.72 and se["8"]["efficiency_vs_1"] >= 0.93
+    bs = d["batch_sweep"]
+    assert bs["512"]["frac_of_mfma_peak"] >= 0.47 and bs["1024"]["frac_of_mfma_peak"] >= 0.50 and bs["256"]["ms_per_step"] <= 1.52
+    assert bs["128"]["certifying_ms_per_step"] / bs["128"]["ms_per_step"] <= 1.05
