@@ -211,6 +211,41 @@ __device__ __forceinline__ gelu_f2 gelu_erf_poly2(const gelu_f2 v) {
     const gelu_f2 relu = {__builtin_fmaxf(v.x, 0.0f), __builtin_fmaxf(v.y, 0.0f)};
     return relu - habs;
 }
+// The same function on FOUR pairs at once, breadth first: every step of the four independent chains is issued before the next step of any of
+// them (scheduling barriers keep hipcc from going depth first). Written pair by pair, hipcc emitted each pair's Horner scheme as seven
+// back-to-back DEPENDENT v_pk_fma_f32 on one register pair -- an instruction-level parallelism of one in the epilogue of the largest GEMM of a
+// layer (FFN-1: 64 pairs per wave and tile). Same operations in the same order per element: bit-identical to gelu_erf_poly2 / gelu_erf_poly.
+__device__ __forceinline__ void gelu_erf_poly2x4(const gelu_f2 (&v)[4], gelu_f2 (&out)[4]) {
+    gelu_f2 z[4], p[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        z[i] = (gelu_f2){fabsf(v[i].x) * 0.70710678118654752f, fabsf(v[i].y) * 0.70710678118654752f};
+        p[i] = __builtin_elementwise_fma((gelu_f2){-4.536094274953939e-05f, -4.536094274953939e-05f}, z[i], (gelu_f2){0.0004455238813534379f, 0.0004455238813534379f});
+    }
+    constexpr float c[6] = {-0.0014894854975864291f, -0.0007745709153823555f, 0.028253639116883278f, -0.1484816074371338f, -0.9184163808822632f,
+                            -1.6279085874557495f};
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = __builtin_elementwise_fma(p[i], z[i], (gelu_f2){c[s], c[s]});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    gelu_f2 e[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        p[i] = p[i] * z[i];
+        e[i] = (gelu_f2){__builtin_amdgcn_exp2f(p[i].x), __builtin_amdgcn_exp2f(p[i].y)};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const gelu_f2 a = {0.5f * fabsf(v[i].x), 0.5f * fabsf(v[i].y)};
+        const gelu_f2 habs = a * e[i];
+        const gelu_f2 relu = {__builtin_fmaxf(v[i].x, 0.0f), __builtin_fmaxf(v[i].y, 0.0f)};
+        out[i] = relu - habs;
+    }
+}
 #endif
 
 }  // namespace atlas

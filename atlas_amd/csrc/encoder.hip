@@ -924,16 +924,26 @@ static __device__ __forceinline__ void pt_epilogue(const f4 (&acc)[8][4], unsign
                 const uint32_t bw[4] = {bq4[j][0], bq4[j][1], bq4[j][2], bq4[j][3]};
                 uint4 o;
                 uint32_t* ow = (uint32_t*)&o;
+                if constexpr (EPI == 1) {
+                    // erf GELU in fp32 on the Linear output in the model dtype (common.h), the lane's four pairs breadth first (gelu_erf_poly2x4)
+                    gelu_f2 vin[4], g[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {                           // columns 2 e, 2 e + 1 of the lane's eight
-                    const f4 s = acc[2 * j + (e >> 1)][b];
-                    float v0 = ((e & 1) ? s[2] : s[0]) + T::ld((uint16_t)(bw[e] & 0xffff));
-                    float v1 = ((e & 1) ? s[3] : s[1]) + T::ld((uint16_t)(bw[e] >> 16));
-                    if (EPI == 1) {                                     // erf GELU in fp32 on the Linear output in the model dtype (common.h)
-                        const gelu_f2 g = gelu_erf_poly2((gelu_f2){T::rnd(v0), T::rnd(v1)});
-                        v0 = g.x; v1 = g.y;
+                    for (int e = 0; e < 4; ++e) {
+                        const f4 s = acc[2 * j + (e >> 1)][b];
+                        vin[e] = (gelu_f2){T::rnd(((e & 1) ? s[2] : s[0]) + T::ld((uint16_t)(bw[e] & 0xffff))),
+                                           T::rnd(((e & 1) ? s[3] : s[1]) + T::ld((uint16_t)(bw[e] >> 16)))};
                     }
-                    ow[e] = pack2<T>(v0, v1);
+                    gelu_erf_poly2x4(vin, g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ow[e] = pack2<T>(g[e].x, g[e].y);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {                       // columns 2 e, 2 e + 1 of the lane's eight
+                        const f4 s = acc[2 * j + (e >> 1)][b];
+                        const float v0 = ((e & 1) ? s[2] : s[0]) + T::ld((uint16_t)(bw[e] & 0xffff));
+                        const float v1 = ((e & 1) ? s[3] : s[1]) + T::ld((uint16_t)(bw[e] >> 16));
+                        ow[e] = pack2<T>(v0, v1);
+                    }
                 }
                 *(uint4*)(s_tr + lr * 256 + (((4 * j + lg) ^ lr) * 16)) = o;
             }

@@ -253,21 +253,23 @@ gscan_kernel(const GScanParams p) {
             // by one: ~230 instructions, 1 200 cycles per tile and wave.) A lane OWNS its query columns: th[b] is per-lane.
             uint32_t colhit = 0;
             GS_ESTAMP(0);
+            // (round 5: the FB column chains step by step, BREADTH first -- written column by column hipcc emitted each column's 16 v_max3 as one
+            //  dependent chain, an instruction-level parallelism of one; scheduling barriers keep the step order)
+            float m[FB];
+            auto el = [&](const int b, const int i) __attribute__((always_inline)) -> float { return acc[i >> 2][b][i & 3]; };     // element i = 0..31 of column b
+#pragma unroll
+            for (int b = 0; b < FB; ++b) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m[b]) : "v"(el(b, 0)), "v"(el(b, 1)), "v"(el(b, 2)));      // (fmaxf: two canonicalising v_max more)
+#pragma unroll
+            for (int s = 1; s < 15; ++s) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int b = 0; b < FB; ++b) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m[b]) : "v"(m[b]), "v"(el(b, 2 * s + 1)), "v"(el(b, 2 * s + 2)));
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int b = 0; b < FB; ++b) {
-                float m;
-                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(acc[0][b][0]), "v"(acc[0][b][1]), "v"(acc[0][b][2]));      // (fmaxf: two canonicalising v_max more)
-                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(acc[0][b][3]), "v"(acc[1][b][0]));
-                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(acc[1][b][1]), "v"(acc[1][b][2]));
-#pragma unroll
-                for (int a = 2; a < 8; a += 2) {
-                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(acc[a - 1][b][3]), "v"(acc[a][b][0]));
-                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(acc[a][b][1]), "v"(acc[a][b][2]));
-                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(acc[a][b][3]), "v"(acc[a + 1][b][0]));
-                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(acc[a + 1][b][1]), "v"(acc[a + 1][b][2]));
-                }
-                m = fmaxf(m, acc[7][b][3]);
-                colhit |= (__builtin_amdgcn_ballot_w64(m > th[b]) != 0ull ? 1u : 0u) << b;
+                m[b] = fmaxf(m[b], el(b, 31));
+                colhit |= (__builtin_amdgcn_ballot_w64(m[b] > th[b]) != 0ull ? 1u : 0u) << b;
             }
             GS_ESTAMP(1);
             if (colhit != 0u) {
