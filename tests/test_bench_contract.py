@@ -306,3 +306,15 @@ def test_the_rounds_line_session_m():
     bs = d["batch_sweep"]
     assert bs["512"]["frac_of_mfma_peak"] >= 0.47 and bs["1024"]["frac_of_mfma_peak"] >= 0.50 and bs["256"]["ms_per_step"] <= 1.52
     assert bs["128"]["certifying_ms_per_step"] / bs["128"]["ms_per_step"] <= 1.05
+
+
+def test_the_rounds_line_session_p_final_code():
+    """session P: session M's code + the two breadth-first micro-changes = the round's final code; smoke + `pytest -m gpu` 132 passed in the same session"""
+    d = _line("r05/bench_default_32m_sessionP.json")
+    r = d["roofline"]
+    assert r["traffic"] is not None and 1.0 <= r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.05
+    assert r["frac"] >= 0.775 and r["certifying_frac"] >= 0.74 and d["value"] >= 8000
+    assert d["refresh"]["roofline"]["frac"] >= 0.35 and d["refresh"]["streamed"]["value"] >= 37000
+    assert d["scale_emulated"]["per_w"]["8"]["step_frac"] >= 0.715
+    bs = d["batch_sweep"]
+    assert bs["512"]["frac_of_mfma_peak"] >= 0.46 and bs["128"]["certifying_ms_per_step"] / bs["128"]["ms_per_step"] <= 1.05
