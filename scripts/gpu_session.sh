@@ -33,7 +33,7 @@ pytest:*)
 bench)
   timeout 1500 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; say "bench rc=$?"; cut -c1-1200 $OUT/bench_default.json | tee -a $OUT/summary.log ;;
 stats32m)
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof32 -o trace -- python $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --refresh-batches 0 --shard-sweep '' --batch-sweep '' > $R/$OUT/bench_32m_only_under_rocprof.json 2> $R/$OUT/prof32.err); say "stats32m rc=$?"
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof32 -o trace -- python $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --refresh-batches 0 --shard-sweep '' --batch-sweep '' --emulate-ranks '' > $R/$OUT/bench_32m_only_under_rocprof.json 2> $R/$OUT/prof32.err); say "stats32m rc=$?"
   f=$(find $OUT/prof32 -name "*kernel_stats*.csv" | head -1); cp $f $OUT/bench_32m_only_kernel_stats.csv; grep -i "scan_kernel\|merge_rescore\|slab_pmax\|Name" $OUT/bench_32m_only_kernel_stats.csv | cut -c1-260 | tee -a $OUT/summary.log; rm -rf $OUT/prof32 ;;
 stats)
   (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_default -o trace -- python $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --refresh-stream-seconds 3 > $R/$OUT/bench_under_rocprof.json 2> $R/$OUT/prof_default.err); say "stats rc=$?"
