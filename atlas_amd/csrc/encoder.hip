@@ -1007,7 +1007,7 @@ __global__ void __launch_bounds__(512)
 gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* __restrict__ W, const typename T::elem* __restrict__ bias,
                const typename T::elem* __restrict__ R, typename T::elem* __restrict__ C, typename T::elem* __restrict__ VT,
                const int* __restrict__ cu, int n, const int2* __restrict__ tokinfo, int N, int K, int Lp,
-               int diag /* tuning build only: bit 0 = no epilogue, bits 2-3 = store policy (1 nt, 2 sc1), bits 8.. = start stagger; 0 in production */,
+               int diag /* tuning build only: bit 0 = no epilogue, bits 2-3 = store policy (1 nt, 2 sc1), bit 4 / 5 = activation / weight loads aliased to the first tile, bits 8.. = start stagger; 0 in production */,
                unsigned long long* __restrict__ dbg /* tuning build only: 100 MHz stamps of workgroup 0 around its tile boundaries; null in production */) {
     typedef typename T::elem E;
     static_assert(sizeof(E) == 2, "16-bit dtypes only");
@@ -1083,8 +1083,16 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     auto stage = [&](auto grp_tag, const int buf, const int j, const int kt, auto&& between) __attribute__((always_inline)) {
         constexpr bool GB = decltype(grp_tag)::value;
         const uint32_t kb = (uint32_t)kt * 128u;
+#if ATLAS_TUNING
+        // experiment (results wrong, timing only): bit 4 = every tile loads the activations of the XCD's FIRST token tile, bit 5 = the weights of
+        // column tile 0 -- the same instruction stream with that operand always an L2 hit: what part of the k-tile period is the operand's way in?
+        const int ja = (diag & 16) ? (j % ncol) : j, jw = (diag & 32) ? (j - j % ncol) : j;
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)tile_n0(jw) * K), 0, (int)(256u * K2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ra = rows_rsrc(A, tile_m0(ja), K);
+#else
         const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)tile_n0(j) * K), 0, (int)(256u * K2), 0x00020000);
         const __amdgpu_buffer_rsrc_t ra = rows_rsrc(A, tile_m0(j), K);
+#endif
         unsigned char* const lw = smem_raw + buf * STG + (we * 32) * 128;
         unsigned char* const la = smem_raw + 2 * STG + buf * STG + (wa * 32) * 128;
         pt_static_for<0, 8>([&](auto ic) __attribute__((always_inline)) {

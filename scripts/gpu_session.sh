@@ -12,9 +12,11 @@
 #   gscan_ab       tools/batch_gemm_ab.py at 4M and 32M rows (streaming passes vs GEMM-shaped passes, same process)
 #   gscan_prof     per-kernel durations + MFMA-busy + FETCH_SIZE counters of the GEMM-shaped pass (4M rows x 512 / 256 queries), phase stamps
 #   enc_pmc        MFMA-busy PMC passes of the refresh encoder (two layers) + per-layer GEMM report
+#   gemm_alias     per-layer GEMM times with diag bits: 1 = no epilogue, 16 / 32 = activation / weight loads aliased to the first tile (always L2 hits)
 #   host           tools/host_overhead.py 1M 4M
 #   refatlas       tests/test_gpu_reference_atlas.py (needs .refstage/: scripts/stage_reference.sh in the build container)
 #   gloo2          two ranks on one GPU over gloo: bench.py --gpus 2 logic check, replicated and --distinct-queries
+#   encpower       tools/refresh_power.py random zero random zero: the refresh batch with all-zero operands (same instructions, no toggling) beside the real one
 #   fullshard      BASELINE configs[3]'s per-GPU share: bench.py --refresh-full-shard 4000000 (one streamed refresh of 4M ragged passages, ~2 min), the
 #                  other legs cut short
 TAG=$1; shift
@@ -75,6 +77,10 @@ enc_pmc)
   python tools/pmc_mfma_summarize.py $OUT/enc | tee $OUT/mfma_util_encoder.txt | tee -a $OUT/summary.log; rm -rf $OUT/enc
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/$OUT/gdiag -o t -- python $R/tools/gemm_diag.py 9:0 10:0 > $R/$OUT/gemm_diag.log 2>&1); say "gemm_diag rc=$?"
   python tools/gemm_layer_report.py $(find $OUT/gdiag -name "*kernel_trace.csv" | head -1) 9:0 10:0 | tee $OUT/gemm_layer_report.txt | tee -a $OUT/summary.log; rm -rf $OUT/gdiag ;;
+gemm_alias)
+  M="9:0 9:1 9:17 9:33 9:49 9:16 9:32"
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/$OUT/galias -o t -- python $R/tools/gemm_diag.py $M > $R/$OUT/gemm_alias.log 2>&1); say "gemm_alias rc=$?"
+  python tools/gemm_layer_report.py $(find $OUT/galias -name "*kernel_trace.csv" | head -1) $M | tee $OUT/gemm_alias_report.txt | tee -a $OUT/summary.log; rm -rf $OUT/galias ;;
 host)
   timeout 600 python tools/host_overhead.py 1000000 4000000 > $OUT/host_overhead.txt 2>&1; say "host rc=$?"; grep "^N=" $OUT/host_overhead.txt | tee -a $OUT/summary.log ;;
 refatlas)
@@ -85,6 +91,8 @@ gloo2)
     ATLAS_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --passages 2000003 --refresh-batches 0 --cpu-seconds 0 $extra > $OUT/bench_w2_gloo$extra.json 2> $OUT/bench_w2_gloo$extra.err; say "gloo2 $extra rc=$?"
     grep "^{" $OUT/bench_w2_gloo$extra.json | cut -c1-900 | tee -a $OUT/summary.log
   done ;;
+encpower)
+  timeout 300 python tools/refresh_power.py random zero random zero > $OUT/refresh_power_data.txt 2>&1; say "encpower rc=$?"; cat $OUT/refresh_power_data.txt | tee -a $OUT/summary.log ;;
 fullshard)
   timeout 1500 python bench.py --passages 8000000 --steps 5 --warmup 2 --cpu-seconds 0 --shard-sweep '' --batch-sweep '' --emulate-ranks '' --refresh-batches 10 --refresh-stream-seconds 5 --refresh-full-shard 4000000 > $OUT/bench_refresh_full_shard.json 2> $OUT/bench_refresh_full_shard.err; say "fullshard rc=$?"
   python - <<PY | tee -a $OUT/summary.log
