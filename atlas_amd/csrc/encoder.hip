@@ -1007,15 +1007,19 @@ __global__ void __launch_bounds__(512)
 gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* __restrict__ W, const typename T::elem* __restrict__ bias,
                const typename T::elem* __restrict__ R, typename T::elem* __restrict__ C, typename T::elem* __restrict__ VT,
                const int* __restrict__ cu, int n, const int2* __restrict__ tokinfo, int N, int K, int Lp,
-               int diag /* tuning build only: bit 0 = no epilogue, bits 2-3 = store policy (1 nt, 2 sc1), bit 4 / 5 = activation / weight loads aliased to the first tile, bits 8.. = start stagger; 0 in production */,
+               int diag /* tuning build only: bit 0 = no epilogue, bits 2-3 = store policy (1 nt, 2 sc1), bit 4 / 5 = activation / weight loads aliased to the first tile, bit 6 = no MFMAs, bit 7 = no LDS-DMA pieces, bits 8.. = start stagger; 0 in production */,
                unsigned long long* __restrict__ dbg /* tuning build only: 100 MHz stamps of workgroup 0 around its tile boundaries; null in production */) {
     typedef typename T::elem E;
     static_assert(sizeof(E) == 2, "16-bit dtypes only");
 #if ATLAS_TUNING
+    // (bit 0 of the pointer: only the two stamps at the ends of workgroup 0 -- both clocks over an UNPERTURBED kernel: every other stamp is a
+    //  store in the counted vmcnt stream)
+    const bool ends_only = ((uintptr_t)dbg & 1) != 0;
+    unsigned long long* const dbgp = (unsigned long long*)((uintptr_t)dbg & ~(uintptr_t)1);
     int tstamp = 0;                                                  // tile counter of the stamps
-#define PT_STAMP(i) do { if (dbg != nullptr && blockIdx.x == 0 && tstamp < 8 && pt_fresh_lane() == 0) dbg[((int)wave * 8 + tstamp) * 16 + (i)] = wall_clock64(); } while (0)
+#define PT_STAMP(i) do { if (dbgp != nullptr && !ends_only && blockIdx.x == 0 && tstamp < 8 && pt_fresh_lane() == 0) dbgp[((int)wave * 8 + tstamp) * 16 + (i)] = wall_clock64(); } while (0)
     int itc = 0;                                                     // iteration counter of the per-iteration stamps: shader cycles, iterations 24 .. 55
-#define PT_ISTAMP(i) do { if (dbg != nullptr && blockIdx.x == 0 && itc >= 24 && itc < 56 && pt_fresh_lane() == 0) dbg[2048 + ((int)wave * 32 + itc - 24) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define PT_ISTAMP(i) do { if (dbgp != nullptr && !ends_only && blockIdx.x == 0 && itc >= 24 && itc < 56 && pt_fresh_lane() == 0) dbgp[2048 + ((int)wave * 32 + itc - 24) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define PT_STAMP(i) do { } while (0)
 #define PT_ISTAMP(i) do { } while (0)
@@ -1037,7 +1041,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     if (slot >= njobs) return;
 #if ATLAS_TUNING
     // (both clocks at the two ends of workgroup 0: what the shader clock is under this kernel's load)
-    if (dbg != nullptr && blockIdx.x == 0 && tid == 0) { dbg[1024] = wall_clock64(); dbg[1025] = __builtin_readcyclecounter(); }
+    if (dbgp != nullptr && blockIdx.x == 0 && tid == 0) { dbgp[1024] = wall_clock64(); dbgp[1025] = __builtin_readcyclecounter(); }
 #endif
     const int nk = K >> 6;                                                    // k-tiles of 128 bytes per tile (>= 2)
     const uint32_t K2 = (uint32_t)K * 2u;
@@ -1203,6 +1207,9 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         bool stages; int sj, skt;
         if (!grpB) { stages = !LAST || has_next; sj = LAST ? jc + nslots : jc; skt = LAST ? 0 : kt + 1; }
         else { stages = !b_first && (kt + 2 < nk || has_next); sj = kt + 2 < nk ? jc : jc + nslots; skt = kt + 2 < nk ? kt + 2 : kt + 2 - nk; }
+#if ATLAS_TUNING
+        if (diag & 128) stages = false;                // experiment (timing only): no LDS-DMA pieces after the prologue's -- fragment reads, barriers and MFMAs alone
+#endif
         // (every fragment register is an in/out operand of the phase's last wait: nothing reads one in front of it; the reads are single
         //  asm statements so that they can sit between the pieces, and the registers they fill asynchronously must not be copied or spilled:
         //  tests/test_kernel_isa.py)
@@ -1277,6 +1284,9 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         if (kt == 0) PT_STAMP(9);
         if (LAST) PT_STAMP(2);
         PT_ISTAMP(3);
+#if ATLAS_TUNING
+        if (!(diag & 128))
+#endif
         if (b_first && (kt + 2 < nk || has_next)) stage(std::true_type{}, buf, sj, skt, nothing);      // once per tile: in front of the MFMAs
         if constexpr (VTR) {                           // activations as the MFMA A operand: C^T fragments, the same products in the same order
 #pragma unroll
@@ -1288,8 +1298,13 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 #pragma unroll
                 for (int b = 0; b < FB; ++b) acc[a][b] = T::mma(fa1[b], fw1[a], acc[a][b]);
         } else {
+#if ATLAS_TUNING
+            if (!(diag & 64))                          // experiment (timing only): no MFMAs -- what the feed side (pieces, fragment reads, barriers) takes alone
+#endif
+            {
             mma_tile<T, FA, FB>(fw0, fa0, acc);
             mma_tile<T, FA, FB>(fw1, fa1, acc);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (kt == 0) PT_STAMP(10);
@@ -1378,7 +1393,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         if (jc >= njobs) break;
     }
 #if ATLAS_TUNING
-    if (dbg != nullptr && blockIdx.x == 0 && tid == 0) { dbg[1026] = wall_clock64(); dbg[1027] = __builtin_readcyclecounter(); }
+    if (dbgp != nullptr && blockIdx.x == 0 && tid == 0) { dbgp[1026] = wall_clock64(); dbgp[1027] = __builtin_readcyclecounter(); }
 #endif
 #undef PT_STAMP
 #undef PT_ISTAMP

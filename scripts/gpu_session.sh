@@ -13,6 +13,7 @@
 #   gscan_prof     per-kernel durations + MFMA-busy + FETCH_SIZE counters of the GEMM-shaped pass (4M rows x 512 / 256 queries), phase stamps
 #   enc_pmc        MFMA-busy PMC passes of the refresh encoder (two layers) + per-layer GEMM report
 #   gemm_alias     per-layer GEMM times with diag bits: 1 = no epilogue, 16 / 32 = activation / weight loads aliased to the first tile (always L2 hits)
+#   pt_cycles      tools/pt_cycles.py: shader cycles per k-tile of the refresh GEMM from end stamps only, per diag mode
 #   host           tools/host_overhead.py 1M 4M
 #   refatlas       tests/test_gpu_reference_atlas.py (needs .refstage/: scripts/stage_reference.sh in the build container)
 #   gloo2          two ranks on one GPU over gloo: bench.py --gpus 2 logic check, replicated and --distinct-queries
@@ -78,9 +79,11 @@ enc_pmc)
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/$OUT/gdiag -o t -- python $R/tools/gemm_diag.py 9:0 10:0 > $R/$OUT/gemm_diag.log 2>&1); say "gemm_diag rc=$?"
   python tools/gemm_layer_report.py $(find $OUT/gdiag -name "*kernel_trace.csv" | head -1) 9:0 10:0 | tee $OUT/gemm_layer_report.txt | tee -a $OUT/summary.log; rm -rf $OUT/gdiag ;;
 gemm_alias)
-  M="9:0 9:1 9:17 9:33 9:49 9:16 9:32"
+  M=${GEMM_ALIAS_MODES:-"9:0 9:1 9:17 9:33 9:49 9:16 9:32"}
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/$OUT/galias -o t -- python $R/tools/gemm_diag.py $M > $R/$OUT/gemm_alias.log 2>&1); say "gemm_alias rc=$?"
   python tools/gemm_layer_report.py $(find $OUT/galias -name "*kernel_trace.csv" | head -1) $M | tee $OUT/gemm_alias_report.txt | tee -a $OUT/summary.log; rm -rf $OUT/galias ;;
+pt_cycles)
+  timeout 300 python tools/pt_cycles.py ${PT_CYCLES_MODES:-0,1,65,129,193,49} > $OUT/pt_cycles.txt 2>&1; say "pt_cycles rc=$?"; cat $OUT/pt_cycles.txt | tee -a $OUT/summary.log ;;
 host)
   timeout 600 python tools/host_overhead.py 1000000 4000000 > $OUT/host_overhead.txt 2>&1; say "host rc=$?"; grep "^N=" $OUT/host_overhead.txt | tee -a $OUT/summary.log ;;
 refatlas)
