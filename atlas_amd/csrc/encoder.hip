@@ -44,6 +44,13 @@
 #include "common.h"
 #include "../../include/atlas_hip.h"
 
+#ifndef ATLAS_PT_WDEFER
+#define ATLAS_PT_WDEFER 0            // gemm_pt_kernel experiment (measured slower, see its `stage`): W pieces per wave and k-tile issued between the wave's own MFMAs
+#endif
+#ifndef ATLAS_PT_WSTRIDE
+#define ATLAS_PT_WSTRIDE 1           // ... one in front of every ATLAS_PT_WSTRIDE-th chunk of eight MFMAs
+#endif
+
 using namespace atlas;
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -1084,8 +1091,16 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     // this wave's pieces of k-tile kt of tile j -> stage buffer buf; `between(i)` runs behind piece i. Group A: its activation pieces first (read
     // a phase and a half on: `vmcnt(4)` at the end of its multiply phase covers them), group B: its W pieces first (its activation pieces
     // overwrite rows it reads in this very phase: they go out behind those reads)
-    auto stage = [&](auto grp_tag, const int buf, const int j, const int kt, auto&& between) __attribute__((always_inline)) {
+    // `mask_tag`: which of the eight pieces go out (bit p8; `between` runs for every slot either way). All of them in the product: ATLAS_PT_WDEFER
+    // (round 5 experiment, default 0) takes the last WD of a wave's four W pieces out of its read phase and issues them BETWEEN ITS OWN MFMAs.
+    // Why it was tried: a wave alone gets a ds_read_b128 through every ~30 cycles (tools/lds_read_probe.hip: 4 waves x 24 reads = 720 cycles,
+    // whatever the other group does), every piece lengthens the read phase further, and tools/pt_cycles.py puts the k-tile at ~3 200 cycles
+    // against 2 048 of MFMA issue -- the read phase, not the multiply phase, is the half period. What came out (same-process A/B of the builds,
+    // bit-identical outputs, profiles/r05/enc_wdefer_ab.txt): 13.13 ms -> 13.63 (WD 4) / 13.75 (WD 2, 3) per 512 x 128 batch. A piece issued
+    // by the multiplying wave stalls its MFMA issue for longer than the same piece costs a reading wave (round 4 found the same from the other side).
+    auto stage = [&](auto grp_tag, auto mask_tag, const int buf, const int j, const int kt, auto&& between) __attribute__((always_inline)) {
         constexpr bool GB = decltype(grp_tag)::value;
+        constexpr int MASK = decltype(mask_tag)::value;
         const uint32_t kb = (uint32_t)kt * 128u;
 #if ATLAS_TUNING
         // experiment (results wrong, timing only): bit 4 = every tile loads the activations of the XCD's FIRST token tile, bit 5 = the weights of
@@ -1103,7 +1118,8 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
             constexpr int p8 = decltype(ic)::value;
             constexpr bool isw = GB ? (p8 < 4) : (p8 >= 4);
             constexpr int i = p8 & 3;
-            if constexpr (isw) {
+            if constexpr (((MASK >> p8) & 1) == 0) {
+            } else if constexpr (isw) {
                 constexpr uint32_t rw_ = (uint32_t)(VTR ? 8 * i : 16 * (i & 1) + 4 * (i >> 1));
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(lw + i * 8 * 128), 16, (int)vw, (int)(rw_ * K2 + kb), 0, 0);
             } else {
@@ -1116,6 +1132,18 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         });
     };
     auto nothing = [](auto) __attribute__((always_inline)) {};
+    constexpr int WD = VTR ? 0 : ATLAS_PT_WDEFER;                       // W pieces per wave and k-tile issued from the MFMA phase (0 .. 4; the V^T kernel of tuning cfg 10 keeps the old order)
+    static_assert(WD >= 0 && WD <= 4 && ATLAS_PT_WSTRIDE * (WD - 1) < 8, "ATLAS_PT_WDEFER / ATLAS_PT_WSTRIDE");
+    typedef std::integral_constant<int, 0xFF> all_pieces;
+    typedef std::integral_constant<int, 0xFF & ~(((1 << WD) - 1) << (8 - WD))> read_pieces_a;      // group A: W pieces are slots 4..7
+    typedef std::integral_constant<int, 0xFF & ~(((1 << WD) - 1) << (4 - WD))> read_pieces_b;      // group B: W pieces are slots 0..3
+    // W piece i (0..3) of k-tile kt of tile j -> stage buffer buf, by itself (the deferred ones, from the MFMA phase)
+    auto stage_w_deferred = [&](auto ic, const int buf, const int j, const int kt) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)tile_n0(j) * K), 0, (int)(256u * K2), 0x00020000);
+        constexpr uint32_t rw_ = (uint32_t)(VTR ? 8 * i : 16 * (i & 1) + 4 * (i >> 1));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem_raw + buf * STG + (we * 32) * 128 + i * 8 * 128), 16, (int)vw, (int)(rw_ * K2 + (uint32_t)kt * 128u), 0, 0);
+    };
 
     // LDS byte addresses of this lane's fragment chunks (fragment a / b adds a * 2048: rows 16 apart keep row & 7)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
@@ -1150,11 +1178,11 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
     }
 #endif
-    if (!grpB) stage(std::false_type{}, 0, jc, 0, nothing); else stage(std::true_type{}, 0, jc, 0, nothing);
+    if (!grpB) stage(std::false_type{}, all_pieces{}, 0, jc, 0, nothing); else stage(std::true_type{}, all_pieces{}, 0, jc, 0, nothing);
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's pieces of k-tile 0 have landed
     __builtin_amdgcn_s_barrier();
     if (grpB) {                                        // B's phase 0: nothing to multiply yet; its pieces of k-tile 1
-        stage(std::true_type{}, 1, jc, 1, nothing);
+        stage(std::true_type{}, all_pieces{}, 1, jc, 1, nothing);
         __builtin_amdgcn_s_barrier();
     }
     int buf = 0;
@@ -1219,7 +1247,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
               "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]), "+v"(fa1[0]), "+v"(fa1[1]), "+v"(fa1[2]), "+v"(fa1[3]) :: "memory")
         if (stages && !grpB) {
             __builtin_amdgcn_sched_barrier(0);
-            stage(std::false_type{}, buf ^ 1, sj, skt, [&](auto ic) __attribute__((always_inline)) {
+            stage(std::false_type{}, read_pieces_a{}, buf ^ 1, sj, skt, [&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
                 __builtin_amdgcn_sched_barrier(0);
                 pt_static_for<3 * i, 3 * i + 3>([&](auto kc) __attribute__((always_inline)) {
@@ -1241,7 +1269,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
                 pt_ds_read<b * 2048>(fa0[b], a0);
                 pt_ds_read<b * 2048>(fa1[b], a1);
             });
-            stage(std::true_type{}, buf, sj, skt, [&](auto ic) __attribute__((always_inline)) {
+            stage(std::true_type{}, read_pieces_b{}, buf, sj, skt, [&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (i < 4) { pt_ds_read<(2 * i) * 2048>(fw0[2 * i], w0); pt_ds_read<(2 * i + 1) * 2048>(fw0[2 * i + 1], w0); }
@@ -1273,7 +1301,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         // what must have LANDED before the barrier: the pieces issued before this phase (the W rows the other group reads next, group B's
         // activation rows) -- all but this phase's 8. A tile's first iteration: nothing is owed (both groups drained before the epilogue) and
         // the epilogue's stores are still in flight -- no wait
-        if (stages) { if (!(skip_b1 || skip_wait)) __builtin_amdgcn_s_waitcnt(0x0F70 | 8); }
+        if (stages) { if (!(skip_b1 || skip_wait)) __builtin_amdgcn_s_waitcnt(0x0F70 | (8 - WD)); }
         else if (!(skip_b1 || skip_wait)) __builtin_amdgcn_s_waitcnt(0x0F70);
         PT_ISTAMP(2);
         if (EPI == 2 && grpB && kt == nk - 3) touch_residual();
@@ -1287,7 +1315,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 #if ATLAS_TUNING
         if (!(diag & 128))
 #endif
-        if (b_first && (kt + 2 < nk || has_next)) stage(std::true_type{}, buf, sj, skt, nothing);      // once per tile: in front of the MFMAs
+        if (b_first && (kt + 2 < nk || has_next)) stage(std::true_type{}, all_pieces{}, buf, sj, skt, nothing);      // once per tile: in front of the MFMAs
         if constexpr (VTR) {                           // activations as the MFMA A operand: C^T fragments, the same products in the same order
 #pragma unroll
             for (int a = 0; a < FA; ++a)
@@ -1302,8 +1330,35 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
             if (!(diag & 64))                          // experiment (timing only): no MFMAs -- what the feed side (pieces, fragment reads, barriers) takes alone
 #endif
             {
-            mma_tile<T, FA, FB>(fw0, fa0, acc);
-            mma_tile<T, FA, FB>(fw1, fa1, acc);
+            if constexpr (WD == 0) {
+                mma_tile<T, FA, FB>(fw0, fa0, acc);
+                mma_tile<T, FA, FB>(fw1, fa1, acc);
+            } else {
+                // the 64 MFMAs in eight chunks of eight (two W fragments x four activation fragments; every accumulator still takes k-step 0
+                // before k-step 1: same bits); deferred W piece c goes out in front of chunk ATLAS_PT_WSTRIDE * c. ONE block of MFMAs, no
+                // branch (a second copy of the block for the iterations that stage nothing sent hipcc's register allocation into 600 B of
+                // scratch): in those iterations -- the last of the workgroup's last tile, group B's first of every tile -- the pieces are
+                // real loads of the same weight rows into the wave's own epilogue slot, which nothing reads before the vmcnt(0) in front of
+                // the epilogue. Descriptor and LDS base are formed once, in front of the first MFMA.
+                const __amdgpu_buffer_rsrc_t rwd = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)tile_n0(sj) * K), 0, (int)(256u * K2), 0x00020000);
+                unsigned char* const lwd = stages ? smem_raw + (grpB ? buf : buf ^ 1) * STG + (we * 32) * 128 : smem_raw + TR_OFF + wave * 4096;
+                const uint32_t kbd = (uint32_t)skt * 128u;
+                __builtin_amdgcn_sched_barrier(0);
+                pt_static_for<0, 8>([&](auto cc) __attribute__((always_inline)) {
+                    constexpr int c = decltype(cc)::value;
+                    if constexpr (c % ATLAS_PT_WSTRIDE == 0 && c / ATLAS_PT_WSTRIDE < WD) {
+                        constexpr int i = 4 - WD + c / ATLAS_PT_WSTRIDE;
+                        constexpr uint32_t rw_ = (uint32_t)(VTR ? 8 * i : 16 * (i & 1) + 4 * (i >> 1));
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rwd, (lds_ptr)(lwd + (i & 3) * 8 * 128), 16, (int)vw, (int)(rw_ * K2 + kbd), 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int a = 2 * (c & 3); a < 2 * (c & 3) + 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < FB; ++b) acc[a][b] = (c < 4) ? T::mma(fw0[a], fa0[b], acc[a][b]) : T::mma(fw1[a], fa1[b], acc[a][b]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
             }
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -14,6 +14,7 @@
 #   enc_pmc        MFMA-busy PMC passes of the refresh encoder (two layers) + per-layer GEMM report
 #   gemm_alias     per-layer GEMM times with diag bits: 1 = no epilogue, 16 / 32 = activation / weight loads aliased to the first tile (always L2 hits)
 #   pt_cycles      tools/pt_cycles.py: shader cycles per k-tile of the refresh GEMM from end stamps only, per diag mode
+#   ldsprobe       tools/lds_read_probe.hip: what a read phase (24 ds_read_b128 per wave, ping-pong, barriers) costs by itself
 #   host           tools/host_overhead.py 1M 4M
 #   refatlas       tests/test_gpu_reference_atlas.py (needs .refstage/: scripts/stage_reference.sh in the build container)
 #   gloo2          two ranks on one GPU over gloo: bench.py --gpus 2 logic check, replicated and --distinct-queries
@@ -84,6 +85,8 @@ gemm_alias)
   python tools/gemm_layer_report.py $(find $OUT/galias -name "*kernel_trace.csv" | head -1) $M | tee $OUT/gemm_alias_report.txt | tee -a $OUT/summary.log; rm -rf $OUT/galias ;;
 pt_cycles)
   timeout 300 python tools/pt_cycles.py ${PT_CYCLES_MODES:-0,1,65,129,193,49} > $OUT/pt_cycles.txt 2>&1; say "pt_cycles rc=$?"; cat $OUT/pt_cycles.txt | tee -a $OUT/summary.log ;;
+ldsprobe)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -w tools/lds_read_probe.hip -o /tmp/lds_read_probe && timeout 120 /tmp/lds_read_probe > $OUT/lds_read_probe.txt 2>&1; say "ldsprobe rc=$?"; cat $OUT/lds_read_probe.txt | tee -a $OUT/summary.log ;;
 host)
   timeout 600 python tools/host_overhead.py 1000000 4000000 > $OUT/host_overhead.txt 2>&1; say "host rc=$?"; grep "^N=" $OUT/host_overhead.txt | tee -a $OUT/summary.log ;;
 refatlas)
