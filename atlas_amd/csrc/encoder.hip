@@ -47,6 +47,9 @@
 #ifndef ATLAS_PT_WDEFER
 #define ATLAS_PT_WDEFER 0            // gemm_pt_kernel experiment (measured slower, see its `stage`): W pieces per wave and k-tile issued between the wave's own MFMAs
 #endif
+#ifndef ATLAS_PT_RSPLIT
+#define ATLAS_PT_RSPLIT 1            // gemm_pt_kernel: a k-tile's k-step-0 fragments are read a phase AHEAD, between the wave's own MFMAs of the previous k-tile's k-step 1 (0 = rounds 3-4; 2 = a variant that spills)
+#endif
 #ifndef ATLAS_PT_WSTRIDE
 #define ATLAS_PT_WSTRIDE 1           // ... one in front of every ATLAS_PT_WSTRIDE-th chunk of eight MFMAs
 #endif
@@ -882,6 +885,8 @@ template <int B, int E, class F>
 static __device__ __forceinline__ void pt_static_for(F&& f) {           // f(integral_constant<int, B>) ... f(integral_constant<int, E - 1>)
     if constexpr (B < E) { f(std::integral_constant<int, B>{}); pt_static_for<B + 1, E>(f); }
 }
+template <bool C, class A_, class B_>
+static __device__ __forceinline__ auto& pt_pick(A_& a, B_& b) { if constexpr (C) return a; else return b; }
 template <int OFF>
 static __device__ __forceinline__ void pt_ds_read(u4v& dst, const uint32_t addr) {      // issued, NOT waited for
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(OFF) : "memory");
@@ -1179,10 +1184,11 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     }
 #endif
     if (!grpB) stage(std::false_type{}, all_pieces{}, 0, jc, 0, nothing); else stage(std::true_type{}, all_pieces{}, 0, jc, 0, nothing);
+    if ((ATLAS_PT_RSPLIT != 0 && !VTR) && grpB) stage(std::true_type{}, all_pieces{}, 1, jc, 1, nothing);      // (read half a phase earlier there: they land under this first wait)
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's pieces of k-tile 0 have landed
     __builtin_amdgcn_s_barrier();
     if (grpB) {                                        // B's phase 0: nothing to multiply yet; its pieces of k-tile 1
-        stage(std::true_type{}, all_pieces{}, 1, jc, 1, nothing);
+        if (!(ATLAS_PT_RSPLIT != 0 && !VTR)) stage(std::true_type{}, all_pieces{}, 1, jc, 1, nothing);
         __builtin_amdgcn_s_barrier();
     }
     int buf = 0;
@@ -1220,11 +1226,24 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
             for (int b = 0; b < FB; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto iteration = [&](const int kt, auto last_tag) {
+    // ATLAS_PT_RSPLIT (round 5): the read phase, not the multiply phase, is the half period (a lone wave per SIMD gets a ds_read_b128 through
+    // every ~30 cycles: 24 reads = 720 cycles before the 8 pieces, against 1 024 cycles of MFMA issue; tools/lds_read_probe.hip, pt_cycles.py).
+    // So a k-tile's k-step-0 fragments (12 of the 24 reads) are read a phase AHEAD: between the wave's own MFMAs of the previous k-tile's k-step 1,
+    // into the registers its k-step-0 MFMAs have just released -- while the SIMD's other wave is in ITS read phase (two waves reading at once is
+    // the fast case). A tile's first iteration reads all 24 in its read phase, its last one reads nothing ahead (the epilogue needs the registers).
+    // What has to have landed earlier for that: the OTHER group's pieces of the next k-tile by the end of its multiply phase (both groups now
+    // wait for all of their pieces there), a wave's own activation pieces by the middle of its multiply phase (vmcnt(4) in front of the four
+    // activation reads; the eight W reads go first).
+    constexpr bool RS = !VTR && ATLAS_PT_RSPLIT != 0;
+    u4v cfw0[RS ? FA : 1], cfa0[RS ? FB : 1];                          // (RS) the k-step-0 fragments, carried from one iteration's multiply phase to the next
+    auto iteration = [&](const int kt, auto last_tag, auto first_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
+        constexpr bool HALF = RS && !decltype(first_tag)::value;       // the read phase reads k-step 1 only
         const bool has_next = jc + nslots < njobs;
         PT_ISTAMP(0);
-        u4v fw0[FA], fa0[FB], fw1[FA], fa1[FB];
+        u4v lfw0[RS ? 1 : FA], lfa0[RS ? 1 : FB], fw1[FA], fa1[FB];
+        auto& fw0 = pt_pick<RS>(cfw0, lfw0);
+        auto& fa0 = pt_pick<RS>(cfa0, lfa0);
         // (one lane-dependent address lives across the k-loop; k-step 1 = chunk (4 + lg) ^ (lr & 7) = k-step 0's with bit 2 flipped: byte
         //  address ^ 64 -- the dynamic LDS segment starts at a multiple of 128 --, the activations sit a wave-uniform distance behind the weights)
         const uint32_t w0 = aw0 + buf * STG, w1 = w0 ^ 64u, a0 = w0 + (uint32_t)(2 * STG + (wj * 64 - wi * 128) * 128), a1 = a0 ^ 64u;
@@ -1241,16 +1260,24 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         // (every fragment register is an in/out operand of the phase's last wait: nothing reads one in front of it; the reads are single
         //  asm statements so that they can sit between the pieces, and the registers they fill asynchronously must not be copied or spilled:
         //  tests/test_kernel_isa.py)
-#define PT_READS_DONE() asm volatile("s_waitcnt lgkmcnt(0)" \
+#define PT_READS_DONE_ALL() asm volatile("s_waitcnt lgkmcnt(0)" \
             : "+v"(fw0[0]), "+v"(fw0[1]), "+v"(fw0[2]), "+v"(fw0[3]), "+v"(fw0[4]), "+v"(fw0[5]), "+v"(fw0[6]), "+v"(fw0[7]), \
               "+v"(fw1[0]), "+v"(fw1[1]), "+v"(fw1[2]), "+v"(fw1[3]), "+v"(fw1[4]), "+v"(fw1[5]), "+v"(fw1[6]), "+v"(fw1[7]), \
               "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]), "+v"(fa1[0]), "+v"(fa1[1]), "+v"(fa1[2]), "+v"(fa1[3]) :: "memory")
+#define PT_READS_DONE_1() asm volatile("s_waitcnt lgkmcnt(0)" \
+            : "+v"(fw1[0]), "+v"(fw1[1]), "+v"(fw1[2]), "+v"(fw1[3]), "+v"(fw1[4]), "+v"(fw1[5]), "+v"(fw1[6]), "+v"(fw1[7]), \
+              "+v"(fa1[0]), "+v"(fa1[1]), "+v"(fa1[2]), "+v"(fa1[3]) :: "memory")
+#define PT_READS_DONE_0() asm volatile("s_waitcnt lgkmcnt(0)" \
+            : "+v"(fw0[0]), "+v"(fw0[1]), "+v"(fw0[2]), "+v"(fw0[3]), "+v"(fw0[4]), "+v"(fw0[5]), "+v"(fw0[6]), "+v"(fw0[7]), \
+              "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]) :: "memory")
+#define PT_READS_DONE() do { if constexpr (HALF) PT_READS_DONE_1(); else PT_READS_DONE_ALL(); } while (0)
         if (stages && !grpB) {
             __builtin_amdgcn_sched_barrier(0);
             stage(std::false_type{}, read_pieces_a{}, buf ^ 1, sj, skt, [&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
                 __builtin_amdgcn_sched_barrier(0);
-                pt_static_for<3 * i, 3 * i + 3>([&](auto kc) __attribute__((always_inline)) {
+                // (HALF: the 12 reads of k-step 1 behind the first six pieces, two each)
+                pt_static_for<(HALF ? 12 + 2 * i : 3 * i), (HALF ? (i < 6 ? 14 + 2 * i : 12 + 2 * i) : 3 * i + 3)>([&](auto kc) __attribute__((always_inline)) {
                     constexpr int k = decltype(kc)::value;
                     if constexpr (k < 8) pt_ds_read<k * 2048>(fw0[k], w0);
                     else if constexpr (k < 12) pt_ds_read<(k - 8) * 2048>(fa0[k - 8], a0);
@@ -1266,18 +1293,31 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
             __builtin_amdgcn_sched_barrier(0);
             pt_static_for<0, 4>([&](auto bc) __attribute__((always_inline)) {
                 constexpr int b = decltype(bc)::value;
-                pt_ds_read<b * 2048>(fa0[b], a0);
+                if constexpr (!HALF) pt_ds_read<b * 2048>(fa0[b], a0);
                 pt_ds_read<b * 2048>(fa1[b], a1);
             });
             stage(std::true_type{}, read_pieces_b{}, buf, sj, skt, [&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (i < 4) { pt_ds_read<(2 * i) * 2048>(fw0[2 * i], w0); pt_ds_read<(2 * i + 1) * 2048>(fw0[2 * i + 1], w0); }
+                if constexpr (HALF) {                   // (4 activation + 8 W reads of k-step 1: behind slot 3 all are out, lgkmcnt(8) = the activation reads are back)
+                    if constexpr (i < 4) { pt_ds_read<(2 * i) * 2048>(fw1[2 * i], w1); pt_ds_read<(2 * i + 1) * 2048>(fw1[2 * i + 1], w1); }
+                } else if constexpr (i < 4) { pt_ds_read<(2 * i) * 2048>(fw0[2 * i], w0); pt_ds_read<(2 * i + 1) * 2048>(fw0[2 * i + 1], w0); }
                 else { pt_ds_read<(2 * i - 8) * 2048>(fw1[2 * i - 8], w1); pt_ds_read<(2 * i - 7) * 2048>(fw1[2 * i - 7], w1); }
                 if constexpr (i == 3) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             });
             PT_READS_DONE();
+        } else if constexpr (HALF) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile(
+                "ds_read_b128 %0, %12\n ds_read_b128 %1, %12 offset:2048\n ds_read_b128 %2, %12 offset:4096\n ds_read_b128 %3, %12 offset:6144\n"
+                "ds_read_b128 %4, %12 offset:8192\n ds_read_b128 %5, %12 offset:10240\n ds_read_b128 %6, %12 offset:12288\n ds_read_b128 %7, %12 offset:14336\n"
+                "ds_read_b128 %8, %13\n ds_read_b128 %9, %13 offset:2048\n ds_read_b128 %10, %13 offset:4096\n ds_read_b128 %11, %13 offset:6144\n"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(fw1[0]), "=&v"(fw1[1]), "=&v"(fw1[2]), "=&v"(fw1[3]), "=&v"(fw1[4]), "=&v"(fw1[5]), "=&v"(fw1[6]), "=&v"(fw1[7]),
+                  "=&v"(fa1[0]), "=&v"(fa1[1]), "=&v"(fa1[2]), "=&v"(fa1[3])
+                : "v"(w1), "v"(a1)
+                : "memory");
         } else {
             __builtin_amdgcn_sched_barrier(0);
             asm volatile(
@@ -1296,6 +1336,8 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
                 : "memory");
         }
 #undef PT_READS_DONE
+#undef PT_READS_DONE_ALL
+#undef PT_READS_DONE_1
         if (LAST) PT_STAMP(1);
         PT_ISTAMP(1);
         // what must have LANDED before the barrier: the pieces issued before this phase (the W rows the other group reads next, group B's
@@ -1330,7 +1372,47 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
             if (!(diag & 64))                          // experiment (timing only): no MFMAs -- what the feed side (pieces, fragment reads, barriers) takes alone
 #endif
             {
-            if constexpr (WD == 0) {
+            if constexpr (RS && ATLAS_PT_RSPLIT == 2 && !LAST) {
+                // variant 2: W fragment a of the next k-tile is read as soon as row a of k-step 0 has been issued (its register is free then),
+                // the activation fragments between the two k-steps
+                const uint32_t w0n = aw0 + (buf ^ 1) * STG, a0n = w0n + (uint32_t)(2 * STG + (wj * 64 - wi * 128) * 128);
+                __builtin_amdgcn_sched_barrier(0);
+                pt_static_for<0, FA>([&](auto ac) __attribute__((always_inline)) {
+                    constexpr int a = decltype(ac)::value;
+#pragma unroll
+                    for (int b = 0; b < FB; ++b) acc[a][b] = T::mma(fw0[a], fa0[b], acc[a][b]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    pt_ds_read<a * 2048>(fw0[a], w0n);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                if (!grpB) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
+                pt_static_for<0, FB>([&](auto bc) __attribute__((always_inline)) { pt_ds_read<decltype(bc)::value * 2048>(fa0[decltype(bc)::value], a0n); });
+                __builtin_amdgcn_sched_barrier(0);
+                mma_tile<T, FA, FB>(fw1, fa1, acc);
+                PT_READS_DONE_0();
+            } else if constexpr (RS) {
+                mma_tile<T, FA, FB>(fw0, fa0, acc);
+                if constexpr (LAST) {
+                    mma_tile<T, FA, FB>(fw1, fa1, acc);
+                } else {
+                    // the next k-tile's k-step-0 fragments, from the OTHER stage, into the registers the 32 MFMAs above have released: one W
+                    // read in front of each of the eight rows of MFMAs of k-step 1, the activation reads with rows 4..7 -- behind the wave's
+                    // own wait (group A's four activation pieces of this k-tile's read phase were issued first)
+                    const uint32_t w0n = aw0 + (buf ^ 1) * STG, a0n = w0n + (uint32_t)(2 * STG + (wj * 64 - wi * 128) * 128);
+                    __builtin_amdgcn_sched_barrier(0);
+                    pt_static_for<0, FA>([&](auto ac) __attribute__((always_inline)) {
+                        constexpr int a = decltype(ac)::value;
+                        pt_ds_read<a * 2048>(fw0[a], w0n);
+                        if constexpr (a == 4) { if (!grpB) __builtin_amdgcn_s_waitcnt(0x0F70 | 4); }
+                        if constexpr (a >= 4) pt_ds_read<(a - 4) * 2048>(fa0[a - 4], a0n);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int b = 0; b < FB; ++b) acc[a][b] = T::mma(fw1[a], fa1[b], acc[a][b]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    PT_READS_DONE_0();
+                }
+            } else if constexpr (WD == 0) {
                 mma_tile<T, FA, FB>(fw0, fa0, acc);
                 mma_tile<T, FA, FB>(fw1, fa1, acc);
             } else {
@@ -1404,6 +1486,10 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         // while group B multiplies its last k-tile and are waited for in front of the epilogue: EPL loads on top of the four W pieces.)
         constexpr int EPL = EPI == 4 ? 12 : EPI == 2 ? 20 : 4;
         constexpr int VMA = LAST ? 4 + EPL : 4;     // (s_waitcnt simm16: vmcnt[3:0] in bits 3:0, vmcnt[5:4] in bits 15:14)
+        if constexpr (RS) {                        // both groups: ALL pieces of this iteration have landed (the other group reads some of them half a phase on)
+            constexpr int VMR = LAST ? EPL : 0;
+            if (stages || b_first) __builtin_amdgcn_s_waitcnt(0x0F70 | (VMR & 15) | ((VMR >> 4) << 14)); else __builtin_amdgcn_s_waitcnt(0x0F70);
+        } else
         if (!grpB) { if (stages) __builtin_amdgcn_s_waitcnt(0x0F70 | (VMA & 15) | ((VMA >> 4) << 14)); else __builtin_amdgcn_s_waitcnt(0x0F70); }
         if (EPI == 2 && !grpB && kt == nk - 3) touch_residual();
         if (LAST) PT_STAMP(4);
@@ -1423,8 +1509,12 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     for (;;) {
         PT_STAMP(0);
 #pragma unroll 1
-        for (int kt = 0; kt < nk - 1; ++kt) iteration(kt, std::false_type{});
-        iteration(nk - 1, std::true_type{});
+        for (int kt = 0; kt < (RS ? 1 : nk - 1); ++kt) iteration(kt, std::false_type{}, std::true_type{});
+        if constexpr (RS) {
+#pragma unroll 1
+            for (int kt = 1; kt < nk - 1; ++kt) iteration(kt, std::false_type{}, std::false_type{});
+            iteration(nk - 1, std::true_type{}, std::false_type{});
+        } else iteration(nk - 1, std::true_type{}, std::true_type{});
         // Epilogue of this tile, BOTH GROUPS SIDE BY SIDE: an epilogue is a chain of dependent VALU work (bias, GELU polynomial, packing)
         // that one wave per SIMD runs at ~7 cycles per instruction; two waves per SIMD hide each other's latencies. The barrier between a
         // group's reads and its MFMAs only keeps the two groups in opposite phases (no LDS hazard hangs on it: every buffer hand-over
@@ -1450,6 +1540,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
 #if ATLAS_TUNING
     if (dbgp != nullptr && blockIdx.x == 0 && tid == 0) { dbgp[1026] = wall_clock64(); dbgp[1027] = __builtin_readcyclecounter(); }
 #endif
+#undef PT_READS_DONE_0
 #undef PT_STAMP
 #undef PT_ISTAMP
 }

@@ -44,9 +44,19 @@ def test_persistent_gemm_has_no_scratch_and_a_clean_loop():
     for name, body in fns.items():
         assert _scratch_bytes(body) == 0, f"{name} spills {_scratch_bytes(body)} bytes"
         assert "scratch_" not in body, name
-        # every block of 64 MFMAs (one k-tile) is free of waits on the vector-memory counter: the LDS-DMA pipeline is never drained mid-tile
-        runs = re.findall(r"(?:\s*v_mfma[^\n]*\n){64}", body)
-        assert len(runs) >= 2, (name, len(runs))
+        # Round 5 (ATLAS_PT_RSPLIT): three flavours of a k-tile -- a tile's first, middle and last iteration -- of 64 MFMAs each. The k-step-0 half
+        # (32 MFMAs) is one uninterrupted run in every flavour and the last iteration's 64 are; in the other two the k-step-1 half carries the
+        # twelve fragment reads of the NEXT k-tile (one W read in front of each row of four MFMAs) and exactly one wait on the vector-memory
+        # counter: group A's vmcnt(4) in front of its four activation reads. Nothing else may drain the LDS-DMA pipeline mid-tile.
+        assert body.count("v_mfma") == 3 * 64, (name, body.count("v_mfma"))
+        lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith((";", "."))]
+        mf = [i for i, l in enumerate(lines) if l.startswith("v_mfma")]
+        inside = [lines[a + 1: b] for a, b in zip(mf, mf[1:]) if 0 < b - a - 1 <= 8]          # what sits BETWEEN the MFMAs of a multiply phase
+        flat = [l for g in inside for l in g]
+        nread = sum(l.startswith("ds_read_b128") for l in flat)                                # two flavours x twelve reads ahead (hipcc rotates the
+        assert 20 <= nread <= 24, (name, nread, flat)                                          #  loop: a read or two may open the block behind the MFMAs)
+        assert set(l for l in flat if l.startswith("s_waitcnt")) == {"s_waitcnt vmcnt(4)"}, (name, flat)
+        assert not [l for l in flat if l.startswith(("buffer_", "global_", "scratch_", "s_barrier"))], (name, flat)
 
 
 def test_scan_has_no_scratch_and_a_clean_loop():
