@@ -318,3 +318,20 @@ def test_the_rounds_line_session_p_final_code():
     assert d["scale_emulated"]["per_w"]["8"]["step_frac"] >= 0.715
     bs = d["batch_sweep"]
     assert bs["512"]["frac_of_mfma_peak"] >= 0.46 and bs["128"]["certifying_ms_per_step"] / bs["128"]["ms_per_step"] <= 1.05
+
+
+def test_the_rounds_line_session_aa_reads_ahead():
+    """session AA = THE line of round 5: session P's code + the refresh GEMM's fragment reads a phase ahead (ATLAS_PT_RSPLIT; bit-identical embeddings,
+    A/B of the builds - 1.6 %); smoke + `pytest -m gpu` 132 passed in the same session. The search side is untouched code: same numbers as session P"""
+    d = _line("r05/bench_default_32m_sessionAA.json")
+    r = d["roofline"]
+    assert r["traffic"] is not None and 1.0 <= r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.05
+    assert r["frac"] >= 0.775 and r["certifying_frac"] >= 0.74 and d["value"] >= 8000
+    assert d["detail"]["parity_checked"]["rows"] == 32_000_000 and d["detail"]["parity_checked"]["queries_oracle"] == 1
+    assert d["refresh"]["roofline"]["frac"] >= 0.354 and d["refresh"]["streamed"]["value"] >= 37500 and d["refresh"]["ragged"]["value"] >= 34500
+    assert d["scale_emulated"]["per_w"]["8"]["step_frac"] >= 0.72
+    bs = d["batch_sweep"]
+    assert bs["512"]["frac_of_mfma_peak"] >= 0.46 and bs["128"]["certifying_ms_per_step"] / bs["128"]["ms_per_step"] <= 1.05
+    log = open(os.path.join(ROOT, "profiles", "r05", "pytest_gpu_sessionAA.log")).read()
+    assert "132 passed" in log and "failed" not in log
+
