@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="most rows of the CPU baseline sample (at least 500k are timed)")
     ap.add_argument("--refresh-batches", type=int, default=30, help="timed 512-passage encoder batches for the index-refresh leg (0 = skip)")
     ap.add_argument("--refresh-len", type=int, default=128, help="tokens per passage in the refresh leg")
+    ap.add_argument("--no-refresh-zero-leg", dest="refresh_zero_leg", action="store_false",
+                    help="skip refresh.power_limit_probe (N = 1 only, ~5 s): the refresh batch on all-zero operands beside the real one, with rocm-smi power / clock samples")
     ap.add_argument("--refresh-stream-seconds", type=float, default=15.0, help="sustained streamed-refresh leg from the token store, with rocm-smi power / clock samples (0 = skip)")
     ap.add_argument("--batch-sweep", type=str, default="64,96,128,192,256,384,512,1024", help="query-batch sizes timed on the 4M-row prefix (a rank of an N-GPU search scores ALL gathered queries; N=1 only; '' = skip)")
     ap.add_argument("--shard-sweep", type=str, default="1000000,4000000,8000000,16000000",
@@ -616,6 +618,45 @@ def main():
                    "data": "synthetic token ids, " + (f"weights of the checkpoint {ckpt_dir}" if ckpt_dir else "random-init BERT-base weights"),
                    "roofline": {"bound": "mfma", "achieved": pps * flops_pp / world / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                                 "frac": pps * flops_pp / world / 1e12 / 2500.0, "flops_per_passage": flops_pp}}
+        # Round 5: is that fraction the schedule's or the board's? The SAME batch with every parameter cleared in place -- the same kernels,
+        # launches and addresses, every GEMM operand, activation and stored tile = 0, so (almost) nothing toggles in the matrix pipe, the LDS
+        # and the fabric -- timed for >= 2 s beside rocm-smi, and the real batch again the same way. Not a throughput claim (the embeddings
+        # are all zero): the time the schedule takes when the 1 400 W limit does not bind. The parameters are restored and one batch is
+        # re-embedded and compared bit for bit with the first leg's.
+        if world == 1 and args.refresh_zero_leg:
+            scratch = torch.empty((nb, D), dtype=torch.float16, device=dev)
+
+            def _sustained(seconds):
+                for _ in range(3):
+                    enc.embed_into(scratch, ids, msk)
+                fence()
+                sm = _SmiSampler(); sm.start()
+                t, n = time.perf_counter(), 0
+                while time.perf_counter() - t < seconds:
+                    for _ in range(10):
+                        enc.embed_into(scratch, ids, msk)
+                    fence(); n += 10
+                ms = (time.perf_counter() - t) / n * 1e3
+                return {"ms_per_batch": ms, "frac_of_mfma_peak": nb / ms * 1e3 * flops_pp / 1e12 / 2500.0, "power": sm.finish()}
+
+            saved = [q.detach().clone() for q in enc.parameters()]
+            try:
+                real = _sustained(2.0)
+                with torch.no_grad():
+                    for q in enc.parameters():
+                        q.zero_()
+                zero = _sustained(2.0)
+                assert float(scratch.float().abs().max()) == 0.0
+            finally:
+                with torch.no_grad():
+                    for q, s_ in zip(enc.parameters(), saved):
+                        q.copy_(s_)
+            enc.embed_into(scratch, ids, msk)
+            fence()
+            assert torch.equal(scratch, tgt[1]), "the parameters were not restored"
+            refresh["power_limit_probe"] = {"what": "the same 512 x %d batch, back to back for 2 s each: real parameters | every parameter cleared in place (all-zero operands, same instruction stream)" % Lr,
+                                            "real": real, "zero_operands": zero, "time_ratio": zero["ms_per_batch"] / real["ms_per_batch"]}
+            del saved, scratch
         # SURVEY §8d variant (b): ragged passages, lengths uniform in 64..200 padded to the longest of the batch
         # (padding="longest"); only real tokens are computed, so the real-token FLOPs are what the MFMAs do and the
         # padded-token FLOPs are what a padded implementation would have spent
