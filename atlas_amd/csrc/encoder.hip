@@ -1064,6 +1064,8 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     auto tile_n0 = [&](const int j) { return (j % ncol) << 8; };
     auto tile_m0 = [&](const int j) { return (int64_t)((j / ncol) * 8 + xcd) << 8; };
     auto rows_rsrc = [&](const E* base, const int64_t m0, const int ld) {      // rows [m0, M) of a [M, ld] tensor
+        // (a descriptor that ends with the TILE -- one 32-bit product instead of the clamped 64-bit one -- was tried in round 5: hipcc answers
+        //  with vector compares and 35 % more instructions in the kernel; left as it is)
         int64_t rem = (M - m0) * (int64_t)ld * 2;
         if (rem > 0xfffffff0ll) rem = 0xfffffff0ll;
         return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)m0 * ld), 0, (int)rem, 0x00020000);
@@ -1346,7 +1348,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
         if (stages) { if (!(skip_b1 || skip_wait)) __builtin_amdgcn_s_waitcnt(0x0F70 | (8 - WD)); }
         else if (!(skip_b1 || skip_wait)) __builtin_amdgcn_s_waitcnt(0x0F70);
         PT_ISTAMP(2);
-        if (EPI == 2 && grpB && kt == nk - 3) touch_residual();
+        if (EPI == 2 && !RS && grpB && kt == nk - 3) touch_residual();
         __builtin_amdgcn_sched_barrier(0);
         if (!skip_b1) __builtin_amdgcn_s_barrier();    // (group A took a tile's first barrier ahead of its epilogue: see the tile loop)
         skip_b1 = false;
@@ -1491,7 +1493,7 @@ gemm_pt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
             if (stages || b_first) __builtin_amdgcn_s_waitcnt(0x0F70 | (VMR & 15) | ((VMR >> 4) << 14)); else __builtin_amdgcn_s_waitcnt(0x0F70);
         } else
         if (!grpB) { if (stages) __builtin_amdgcn_s_waitcnt(0x0F70 | (VMA & 15) | ((VMA >> 4) << 14)); else __builtin_amdgcn_s_waitcnt(0x0F70); }
-        if (EPI == 2 && !grpB && kt == nk - 3) touch_residual();
+        if (EPI == 2 && (RS || !grpB) && kt == nk - 3) touch_residual();          // (RS: group B too touches BEHIND its wait -- it now waits for all its loads at the end of every multiply phase)
         if (LAST) PT_STAMP(4);
         PT_ISTAMP(6);
         __builtin_amdgcn_s_barrier();

@@ -335,3 +335,16 @@ def test_the_rounds_line_session_aa_reads_ahead():
     log = open(os.path.join(ROOT, "profiles", "r05", "pytest_gpu_sessionAA.log")).read()
     assert "132 passed" in log and "failed" not in log
 
+
+def test_power_limit_probe_of_the_refresh_leg():
+    """session AE (the final library, bench.py + `refresh.power_limit_probe`): the refresh batch on all-zero operands -- the same instruction stream --
+    runs at the full clock and well below the power limit, and is > 10 % faster: the board's 1 400 W, not the schedule, bounds the real batch"""
+    d = _line("r05/bench_default_32m_sessionAE.json")
+    pr = d["refresh"]["power_limit_probe"]
+    real, zero = pr["real"], pr["zero_operands"]
+    assert real["power"]["watts_mean"] > 1300 and zero["power"]["watts_mean"] < 1100
+    assert zero["power"]["sclk_mhz_mean"] > 2300 > 2000 > real["power"]["sclk_mhz_mean"]
+    assert 0.85 < pr["time_ratio"] < 0.92 and zero["frac_of_mfma_peak"] >= 0.40
+    assert abs(real["ms_per_batch"] - d["refresh"]["ms_per_batch"]) < 0.03 * real["ms_per_batch"]
+    assert d["value"] >= 8100 and d["roofline"]["frac"] >= 0.785 and d["refresh"]["roofline"]["frac"] >= 0.355
+
