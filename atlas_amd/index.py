@@ -113,6 +113,10 @@ class _DocMap(dict):
         self.edits += 1
         return dict.setdefault(self, *a)
 
+    def __ior__(self, other):                   # (`dm |= other` does not go through update())
+        self.edits += 1
+        return dict.__ior__(self, other)
+
     def __reduce__(self):                       # pickles (and deep-copies) as a plain dict's content
         return (_DocMap, (dict(self),))
 
@@ -156,10 +160,10 @@ class HipDistributedIndex(object):
         The store must have been built in this index's global-id order: `PassageStore.iter_jsonl` for passages loaded
         round-robin by `index_io.load_passages`, `PassageStore.iter_saved_index` for an index loaded with `load_index`.
         Collective (every rank attaches): the store must hold exactly as many passages as all shards together."""
-        sizes = [int(n) for n in dist_utils.all_gather_object(len(self.doc_map))]
-        total = sum(sizes)
-        if self._slab is not None and len(self.doc_map) == int(self._slab.shape[0]):
-            self._min_shard_rows = min(sizes)          # (the shard sizes of the job, for free: search_knn's collective range check)
+        both = dist_utils.all_gather_object((len(self.doc_map), -1 if self._slab is None else int(self._slab.shape[0])))
+        total = sum(int(n) for n, _ in both)
+        if all(int(r) >= 0 for _, r in both):          # (decided from what EVERY rank reported: all ranks take it, or none does)
+            self._min_shard_rows = min(int(r) for _, r in both)      # the shard sizes of the job, for free: search_knn's collective range check
         if len(store) != total:
             raise ValueError(f"passage store holds {len(store)} passages, the index {total}: it was built from another corpus")
         self._passage_store = store

@@ -82,31 +82,40 @@ def _passage_store_path(opt, restored: bool):
     import socket
     import tempfile
 
-    explicit = getattr(opt, "passage_store_path", None)
-    if os.environ.get("ATLAS_PASSAGE_STORE", "").lower() in ("off", "0", "none"):
-        explicit = "off"
-    if explicit is not None:
-        return None if str(explicit).lower() in ("off", "none", "") else explicit
+    explicit = getattr(opt, "passage_store_path", None)       # (an option: the same on every rank)
+    env_off = os.environ.get("ATLAS_PASSAGE_STORE", "").lower() in ("off", "0", "none")
     if dist_utils.get_world_size() < 2:
-        return None                                   # one process: doc_map resolves everything, nothing to exchange
-    if not restored and getattr(opt, "use_file_passages", False):
+        # one process: an explicit path is honoured (the store then replaces doc_map lookups of nothing -- harmless), nothing automatic
+        return None if explicit is None or env_off or str(explicit).lower() in ("off", "none", "") else explicit
+    if explicit is not None and str(explicit).lower() in ("off", "none", ""):
+        return None
+    if explicit is None and not restored and getattr(opt, "use_file_passages", False):
         return None
     # /dev/shm if it has room for the corpus text (containers often mount 64 MiB there), else the temporary directory (a file the page cache
-    # serves). Every rank proposes, rank 0's proposal is taken: the ranks must agree on the path
+    # serves). Every rank proposes, rank 0's proposal is taken: the ranks must agree on the path. Whatever differs between ranks -- the
+    # environment switch, a corpus file one of them cannot see -- travels IN the one collective: the decision is taken from what every rank
+    # reported, so no rank can leave before it while the others wait in it.
     import shutil
 
-    if restored:
-        need = sum(os.path.getsize(os.path.join(opt.load_index_path, f"passages.{s}.pt")) for s in range(opt.save_index_n_shards))
-    else:
-        need = sum(os.path.getsize(f) for f in opt.passages)
     base = tempfile.gettempdir()
-    if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) and shutil.disk_usage("/dev/shm").free > 1.5 * need + (64 << 20):
-        base = "/dev/shm"
-    hosts = dist_utils.all_gather_object((socket.gethostname(), base))
-    if len({h for h, _ in hosts}) != 1:
-        logger.info("ranks on %d hosts: no automatic passage store (set opt.passage_store_path to a node-local path to get one)", len({h for h, _ in hosts}))
+    try:
+        if restored:
+            need = sum(os.path.getsize(os.path.join(opt.load_index_path, f"passages.{s}.pt")) for s in range(opt.save_index_n_shards))
+        else:
+            need = sum(os.path.getsize(f) for f in opt.passages)
+        if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) and shutil.disk_usage("/dev/shm").free > 1.5 * need + (64 << 20):
+            base = "/dev/shm"
+    except OSError:
+        pass                                          # (the builder will say what is wrong, on every rank: PassageStoreError)
+    reports = dist_utils.all_gather_object((socket.gethostname(), base, env_off))
+    if any(off for _, _, off in reports):
         return None
-    return os.path.join(hosts[0][1], "atlas_amd_passages_" + _corpus_signature(opt)[:16])
+    if explicit is not None:
+        return explicit
+    if len({h for h, _, _ in reports}) != 1:
+        logger.info("ranks on %d hosts: no automatic passage store (set opt.passage_store_path to a node-local path to get one)", len({h for h, _, _ in reports}))
+        return None
+    return os.path.join(reports[0][1], "atlas_amd_passages_" + _corpus_signature(opt)[:16])
 
 
 def load_or_initialize_index(opt):
