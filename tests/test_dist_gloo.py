@@ -292,3 +292,45 @@ def _store_failure_worker(rank, W, port, out_dir):
 
 def test_a_failing_store_builder_reaches_every_rank(tmp_path):
     mp.spawn(_store_failure_worker, args=(2, 29947, str(tmp_path)), nprocs=2, join=True)
+
+
+def _env_mismatch_worker(rank, W, port, out_dir):
+    """one rank runs with ATLAS_PASSAGE_STORE=off, the other without: the switch travels in the factory's one collective, so BOTH end up without a
+    store (neither waits in a collective the other never enters) and the search runs on the winners-only exchange"""
+    import json
+    import types
+
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    if rank == 1:
+        os.environ["ATLAS_PASSAGE_STORE"] = "off"
+    else:
+        os.environ.pop("ATLAS_PASSAGE_STORE", None)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    from atlas_amd import HipDistributedIndex, index_io
+    from oracle_backend import oracle_local_topk
+
+    HipDistributedIndex._local_topk = oracle_local_topk
+    HipDistributedIndex._device = lambda self: torch.device("cpu")
+    N, k = 50, 3
+    jsonl = os.path.join(out_dir, "passages.jsonl")
+    if rank == 0:
+        with open(jsonl, "w") as f:
+            for g in range(N):
+                f.write(json.dumps({"id": str(g), "text": f"p{g}"}) + "\n")
+    dist.barrier()
+    opt = types.SimpleNamespace(index_mode="flat", load_index_path=None, passages=[jsonl], use_file_passages=False, max_passages=-1, save_index_n_shards=2 * W)
+    index, _ = index_io.load_or_initialize_index(opt)
+    assert index._passage_store is None
+    P = synth.passages_f16(N, 768, 91)
+    index.embeddings[:, :] = torch.from_numpy(P[np.arange(rank, N, W)]).T
+    docs, _ = index.search_knn(torch.from_numpy(synth.queries_f32(2, 768, 92 + rank)), k)
+    assert len(docs) == 2 and all(d["text"] == f"p{d['id']}" for row in docs for d in row)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_the_environment_switch_of_one_rank_reaches_every_rank(tmp_path):
+    mp.spawn(_env_mismatch_worker, args=(2, 29953, str(tmp_path)), nprocs=2, join=True)
+
