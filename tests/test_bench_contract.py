@@ -348,3 +348,22 @@ def test_power_limit_probe_of_the_refresh_leg():
     assert abs(real["ms_per_batch"] - d["refresh"]["ms_per_batch"]) < 0.03 * real["ms_per_batch"]
     assert d["value"] >= 8100 and d["roofline"]["frac"] >= 0.785 and d["refresh"]["roofline"]["frac"] >= 0.355
 
+
+def test_the_rounds_line_session_ag_final_code():
+    """session AG = THE line of round 5: the final code (reads ahead in the refresh GEMM, collective hygiene on the host side, `refresh.power_limit_probe`
+    in bench.py), `smoke()` + `pytest -m gpu` (132 passed) + `bench.py` in ONE session; the box's slab pass is on the slow side of the round's range"""
+    d = _line("r05/bench_default_32m_sessionAG.json")
+    r = d["roofline"]
+    assert r["traffic"] is not None and 1.0 <= r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.05
+    assert r["frac"] >= 0.765 and r["certifying_frac"] >= 0.73 and d["value"] >= 7900
+    assert d["detail"]["parity_checked"]["rows"] == 32_000_000 and d["detail"]["parity_checked"]["queries_oracle"] == 1
+    rf = d["refresh"]
+    assert rf["roofline"]["frac"] >= 0.36 and rf["ms_per_batch"] <= 12.75 and rf["streamed"]["value"] >= 38000 and rf["ragged"]["value"] >= 35500
+    pr = rf["power_limit_probe"]
+    assert pr["zero_operands"]["frac_of_mfma_peak"] >= 0.40 and pr["zero_operands"]["power"]["watts_mean"] < 1100 < 1300 < pr["real"]["power"]["watts_mean"]
+    assert d["scale_emulated"]["per_w"]["8"]["step_frac"] >= 0.72 and d["scale_emulated"]["per_w"]["8"]["efficiency_vs_1"] >= 0.94
+    bs = d["batch_sweep"]
+    assert bs["512"]["frac_of_mfma_peak"] >= 0.465 and bs["1024"]["frac_of_mfma_peak"] >= 0.50 and bs["256"]["ms_per_step"] <= 1.55
+    log = open(os.path.join(ROOT, "profiles", "r05", "pytest_gpu_sessionAG.log")).read()
+    assert "132 passed" in log and "failed" not in log
+
