@@ -367,3 +367,16 @@ def test_the_rounds_line_session_ag_final_code():
     log = open(os.path.join(ROOT, "profiles", "r05", "pytest_gpu_sessionAG.log")).read()
     assert "132 passed" in log and "failed" not in log
 
+
+def test_the_last_commit_on_a_third_box_session_aj():
+    """session AJ: the round's last commit (session AG's library; the power probe reports its checks as fields); smoke + `pytest -m gpu` 132 passed + bench.
+    Three boxes with the final library (AE, AG, AJ): 7 955 ... 8 161 queries/s, refresh 0.355 ... 0.361, zero-operand probe 0.402 ... 0.407"""
+    d = _line("r05/bench_default_32m_sessionAJ.json")
+    assert d["value"] >= 8000 and d["roofline"]["frac"] >= 0.77 and d["roofline"]["certifying_frac"] >= 0.735 and d["roofline"]["traffic"] is not None
+    pr = d["refresh"]["power_limit_probe"]
+    assert pr["parameters_restored_bitwise"] is True and pr["zero_operands"]["all_embeddings_zero"] is True
+    assert pr["zero_operands"]["frac_of_mfma_peak"] >= 0.40 and 0.85 < pr["time_ratio"] < 0.92
+    assert d["refresh"]["roofline"]["frac"] >= 0.354 and d["refresh"]["streamed"]["value"] >= 37500
+    log = open(os.path.join(ROOT, "profiles", "r05", "pytest_gpu_sessionAJ.log")).read()
+    assert "132 passed" in log and "failed" not in log
+
