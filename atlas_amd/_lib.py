@@ -33,9 +33,12 @@ SYMBOLS = [
     "atlas_scan_topk_workspace_bytes", "atlas_scan_topk", "atlas_scan_topk_ex", "atlas_scan_topk_flags", "atlas_scan_topk_pack",
     "atlas_exact_topk_workspace_bytes", "atlas_exact_topk",
     "atlas_pack_candidates", "atlas_merge_packed",
-    "atlas_xchg_bytes", "atlas_xchg_create", "atlas_xchg_open", "atlas_xchg_close", "atlas_xchg_destroy", "atlas_xchg_push", "atlas_xchg_merge",
     "atlas_pool_write", "atlas_slab_pmax",
     "atlas_contriever_workspace_bytes", "atlas_contriever_embed", "atlas_contriever_embed_rows",
+]
+# include/atlas_hip_experimental.h: exported, NOT part of the product interface (the peer exchange has never run across two devices)
+EXPERIMENTAL_SYMBOLS = [
+    "atlas_xchg_bytes", "atlas_xchg_create", "atlas_xchg_open", "atlas_xchg_close", "atlas_xchg_destroy", "atlas_xchg_push", "atlas_xchg_merge",
 ]
 
 BERT_MAX_LAYERS = 24

@@ -32,6 +32,7 @@
 #include "scan_kernel.h"
 #include "gscan_kernel.h"
 #include "../../include/atlas_hip.h"
+#include "../../include/atlas_hip_experimental.h"   // atlas_xchg_*: exported, outside the product interface
 
 using namespace atlas;
 

@@ -174,16 +174,20 @@ def _collective_device() -> torch.device:
 
 
 def exchange_objects(per_dst: list) -> list:
-    """Personalised all-to-all of python objects: rank r receives [per_dst[r] of rank 0, ..., of rank W-1]. Two collectives
-    (sizes, then the pickled bytes with uneven splits): every rank gets exactly what was addressed to it, nothing else.
-    ATLAS_EXCHANGE=allgather swaps it for one `all_gather_object` of the whole outbox (W x the bytes, the plainest collective
-    there is): the switch to throw if a backend mishandles uneven or empty all-to-all splits."""
+    """Personalised exchange of python objects: rank r receives [per_dst[r] of rank 0, ..., of rank W-1].
+
+    Default: ONE `all_gather_object` of the whole outbox, of which every rank keeps what was addressed to it -- the plainest object
+    collective there is (W x the bytes of the personalised form: ~W x k short passages per query, host-pickled). It is the default
+    because the personalised form below -- two `all_to_all_single` (sizes, then the pickled bytes with UNEVEN and possibly EMPTY splits,
+    on device tensors under RCCL) -- has never run on RCCL with more than one rank (VERDICT r05 next #1c): the first multi-GPU job must
+    not be the one to find out. `ATLAS_EXCHANGE=alltoall` (the same on every rank) selects it; tests/test_dist_gloo.py covers both forms
+    over gloo. One-host jobs take neither: the node-local passage store resolves ids without a text collective (index_io)."""
     if not is_initialized():
         return [per_dst[0]]
     import os
     import pickle
 
-    if os.environ.get("ATLAS_EXCHANGE", "") == "allgather":
+    if os.environ.get("ATLAS_EXCHANGE", "allgather") != "alltoall":
         rank = dist.get_rank()
         return [outbox[rank] for outbox in all_gather_object(per_dst)]
 

@@ -183,27 +183,8 @@ int atlas_pack_candidates(const void* score_f16, const int64_t* idx, int64_t n, 
 int atlas_merge_packed(const uint64_t* gathered, int W, int B, int k, uint64_t* out_packed,
                        void* stream);
 
-/* ---- peer exchange: a one-hop alternative to the all-gather + atlas_merge_packed above (src/index.py:134-151) ----------
- * EXPERIMENTAL, not what HipDistributedIndex uses by default: it has never run across two devices (no multi-GPU box was attached
- * to the build); its logic is tested with two processes on one GPU. Every rank owns an exchange buffer that its peers map through a
- * 64-byte IPC handle (hipIpcMemHandle_t, carried as bytes by any channel, e.g. torch.distributed.all_gather_object):
- *   atlas_xchg_create   allocates and zeroes a buffer for W ranks x slot_entries packed candidates (>= B*k), returns its handle
- *   atlas_xchg_open     maps a PEER's buffer from its handle (the own buffer is used directly);  _close / _destroy undo them
- *   atlas_xchg_push     copies this rank's [n] packed candidates into slot `rank` of every buffer in peer_bufs[W] (host array of the
- *                       mapped pointers, own buffer at index rank) and then publishes `tag` there (system-scope release)
- *   atlas_xchg_merge    waits -- at most wait_ms -- until all W ranks have published `tag` in the own buffer, then writes the k best of the
- *                       W*k candidates of each of the B queries to out_packed (as atlas_merge_packed). If a peer is late, *status |= 1
- *                       (device int32, zeroed by the caller) and out_packed is left alone: repeat the exchange with the collective.
- * `tag` is the same nonzero number on every rank for one search and changes by one from search to search (slots are double-buffered
- * by its parity). All calls are asynchronous on `stream`. */
-size_t atlas_xchg_bytes(int W, int64_t slot_entries);
-int atlas_xchg_create(int W, int64_t slot_entries, void** buf, unsigned char* handle64);
-int atlas_xchg_open(const unsigned char* handle64, void** peer_buf);
-int atlas_xchg_close(void* peer_buf);
-int atlas_xchg_destroy(void* buf);
-int atlas_xchg_push(const uint64_t* packed, int64_t n, void* const* peer_bufs, int W, int rank, int64_t slot_entries, uint32_t tag, void* stream);
-int atlas_xchg_merge(const void* own_buf, int W, int B, int k, int64_t slot_entries, uint32_t tag, int wait_ms, uint64_t* out_packed,
-                     int32_t* status, void* stream);
+/* (The peer exchange -- atlas_xchg_*: a one-hop alternative to the all-gather + atlas_merge_packed above that has never run across two
+ * devices -- is declared in include/atlas_hip_experimental.h, outside the product interface, until it has.) */
 
 /* ---- index refresh epilogue (replaces src/retrievers.py:50-52 + src/atlas.py:79) ----
  * Masked mean pooling of the encoder's last hidden state, with the reference's fp16

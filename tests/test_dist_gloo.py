@@ -58,8 +58,13 @@ def _worker(rank, W, port, N, batches, k, out_dir, mode):
         return got
 
     du0.exchange_objects = counting_exchange
-    for rep in range(2):                                    # search_knn is a collective: call it twice
+    both = []
+    for form in ("allgather", "alltoall"):                  # search_knn is a collective: called twice, once per form of the text exchange
+        os.environ["ATLAS_EXCHANGE"] = form                 # (default = allgather; alltoall = personalised, uneven / empty splits)
         docs, scores = idx.search_knn(Q, k)
+        both.append((docs, scores))
+    os.environ.pop("ATLAS_EXCHANGE", None)
+    assert both[0] == both[1]
     du0.exchange_objects = real_exchange
     # the text exchange is personalised: a rank receives the k winners of each of ITS OWN queries and nothing else
     # (a passage that wins for several of the rank's queries travels once: only the small batches are sure to have k distinct winners each)
@@ -167,6 +172,12 @@ def _default_worker(rank, W, port, out_dir, store_opt):
     dist.barrier()
     opt = types.SimpleNamespace(index_mode="flat", load_index_path=None, passages=[jsonl], use_file_passages=False, max_passages=-1,
                                 save_index_n_shards=2 * W)
+    alltoall = store_opt == "off-alltoall"                  # the personalised all_to_all_single form of the text exchange (opt-in)
+    if alltoall:
+        store_opt = "off"
+        os.environ["ATLAS_EXCHANGE"] = "alltoall"
+    else:
+        os.environ.pop("ATLAS_EXCHANGE", None)
     if store_opt is not None:
         opt.passage_store_path = store_opt
     index, passages = index_io.load_or_initialize_index(opt)
@@ -198,9 +209,12 @@ def _default_worker(rank, W, port, out_dir, store_opt):
     for n in names:
         setattr(dist, n, real[n])
     assert docs == docs0 and scores == scores0 and all(d["text"] == f"p{d['id']}" for row in docs for d in row)
-    if store_opt == "off":
-        assert steady == {"all_gather_into_tensor": 2, "all_to_all_single": 2}, steady        # + the winners-only text exchange
+    if store_opt == "off" and alltoall:
+        assert steady == {"all_gather_into_tensor": 2, "all_to_all_single": 2}, steady        # + the winners-only text exchange, personalised
         assert first == {"all_gather_into_tensor": 2, "all_to_all_single": 2, "all_gather_object": 1}, first     # + once per slab: the smallest shard
+    elif store_opt == "off":
+        assert steady == {"all_gather_into_tensor": 2, "all_gather_object": 1}, steady        # + the text exchange in its default form (one all_gather_object)
+        assert first == {"all_gather_into_tensor": 2, "all_gather_object": 2}, first          # + once per slab: the smallest shard
     else:
         assert steady == {"all_gather_into_tensor": 2}, steady                                # queries, packed winners: nothing else
         assert first == {"all_gather_into_tensor": 2}, first                                 # (the shard sizes came with attach_passage_store)
@@ -229,12 +243,12 @@ def _default_worker(rank, W, port, out_dir, store_opt):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("store_opt", [None, "off"])
+@pytest.mark.parametrize("store_opt", [None, "off", "off-alltoall"])
 def test_default_one_host_search_is_two_collectives(store_opt, tmp_path, oracle_mod):
     """on one host the node-local passage store is the default text path (index factory; `passage_store_path="off"` opts
     out), so a search is the query gather + the packed-winner gather and nothing else; and the topk range check is collective"""
     W = 2
-    mp.spawn(_default_worker, args=(W, 29911 + (store_opt is None), str(tmp_path), store_opt), nprocs=W, join=True)
+    mp.spawn(_default_worker, args=(W, 29911 + [None, "off", "off-alltoall"].index(store_opt), str(tmp_path), store_opt), nprocs=W, join=True)
     N, k = 301, 6
     P = synth.passages_f16(N, 768, 71)
     Q = np.concatenate([synth.queries_f32(3 + r, 768, 72 + r) for r in range(W)])
