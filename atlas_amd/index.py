@@ -167,6 +167,7 @@ class HipDistributedIndex(object):
         if len(store) != total:
             raise ValueError(f"passage store holds {len(store)} passages, the index {total}: it was built from another corpus")
         self._passage_store = store
+        self._store_edits = getattr(self.doc_map, "edits", 0)      # (see search_knn: in-place doc_map edits made after this point win for this rank's own rows)
 
     # ------------------------------------------------------------------ storage
     def _device(self):
@@ -532,9 +533,20 @@ class HipDistributedIndex(object):
             # node-local passage store: ids resolve locally, no text collective at all
             mine_g, mine_s = m_gid[lo:hi], m_scores[lo:hi]
             if bool((mine_g >= 0).all()):                  # (the common case: every query has k real winners -- lists built in C)
-                return [self._passage_store.get_many(row) for row in mine_g], mine_s.astype(np.float64).tolist()
-            docs = [self._passage_store.get_many(row[row >= 0]) for row in mine_g]
-            out_scores = [[float(s) for s, g in zip(srow, grow) if g >= 0] for srow, grow in zip(mine_s, mine_g)]
+                docs = [self._passage_store.get_many(row) for row in mine_g]
+                out_scores = mine_s.astype(np.float64).tolist()
+            else:
+                docs = [self._passage_store.get_many(row[row >= 0]) for row in mine_g]
+                out_scores = [[float(s) for s, g in zip(srow, grow) if g >= 0] for srow, grow in zip(mine_s, mine_g)]
+            if getattr(self.doc_map, "edits", 0) != getattr(self, "_store_edits", 0):
+                # the store is a snapshot of the corpus taken when it was built; `doc_map` entries edited in place since then (the counter
+                # of _DocMap) win for the winners that live in THIS rank's shard -- no collective involved, so a rank that edited and one that
+                # did not stay in step. Edits made on OTHER ranks are not visible through a store: re-attach one built from the new text.
+                for drow, grow in zip(docs, mine_g):
+                    g = grow[grow >= 0]
+                    owner, local = self._gid_owner(g)
+                    for j in np.nonzero(owner == rank)[0].tolist():
+                        drow[j] = self.doc_map[int(local[j])]
             return docs, out_scores
         owner, local = self._gid_owner(np.maximum(m_gid, 0))
         # passage text: for every rank, the winners of ITS queries that live in this shard (k per query and destination, not

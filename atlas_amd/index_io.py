@@ -66,12 +66,14 @@ def _corpus_signature(opt) -> str:
     h = hashlib.sha256()
     if opt.load_index_path is not None:
         parts = ["saved", os.path.abspath(opt.load_index_path), str(opt.save_index_n_shards)]
-        parts += [str(os.path.getsize(os.path.join(opt.load_index_path, f"passages.{s}.pt"))) for s in range(opt.save_index_n_shards)]
+        for s in range(opt.save_index_n_shards):       # size AND mtime of every shard pickle: an index re-saved to the same path with equal-sized
+            st = os.stat(os.path.join(opt.load_index_path, f"passages.{s}.pt"))        # pickles must not resolve ids to the old text
+            parts += [str(st.st_size), str(st.st_mtime_ns)]
     else:
         parts = ["jsonl", str(opt.max_passages)]
         for f in opt.passages:
             st = os.stat(f)
-            parts += [os.path.abspath(f), str(st.st_size), str(int(st.st_mtime))]
+            parts += [os.path.abspath(f), str(st.st_size), str(st.st_mtime_ns)]
     h.update("\n".join(parts).encode())
     return h.hexdigest()
 
@@ -115,7 +117,9 @@ def _passage_store_path(opt, restored: bool):
     if len({h for h, _, _ in reports}) != 1:
         logger.info("ranks on %d hosts: no automatic passage store (set opt.passage_store_path to a node-local path to get one)", len({h for h, _, _ in reports}))
         return None
-    return os.path.join(reports[0][1], "atlas_amd_passages_" + _corpus_signature(opt)[:16])
+    # AUTOMATIC stores live in a per-user 0700 directory (PassageStore.private_dir) and are only reused when every file is this user's and
+    # nobody else can write to it (open_shared(require_private=True)): every rank unpickles the payload
+    return os.path.join(reports[0][1], "atlas_amd_%d" % os.getuid(), "passages_" + _corpus_signature(opt)[:16])
 
 
 def load_or_initialize_index(opt):
@@ -152,7 +156,13 @@ def load_or_initialize_index(opt):
                 return PassageStore.iter_jsonl(opt.passages, opt.max_passages)
         explicit = getattr(opt, "passage_store_path", None) is not None
         try:
-            store = PassageStore.open_shared(store_path, make, signature=_corpus_signature(opt), local_rank=getattr(opt, "local_rank", None))
+            if not explicit and PassageStore.node_local_rank(getattr(opt, "local_rank", None)) == 0:
+                try:
+                    PassageStore.private_dir(os.path.dirname(os.path.dirname(store_path)))
+                except (OSError, PassageStoreError):
+                    pass                                # (open_shared's builder fails on the missing / foreign directory and tells every rank)
+            store = PassageStore.open_shared(store_path, make, signature=_corpus_signature(opt), local_rank=getattr(opt, "local_rank", None),
+                                             require_private=not explicit)
         except PassageStoreError as e:
             if explicit:
                 raise                                   # the caller asked for a store at that path: say so (on every rank alike)

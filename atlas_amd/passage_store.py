@@ -43,6 +43,9 @@ class PassageStore:
         return int(self._off.shape[0]) - 1
 
     def get(self, gid: int) -> Optional[dict]:
+        gid = int(gid)
+        if not 0 <= gid < len(self):          # (IndexError, so that the sequence protocol -- iteration, list(store) -- terminates: ADVICE r05)
+            raise IndexError(gid)
         a, b = self._off[gid: gid + 2].tolist()
         if a == b:
             return None
@@ -54,6 +57,8 @@ class PassageStore:
     def get_many(self, gids) -> list:
         """passages of a sequence of global ids (negative id -> skipped by the caller): one offset gather for all of them"""
         gids = np.asarray(gids, dtype=np.int64)
+        if gids.size and not (0 <= int(gids.min()) and int(gids.max()) < len(self)):      # (a negative id would wrap around to the last passages)
+            raise IndexError(f"passage id outside [0, {len(self)}): {int(gids.min())} .. {int(gids.max())}")
         a, b = self._off[gids].tolist(), self._off[gids + 1].tolist()
         buf, loads = self._bin, pickle.loads
         return [None if x == y else (loads(buf[x:y]) if buf[x] == 0x80 else json.loads(buf[x:y])) for x, y in zip(a, b)]
@@ -65,15 +70,53 @@ class PassageStore:
         see a partial store."""
         offs = [0]
         tmp_bin = path + ".bin.tmp%d" % os.getpid()
-        with open(tmp_bin, "wb") as fb:
+        tmp_off = path + ".off.tmp%d.npy" % os.getpid()
+        for t in (tmp_bin, tmp_off):
+            try:
+                os.remove(t)
+            except OSError:
+                pass
+        # created exclusively, never through a symlink, readable and writable by the owner only (the payload is unpickled by every rank)
+        with os.fdopen(os.open(tmp_bin, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600), "wb") as fb:
             for it in items:
                 if it is not None:
                     fb.write(pickle.dumps(it, protocol=5))
                 offs.append(fb.tell())
-        tmp_off = path + ".off.tmp%d.npy" % os.getpid()
-        np.save(tmp_off, np.asarray(offs, dtype=np.int64))
+        with os.fdopen(os.open(tmp_off, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600), "wb") as fo:
+            np.save(fo, np.asarray(offs, dtype=np.int64))
         os.replace(tmp_bin, path + ".bin")
         os.replace(tmp_off, path + ".off.npy")
+
+    @staticmethod
+    def private_dir(base: str) -> str:
+        """<base>/atlas_amd_<uid>: the per-user directory AUTOMATIC stores live in (a predictable name directly under the world-
+        writable /dev/shm or /tmp let another local user pre-plant a store whose payload every rank would unpickle). Created 0700; refused
+        (PassageStoreError) unless it is a real directory owned by this user that nobody else can write to."""
+        import stat
+
+        d = os.path.join(base, "atlas_amd_%d" % os.getuid())
+        try:
+            os.mkdir(d, 0o700)
+        except FileExistsError:
+            pass
+        st = os.lstat(d)
+        if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o022):
+            raise PassageStoreError(f"{d} is not a directory owned by uid {os.getuid()} that only its owner can write to")
+        return d
+
+    @staticmethod
+    def is_private(path: str) -> bool:
+        """the three files of the store at `path` are regular files of THIS user that neither group nor others can write to, in a directory
+        of this user that neither group nor others can write to: what an automatic store must be before its pickles are loaded"""
+        import stat
+
+        try:
+            sts = [os.lstat(path + ext) for ext in (".bin", ".off.npy", ".meta.json")] + [os.lstat(os.path.dirname(os.path.abspath(path)))]
+        except OSError:
+            return False
+        uid = os.getuid()
+        return (all(s.st_uid == uid and not (s.st_mode & 0o022) for s in sts) and all(stat.S_ISREG(s.st_mode) for s in sts[:3])
+                and stat.S_ISDIR(sts[3].st_mode))
 
     @staticmethod
     def iter_jsonl(filenames, maxload: int = -1):
@@ -105,10 +148,14 @@ class PassageStore:
         return dist_utils.get_rank()
 
     @classmethod
-    def open_shared(cls, path: str, make_items, signature: Optional[str] = None, local_rank: Optional[int] = None) -> "PassageStore":
+    def open_shared(cls, path: str, make_items, signature: Optional[str] = None, local_rank: Optional[int] = None,
+                    require_private: bool = False) -> "PassageStore":
         """Collective. The first rank of each node builds the store from `make_items()` unless one with the same `signature`
         (what it was built from: index_io._corpus_signature) is already there; everyone maps it after a barrier. A store built from
-        another corpus / max_passages / shard count is rebuilt, never reused: its ids would resolve to the wrong text."""
+        another corpus / max_passages / shard count is rebuilt, never reused: its ids would resolve to the wrong text.
+        require_private (the AUTOMATIC stores of index_io): an existing store is reused only if `is_private` holds for it -- otherwise it is
+        rebuilt --, and every rank checks the same again before it maps and unpickles anything (PassageStoreError if not). A store at a path
+        the user chose (`opt.passage_store_path`) is trusted like the reference's own `passages.{shard}.pt` pickles."""
         meta_path = path + ".meta.json"
         failure = None
         if cls.node_local_rank(local_rank) == 0:
@@ -116,6 +163,13 @@ class PassageStore:
             #  it is caught, every rank learns of it in the one collective below, and every rank raises the same PassageStoreError)
             try:
                 fresh = os.path.exists(path + ".off.npy") and os.path.exists(path + ".bin")
+                if fresh and require_private and not cls.is_private(path):
+                    fresh = False                # somebody else's files (or writable by somebody else): never loaded, replaced by our own
+                    for ext in (".bin", ".off.npy", ".meta.json"):
+                        try:
+                            os.remove(path + ext)
+                        except OSError:
+                            pass
                 if fresh and signature is not None:
                     try:
                         with open(meta_path) as f:
@@ -131,7 +185,11 @@ class PassageStore:
                         pass
                     cls.build_from_items(path, make_items())
                     tmp = meta_path + ".tmp%d" % os.getpid()
-                    with open(tmp, "w") as f:
+                    try:
+                        os.remove(tmp)
+                    except OSError:
+                        pass
+                    with os.fdopen(os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600), "w") as f:
                         json.dump({"signature": signature, "format": FORMAT}, f)
                     os.replace(tmp, meta_path)
             except Exception as e:              # noqa: BLE001  (whatever it was: the verdict has to reach every rank)
@@ -146,6 +204,15 @@ class PassageStore:
             failure = verdicts[0] if verdicts else None
         if failure is not None:
             raise PassageStoreError(f"passage store {path} could not be built: {failure}")
+        if require_private:
+            # every rank, before it maps and unpickles: the files are this user's and nobody else can write to them. The verdict is collective
+            # (one more all_gather_object at index construction): all ranks raise, or none
+            bad = None if cls.is_private(path) else f"rank {dist_utils.get_rank()}: {path}.* is not private to uid {os.getuid()}"
+            if dist_utils.is_initialized():
+                bads = [b for b in dist_utils.all_gather_object(bad) if b is not None]
+                bad = bads[0] if bads else None
+            if bad is not None:
+                raise PassageStoreError(f"passage store {path} is not trusted: {bad}")
         return cls(path)
 
 

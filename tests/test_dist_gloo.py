@@ -189,7 +189,11 @@ def _default_worker(rank, W, port, out_dir, store_opt):
     else:
         assert index._passage_store is not None and len(index._passage_store) == N
         import tempfile
-        assert os.path.dirname(index._passage_store.path) in ("/dev/shm", tempfile.gettempdir())
+        # an AUTOMATIC store: in the per-user 0700 directory, every file private to this user
+        d = os.path.dirname(index._passage_store.path)
+        assert os.path.dirname(d) in ("/dev/shm", tempfile.gettempdir()) and os.path.basename(d) == "atlas_amd_%d" % os.getuid()
+        assert (os.stat(d).st_mode & 0o777) == 0o700 and index._passage_store.is_private(index._passage_store.path)
+        # ... and in-place doc_map edits made after the store was attached win for this rank's own rows (the store is a snapshot)
     # count every collective torch.distributed offers while a search runs
     counts = {}
     names = ["all_gather_into_tensor", "all_gather", "all_gather_object", "all_to_all_single", "all_to_all", "gather", "gather_object", "all_reduce",
@@ -218,6 +222,22 @@ def _default_worker(rank, W, port, out_dir, store_opt):
     else:
         assert steady == {"all_gather_into_tensor": 2}, steady                                # queries, packed winners: nothing else
         assert first == {"all_gather_into_tensor": 2}, first                                 # (the shard sizes came with attach_passage_store)
+    if index._passage_store is not None:
+        # the store is a snapshot; a doc_map entry edited in place AFTER it was attached wins for winners of this rank's own shard
+        # (no collective involved: a rank that edits and one that does not stay in step)
+        own = [(b, j, int(d["id"])) for b, row in enumerate(docs) for j, d in enumerate(row) if int(d["id"]) % W == rank]
+        if own:
+            b, j, g = own[0]
+            old_p = index.doc_map[g // W]
+            index.doc_map[g // W] = {"id": str(g), "title": "edited", "text": f"p{g}"}
+        docs_e, scores_e = index.search_knn(Q, k)
+        assert scores_e == scores
+        if own:
+            assert docs_e[b][j]["title"] == "edited"
+            assert [d for bb, row in enumerate(docs_e) for jj, d in enumerate(row) if int(d["id"]) != g] == \
+                   [d for bb, row in enumerate(docs) for jj, d in enumerate(row) if int(d["id"]) != g]
+            index.doc_map[g // W] = old_p
+            assert index.search_knn(Q, k)[0] == docs
     # topk beyond the SMALLEST shard (150 rows on rank 1, 151 on rank 0): every rank raises, before any collective -- nobody hangs
     counts.clear()
     for n in names:

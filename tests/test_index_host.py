@@ -280,3 +280,102 @@ def test_passage_store_payload_is_pickled_and_old_json_stores_still_read(tmp_pat
     rebuilt = PassageStore.open_shared(old, lambda: iter(items), signature="s")
     assert open(old + ".bin", "rb").read(1) == b"\x80" and [rebuilt.get(i) for i in range(3)] == items
     assert json.load(open(old + ".meta.json"))["format"] == 2
+
+
+def test_passage_store_bounds_and_sequence_protocol(tmp_path):
+    """an id outside [0, len) raises IndexError (get and get_many), so iteration over a store terminates and a negative id never wraps
+    around to the last passages"""
+    from atlas_amd.passage_store import PassageStore
+
+    items = [{"id": str(i), "text": f"t{i}"} for i in range(5)]
+    path = str(tmp_path / "s")
+    PassageStore.build_from_items(path, items)
+    st = PassageStore(path)
+    assert list(st) == items and [p["id"] for p in st] == ["0", "1", "2", "3", "4"]
+    for bad in (5, -1, 10**9):
+        with pytest.raises(IndexError):
+            st.get(bad)
+    with pytest.raises(IndexError):
+        st.get_many([0, -1])
+    with pytest.raises(IndexError):
+        st.get_many([4, 5])
+    assert st.get_many([]) == [] and st.get_many([4, 0]) == [items[4], items[0]]
+
+
+def test_automatic_passage_store_is_private_to_the_user(tmp_path):
+    """an automatic store is only reused when its three files and its directory belong to this user and nobody else can write
+    to them; a store that fails the check is never unpickled -- it is replaced by one built from the corpus"""
+    import json
+    import pickle
+    from atlas_amd.passage_store import PassageStore, PassageStoreError
+
+    base = tmp_path / "shm"
+    base.mkdir()
+    d = PassageStore.private_dir(str(base))
+    assert os.path.basename(d) == "atlas_amd_%d" % os.getuid() and (os.stat(d).st_mode & 0o777) == 0o700
+    path = os.path.join(d, "passages_abc")
+    items = [{"id": "0", "text": "real"}]
+    st = PassageStore.open_shared(path, lambda: iter(items), signature="sig", require_private=True)
+    assert st.get(0) == items[0] and PassageStore.is_private(path)
+    assert all((os.stat(path + e).st_mode & 0o077) == 0 for e in (".bin", ".off.npy", ".meta.json"))
+    # a planted store with the right signature and format whose payload is group-writable: rebuilt, its pickle never loaded
+    class Boom:
+        def __reduce__(self):
+            return (pytest.fail, ("the planted pickle was loaded",))
+    with open(path + ".bin", "wb") as f:
+        f.write(pickle.dumps(Boom(), protocol=5))
+    os.chmod(path + ".bin", 0o664)
+    assert not PassageStore.is_private(path)
+    st2 = PassageStore.open_shared(path, lambda: iter(items), signature="sig", require_private=True)
+    assert st2.get(0) == items[0] and PassageStore.is_private(path)
+    # a world-writable directory is refused outright
+    os.chmod(d, 0o777)
+    try:
+        with pytest.raises(PassageStoreError):
+            PassageStore.private_dir(str(base))
+        with pytest.raises(PassageStoreError, match="not trusted"):
+            PassageStore.open_shared(path, lambda: iter(items), signature="sig", require_private=True)
+    finally:
+        os.chmod(d, 0o700)
+    # an explicit store (a path the user chose) keeps the reference's trust model: no ownership requirement
+    ex = str(tmp_path / "explicit")
+    PassageStore.open_shared(ex, lambda: iter(items), signature="sig")
+    os.chmod(ex + ".bin", 0o664)
+    assert PassageStore.open_shared(ex, lambda: pytest.fail("rebuilt"), signature="sig").get(0) == items[0]
+
+
+def test_saved_index_signature_sees_a_resave_with_equal_sizes(tmp_path):
+    """the signature of a restored index holds every shard pickle's mtime, not only its size"""
+    import pickle
+    import types
+    from atlas_amd import index_io
+
+    for s in range(2):
+        with open(tmp_path / f"passages.{s}.pt", "wb") as f:
+            pickle.dump([{"id": str(s), "text": "aaaa"}], f)
+    opt = types.SimpleNamespace(load_index_path=str(tmp_path), save_index_n_shards=2, passages=[], max_passages=-1)
+    a = index_io._corpus_signature(opt)
+    assert a == index_io._corpus_signature(opt)
+    with open(tmp_path / "passages.1.pt", "wb") as f:
+        pickle.dump([{"id": "1", "text": "bbbb"}], f)            # same size, other text
+    st = os.stat(tmp_path / "passages.1.pt")
+    os.utime(tmp_path / "passages.1.pt", ns=(st.st_atime_ns, st.st_mtime_ns + 1_000_000))
+    assert index_io._corpus_signature(opt) != a
+
+
+def test_refresh_fingerprint_sees_a_length_changing_edit_of_any_passage():
+    """the token store of build_index_streamed is reused only while the sampled entries AND the total text length are unchanged"""
+    from atlas_amd.refresh import _passages_fingerprint
+
+    ps = [{"id": str(i), "title": "t", "text": "x" * (10 + i % 7)} for i in range(5000)]
+    f0 = _passages_fingerprint(ps)
+    assert f0 == _passages_fingerprint(ps) and _passages_fingerprint([]) == (0, 0)
+    picks = {0, 4999, *range(0, 5000, 5000 // 62)}
+    unsampled = next(i for i in range(5000) if i not in picks)
+    ps[unsampled]["text"] += "!"
+    assert _passages_fingerprint(ps) != f0
+    ps[unsampled]["text"] = ps[unsampled]["text"][:-1]
+    assert _passages_fingerprint(ps) == f0
+    ps[0]["text"] = "y" + ps[0]["text"][1:]                        # a same-length edit of a sampled entry
+    assert _passages_fingerprint(ps) != f0
+    assert _passages_fingerprint([{"id": "0"}, {"id": "1", "text": None}]) [1] == 0
