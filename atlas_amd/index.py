@@ -381,7 +381,7 @@ class HipDistributedIndex(object):
             if (d, k) not in self._warned_exact:       # same canonical result, but one fp64 slab pass per 8 queries instead of the MFMA scan
                 self._warned_exact.add((d, k))
                 logger.warning("topk=%d / d=%d is outside the fused scan (d == %d, k <= %d): whole batches take the exact path "
-                               "(~15 ms per 8 queries at 32M rows)", k, d, _lib.D_FAST, _lib.K_FAST_MAX)
+                               "(~20 ms per 8 queries at 32M rows)", k, d, _lib.D_FAST, _lib.K_FAST_MAX)
             s, i = self._exact_topk(q, k)
             self.last_search_stats = {"path": "exact"}
             return s, i, s.cpu().numpy(), i.cpu().numpy()

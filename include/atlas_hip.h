@@ -159,7 +159,7 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
  * every score is formed in the canonical double order and selection is exact. Slower than the
  * scan (fp64 VALU) but bounded: ONE slab pass scores up to 8 queries (one wave per row, the 64 chains of
  * every query reduced by the canonical tree), then a 6-pass radix select over the 48 significant key
- * bits per query -- at 32M rows ~15 ms per 8 queries. Used for queries flagged ATLAS_Q_FALLBACK, for
+ * bits per query -- at 32M rows ~20 ms per 8 queries (measured 20.4 ms, profiles/r05/bench_32m_only_kernel_stats.csv). Used for queries flagged ATLAS_Q_FALLBACK, for
  * shapes outside the fast path (d <= 8192, k <= 2048), and as the on-device cross-check in tests.
  * Workspace: 8 keys of 8 bytes per row (atlas_exact_topk_workspace_bytes).
  */
