@@ -21,12 +21,19 @@
 #   encpower       tools/refresh_power.py random zero random zero: the refresh batch with all-zero operands (same instructions, no toggling) beside the real one
 #   fullshard      BASELINE configs[3]'s per-GPU share: bench.py --refresh-full-shard 4000000 (one streamed refresh of 4M ragged passages, ~2 min), the
 #                  other legs cut short
+#   realdry        scripts/real_assets.sh on STAND-IN assets (tools/make_fake_assets.py: random weights, made-up vocabulary / corpus / queries): a dry run
+#                  of the real-asset pipeline (encoder tests with ATLAS_CONTRIEVER_DIR set, refresh incl. HF tokenisation, retrieve-only loop)
 TAG=$1; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 say() { echo "$@" | tee -a $OUT/summary.log; }
 for STEP in "$@"; do
 case $STEP in
+realdry)
+  python tools/make_fake_assets.py /tmp/fake_assets --layers 12 --passages 30000 --queries 512 > $OUT/fake_assets.log 2>&1
+  [ -f tests/golden/enc_real_fake.npz ] && export ATLAS_REAL_GOLDEN=$R/tests/golden/enc_real_fake.npz
+  ATLAS_CONTRIEVER_DIR=/tmp/fake_assets/contriever ATLAS_PASSAGES=/tmp/fake_assets/passages.jsonl ATLAS_QUERIES=/tmp/fake_assets/queries.jsonl \
+    timeout 1500 bash scripts/real_assets.sh $OUT/real_assets_dry > $OUT/real_assets_dry.log 2>&1; say "realdry rc=$?"; cat $OUT/real_assets_dry/summary.log | cut -c1-700 | tee -a $OUT/summary.log ;;
 smoke)
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; say "smoke rc=$?"; tail -1 $OUT/smoke.log | cut -c1-400 | tee -a $OUT/summary.log ;;
 pytest)
