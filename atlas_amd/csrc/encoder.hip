@@ -1799,10 +1799,14 @@ unsigned long long* g_gemm_dbg = nullptr;    // atlas_tune_set_gemm_stamps
 int g_pt_stamp_nth = 0, g_pt_launches = 0;   // atlas_tune_set_gemm_stamps_nth: only the nth gemm_pt launch from now on gets the stamp buffer
 int g_gemm_diag = 0;                         // atlas_tune_set_gemm_diag
 int g_gemm_cfg = -1;                         // atlas_tune_set_gemm_cfg: -1 = by size (what the product library always does)
+int g_att_pf = 2;                            // atlas_tune_set_att_pf: 0 = attention_kernel<.., VROW> (one workgroup per item, no prefetch); 2 / 3 = attention_pf_kernel with that many workgroups per CU
+int g_skip_ln = 0;                           // atlas_tune_set_skip_ln: 1 = the two ln_kernel launches of a layer are left out (RESULTS WRONG: the bound of any LayerNorm fusion)
 #else
 constexpr unsigned long long* g_gemm_dbg = nullptr;
 constexpr int g_gemm_diag = 0;
 constexpr int g_gemm_cfg = -1;
+constexpr int g_att_pf = 2;
+constexpr int g_skip_ln = 0;
 #endif
 
 static int encoder_device_cus() {     // CU count of the current device, asked every time (an attribute read; no cached state)
@@ -1935,7 +1939,7 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
     uint4* sK = (uint4*)smem;                                  // [Lp][8]
     const int vstride = Lp + 8;                                // halfs
     uint16_t* sVt = (uint16_t*)(sK + (size_t)Lp * 8);          // [64][Lp + 8]   (VROW: [Lp][72]: the same bytes at Lp = 64, 9 / 8.5 of them above)
-    constexpr int VPITCH = 144;                                // VROW: bytes per key row of the V tile (64 dims + 16 B: the 4 rows of a tr read hit 4 different bank windows)
+    constexpr int VPITCH = 160;                                // VROW: bytes per key row of the V tile (round 6: 160, not 144 -- 36 r mod 64 put rows 0 and 7 of a 32-lane group of the tr read on four common banks, 27 % of the kernel's LDS cycles; 40 r mod 64 covers the 64 banks exactly once)
     float* sMask = VROW ? (float*)((unsigned char*)sVt + (size_t)Lp * VPITCH) : (float*)(sVt + 64 * vstride);      // [Lp] 0 for keys < L, -inf beyond
     constexpr int QLD = VROW ? 3 * HID : 2 * HID;              // row pitch of `qk`
     const uint16_t* Qb = qk + (size_t)tb * QLD + h * DHEAD;
@@ -2137,16 +2141,17 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
                     const uint32_t va = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)sVt +
                                         (uint32_t)((32 * ks + 4 * lg + (lr >> 2)) * VPITCH + 8 * (lr & 3));
                     unsigned long long t0, t1, t2, t3, t4, t5, t6, t7;
-                    asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:2304\n\t"
-                                 "ds_read_b64_tr_b16 %2, %8 offset:32\n\tds_read_b64_tr_b16 %3, %8 offset:2336\n\t"
-                                 "ds_read_b64_tr_b16 %4, %8 offset:64\n\tds_read_b64_tr_b16 %5, %8 offset:2368\n\t"
-                                 "ds_read_b64_tr_b16 %6, %8 offset:96\n\tds_read_b64_tr_b16 %7, %8 offset:2400\n\t"
+                    asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:2560\n\t"
+                                 "ds_read_b64_tr_b16 %2, %8 offset:32\n\tds_read_b64_tr_b16 %3, %8 offset:2592\n\t"
+                                 "ds_read_b64_tr_b16 %4, %8 offset:64\n\tds_read_b64_tr_b16 %5, %8 offset:2624\n\t"
+                                 "ds_read_b64_tr_b16 %6, %8 offset:96\n\tds_read_b64_tr_b16 %7, %8 offset:2656\n\t"
                                  "s_waitcnt lgkmcnt(0)"
                                  : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7) : "v"(va) : "memory");
                     const unsigned long long tv[4][2] = {{t0, t1}, {t2, t3}, {t4, t5}, {t6, t7}};
 #pragma unroll
                     for (int df = 0; df < 4; ++df)
-                        o[df] = T::mma(pa, make_uint4((uint32_t)tv[df][0], (uint32_t)(tv[df][0] >> 32), (uint32_t)tv[df][1], (uint32_t)(tv[df][1] >> 32)), o[df]);
+                        // (round 6: operands swapped -- ctx^T = V^T . P^T, the same products over the same keys -- so that o[df][r] = ctx[query 16 qf + lr][dim 16 df + 4 lg + r])
+                        o[df] = T::mma(make_uint4((uint32_t)tv[df][0], (uint32_t)(tv[df][0] >> 32), (uint32_t)tv[df][1], (uint32_t)(tv[df][1] >> 32)), pa, o[df]);
                 } else {
 #pragma unroll
                     for (int df = 0; df < 4; ++df) {
@@ -2157,6 +2162,16 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
                 }
             }
         // context_layer.permute(0,2,1,3).view(.., 768): [token][h*64 + dim]
+        if constexpr (VROW) {                                      // four consecutive dims of one query row per lane: 4 stores of 8 bytes
+            const int row = qf * 16 + lr;
+            if (FULL || row < L) {
+                uint16_t* dst = ctx + ((size_t)tb + row) * HID + h * DHEAD + 4 * lg;
+#pragma unroll
+                for (int df = 0; df < 4; ++df)
+                    *(uint2*)(dst + df * 16) = make_uint2((uint32_t)T::st(o[df][0]) | ((uint32_t)T::st(o[df][1]) << 16),
+                                                          (uint32_t)T::st(o[df][2]) | ((uint32_t)T::st(o[df][3]) << 16));
+            }
+        } else {
 #pragma unroll
         for (int df = 0; df < 4; ++df)
 #pragma unroll
@@ -2164,6 +2179,7 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
                 const int row = qf * 16 + lg * 4 + r;
                 if (FULL || row < L) ctx[((size_t)tb + row) * HID + h * DHEAD + df * 16 + lr] = T::st(o[df][r]);
             }
+        }
     };
     const bool full = (L == Lp);                                 // workgroup-uniform
     auto run = [&](auto nkf_tag) {
@@ -2193,6 +2209,240 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
                 }
                 break;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// attention_pf_kernel (round 6): the VROW attention of the 16-bit bulk path, PERSISTENT and PREFETCHING.
+// What bounded attention_kernel<.., VROW> (96 us per layer at 512 x 128 tokens = 4.2 TB/s of its 400 MB, 12 % MFMA-busy, VALU a third of the
+// time): bytes in flight. A workgroup requested its 32 KB of K | V, waited, and only then computed; with four workgroups per CU in
+// different phases about ONE of them had loads outstanding at any time: 32 KB per CU / ~2 us = 16 GB/s per CU = 4 TB/s. Here a workgroup
+// walks its (passage, head) items -- item = blockIdx + i * gridDim, so neighbouring workgroups read neighbouring heads of one passage's
+// q | k | v rows -- and requests the NEXT item's K | V chunks into registers right after the current item's tile went to LDS: the loads are in
+// flight for the whole of the current item's arithmetic, every resident workgroup has 32 KB outstanding all the time. The barriers are
+// `s_waitcnt lgkmcnt(0); s_barrier` (what LDS visibility needs), not __syncthreads (whose fence also drains vmcnt: the prefetch and the
+// query loads must stay in flight across them).
+// Also: the V tile's row pitch is 160 B (144 B put rows 0 and 7 of a 32-lane group of `ds_read_b64_tr_b16` on four common banks: 27 % of the
+// kernel's LDS cycles were conflicts; 40 r mod 64 covers the 64 banks with 8 rows of 8 banks exactly once), and P.V runs with the MFMA operands
+// swapped -- ctx^T = V^T . P^T, the same products summed over the same keys -- so that a lane ends up with FOUR CONSECUTIVE dims of one
+// query row: 4 stores of 8 bytes per query fragment instead of 16 of 2 bytes (with their 16 address computations).
+// Arithmetic per element is that of attention_kernel, in the same order: embeddings are bit-identical (tests/test_gpu_encoder.py).
+// ------------------------------------------------------------------------------------------
+#define ATT_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+template <class T, int MAXKF, int WPC>
+__global__ void __launch_bounds__(256, WPC)                     // WPC workgroups per CU: the registers must leave room for them (3: 168 VGPRs, 2: 256)
+attention_pf_kernel(const uint16_t* __restrict__ qkv, const int* __restrict__ cu, const int nitems, const int LpMax, uint16_t* __restrict__ ctx) {
+    static_assert(MAXKF == 8, "longer passages keep attention_kernel<T, MAXKF, true> (the prefetch of Lp / 16 chunks per thread does not fit their registers)");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int VPITCH = 160, QLD = 3 * HID;
+    constexpr int NCH = MAXKF / 2;                             // 16-byte chunks of K (and of V) per thread: MAXKF * 16 keys x 8 chunks / 256 threads
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    uint4* const sK = (uint4*)smem;                            // [LpMax][8], chunk c of key r at c ^ (r & 7)
+    unsigned char* const sV = smem + (size_t)LpMax * 128;      // [LpMax] key rows of 64 dims at a 160-byte pitch
+    float* const sMask = (float*)(sV + (size_t)LpMax * VPITCH);
+
+    uint4 kv[NCH], vv[NCH];
+    // the K | V chunks of `item`, requested and not waited for (keys past the passage's end are clamped: they are zeroed on their way to LDS)
+    auto request = [&](const int item) {
+        const int b = item / NHEAD, h = item - b * NHEAD;
+        const int tb = cu[b], L = cu[b + 1] - tb;
+        if (L <= 0) return;
+        const int Lp8 = ((L + 31) & ~31) * 8;
+        const uint16_t* Kb = qkv + (size_t)tb * QLD + HID + h * DHEAD;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            if (i * 256 >= Lp8) break;                          // workgroup-uniform
+            const int idx = i * 256 + tid, key = idx >> 3, ch = idx & 7;
+            const uint16_t* src = Kb + (size_t)(key < L ? key : L - 1) * QLD + ch * 8;
+            kv[i] = *(const uint4*)src;
+            vv[i] = *(const uint4*)(src + HID);
+        }
+    };
+    int item = blockIdx.x;
+    if (item >= nitems) return;
+    request(item);
+    for (; item < nitems; item += gridDim.x) {
+        const int b = item / NHEAD, h = item - b * NHEAD;
+        const int tb = cu[b], L = cu[b + 1] - tb;
+        const int nxt = item + gridDim.x;
+        if (L <= 0) {                                           // (an all-masked passage: nothing to compute; workgroup-uniform, no barrier skipped unevenly)
+            if (nxt < nitems) request(nxt);
+            continue;
+        }
+        const int Lp = (L + 31) & ~31, nkf = Lp / 16;
+        const uint16_t* Qb = qkv + (size_t)tb * QLD + h * DHEAD;
+        auto load_q = [&](const int qf, uint4& qa, uint4& qb) {
+            int qrow = qf * 16 + lr; if (qrow >= L) qrow = L - 1;
+            qa = *(const uint4*)(Qb + (size_t)qrow * QLD + lg * 8);
+            qb = *(const uint4*)(Qb + (size_t)qrow * QLD + 32 + lg * 8);
+        };
+        // this wave's first two query fragments: requested BEFORE the next item's prefetch, so that waiting for them never waits for it
+        uint4 qa0 = make_uint4(0, 0, 0, 0), qa1 = qa0, qb0 = qa0, qb1 = qa0;
+        if (wave * 16 < L) load_q(wave, qa0, qa1);
+        if ((wave + 4) * 16 < L) load_q(wave + 4, qb0, qb1);
+        // the tile of THIS item: registers -> LDS
+        for (int j = tid; j < Lp; j += 256) sMask[j] = (j < L) ? 0.0f : -__builtin_inff();
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            if (i * 256 >= Lp * 8) break;
+            const int idx = i * 256 + tid, key = idx >> 3, ch = idx & 7;
+            const bool real = key < L;
+            sK[key * 8 + (ch ^ (key & 7))] = real ? kv[i] : make_uint4(0, 0, 0, 0);
+            *(uint4*)(sV + key * VPITCH + ch * 16) = real ? vv[i] : make_uint4(0, 0, 0, 0);
+        }
+        ATT_LDS_BARRIER();
+        if (nxt < nitems) request(nxt);                         // in flight under everything below
+
+        auto fragment = [&](const int qf, const uint4 q0, const uint4 q1, auto nkf_tag, auto full_tag) {
+            constexpr int NKF = decltype(nkf_tag)::value;
+            asm volatile("" ::: "memory");
+            constexpr bool FULL = decltype(full_tag)::value;
+            f4 s[NKF];
+#pragma unroll
+            for (int kf = 0; kf < NKF; ++kf) {
+                const int krow = kf * 16 + lr;
+                const uint4 k0 = sK[krow * 8 + (lg ^ (krow & 7))];
+                const uint4 k1 = sK[krow * 8 + ((4 + lg) ^ (krow & 7))];
+                s[kf] = T::mma(k0, q0, (f4){0.f, 0.f, 0.f, 0.f});
+                s[kf] = T::mma(k1, q1, s[kf]);
+            }
+            uint32_t pk[NKF][2];
+            if constexpr (T::DT == ATLAS_DT_F16) {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                h2 v[NKF][2];
+                h2 mx2 = {(_Float16)(-__builtin_inff()), (_Float16)(-__builtin_inff())};
+#pragma unroll
+                for (int kf = 0; kf < NKF; ++kf)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        h2 x = {(_Float16)s[kf][2 * e], (_Float16)s[kf][2 * e + 1]};
+                        x = x * (h2){(_Float16)0.125f, (_Float16)0.125f};
+                        if (!FULL) {
+                            const float2 am = *(const float2*)(sMask + kf * 16 + lg * 4 + 2 * e);
+                            x = x + (h2){(_Float16)am.x, (_Float16)am.y};
+                        }
+                        v[kf][e] = x;
+                        mx2 = __builtin_elementwise_max(mx2, x);
+                    }
+                float mx = fmaxf((float)mx2.x, (float)mx2.y);
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float nmx = -mx * 1.4426950408889634f;
+                f2 ex[NKF][2];
+                f2 sum2 = {0.f, 0.f};
+#pragma unroll
+                for (int kf = 0; kf < NKF; ++kf)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const f2 ee = {__builtin_amdgcn_exp2f(__builtin_fmaf((float)v[kf][e].x, 1.4426950408889634f, nmx)),
+                                       __builtin_amdgcn_exp2f(__builtin_fmaf((float)v[kf][e].y, 1.4426950408889634f, nmx))};
+                        ex[kf][e] = ee;
+                        sum2 += ee;
+                    }
+                float sum = sum2.x + sum2.y;
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int kf = 0; kf < NKF; ++kf)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const f2 pe = ex[kf][e] * (f2){inv, inv};
+                        const h2 ph = {(_Float16)pe.x, (_Float16)pe.y};
+                        pk[kf][e] = __builtin_bit_cast(uint32_t, ph);
+                    }
+            } else {
+                float mx = -__builtin_inff();
+#pragma unroll
+                for (int kf = 0; kf < NKF; ++kf) {
+                    const float4 am = *(const float4*)(sMask + kf * 16 + lg * 4);
+                    const float a4[4] = {am.x, am.y, am.z, am.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float vv_ = T::rnd(T::rnd(s[kf][r]) * 0.125f + a4[r]);
+                        s[kf][r] = vv_;
+                        mx = fmaxf(mx, vv_);
+                    }
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float sum = 0.f;
+#pragma unroll
+                for (int kf = 0; kf < NKF; ++kf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __expf(s[kf][r] - mx);
+                        s[kf][r] = e;
+                        sum += e;
+                    }
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int kf = 0; kf < NKF; ++kf)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        pk[kf][e] = (uint32_t)T::st(s[kf][2 * e] * inv) | ((uint32_t)T::st(s[kf][2 * e + 1] * inv) << 16);
+            }
+            // ctx^T = V^T . P^T: o[df][r] = ctx[query 16 qf + lr][dim 16 df + 4 lg + r]
+            f4 o[4];
+#pragma unroll
+            for (int df = 0; df < 4; ++df) o[df] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKF / 2; ++ks) {
+                const uint4 pa = make_uint4(pk[2 * ks][0], pk[2 * ks][1], pk[2 * ks + 1][0], pk[2 * ks + 1][1]);
+                const uint32_t va = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)sV +
+                                    (uint32_t)((32 * ks + 4 * lg + (lr >> 2)) * VPITCH + 8 * (lr & 3));
+                unsigned long long t0, t1, t2, t3, t4, t5, t6, t7;
+                asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:2560\n\t"
+                             "ds_read_b64_tr_b16 %2, %8 offset:32\n\tds_read_b64_tr_b16 %3, %8 offset:2592\n\t"
+                             "ds_read_b64_tr_b16 %4, %8 offset:64\n\tds_read_b64_tr_b16 %5, %8 offset:2624\n\t"
+                             "ds_read_b64_tr_b16 %6, %8 offset:96\n\tds_read_b64_tr_b16 %7, %8 offset:2656\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7) : "v"(va) : "memory");
+                const unsigned long long tv[4][2] = {{t0, t1}, {t2, t3}, {t4, t5}, {t6, t7}};
+#pragma unroll
+                for (int df = 0; df < 4; ++df)
+                    o[df] = T::mma(make_uint4((uint32_t)tv[df][0], (uint32_t)(tv[df][0] >> 32), (uint32_t)tv[df][1], (uint32_t)(tv[df][1] >> 32)), pa, o[df]);
+            }
+            const int row = qf * 16 + lr;
+            if (FULL || row < L) {
+                uint16_t* dst = ctx + ((size_t)tb + row) * HID + h * DHEAD + 4 * lg;
+#pragma unroll
+                for (int df = 0; df < 4; ++df)
+                    *(uint2*)(dst + df * 16) = make_uint2((uint32_t)T::st(o[df][0]) | ((uint32_t)T::st(o[df][1]) << 16),
+                                                          (uint32_t)T::st(o[df][2]) | ((uint32_t)T::st(o[df][3]) << 16));
+            }
+        };
+        const bool full = (L == Lp);
+        auto run = [&](auto nkf_tag) {
+            for (int qf = wave; qf * 16 < L; qf += 4) {
+                const uint4 q0 = qa0, q1 = qa1;
+                qa0 = qb0; qa1 = qb1;
+                if ((qf + 8) * 16 < L) load_q(qf + 8, qb0, qb1);
+                if (full) fragment(qf, q0, q1, nkf_tag, std::true_type{});
+                else fragment(qf, q0, q1, nkf_tag, std::false_type{});
+            }
+        };
+        switch (nkf) {                                           // Lp is a multiple of 32: nkf is even
+            case 2: run(std::integral_constant<int, 2>{}); break;
+            case 4: run(std::integral_constant<int, 4>{}); break;
+            case 6: run(std::integral_constant<int, 6>{}); break;
+            case 8: run(std::integral_constant<int, 8>{}); break;
+            default:
+                if constexpr (MAXKF > 8) {
+                    switch (nkf) {
+                        case 10: run(std::integral_constant<int, 10>{}); break;
+                        case 12: run(std::integral_constant<int, 12>{}); break;
+                        case 14: run(std::integral_constant<int, 14>{}); break;
+                        default: run(std::integral_constant<int, 16>{}); break;
+                    }
+                }
+                break;
+        }
+        ATT_LDS_BARRIER();                                       // every wave is done with this item's tile before the next one overwrites it
     }
 }
 
@@ -2375,13 +2625,29 @@ int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int
             // (the persistent bulk GEMM -- cfg 9, 16-bit -- left q | k | v row-major in [M, 2304] starting at `qk`: the V^T region behind it is
             //  part of that buffer then; every other configuration keeps q | k [M, 1536] + V^T)
             const bool vrow = (cfg == 9);
-            const size_t att_lds = vrow ? (size_t)Lp * 128 + (size_t)Lp * 144 + (size_t)Lp * 4
+            const size_t att_lds = vrow ? (size_t)Lp * 128 + (size_t)Lp * 160 + (size_t)Lp * 4
                                         : (size_t)Lp * 128 + (size_t)64 * (Lp + 8) * 2 + (size_t)Lp * 4;
             auto att = [&](auto kern) {
                 (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 hipLaunchKernelGGL(kern, dim3((unsigned)n * NHEAD), dim3(256), att_lds, stream, qk, vt, cu, LpS, ctx);
             };
-            if (vrow) {
+            if (vrow && Lp <= 128 && g_att_pf) {
+                // round 6: persistent, prefetching (attention_pf_kernel) for batches of up to 128 tokens per passage; longer passages keep one
+                // workgroup per item (their prefetch does not fit the registers). g_att_pf (tuning build): 2 / 3 = workgroups per CU
+                const int nitems = n * NHEAD;
+                const size_t pf_lds = (size_t)Lp * (128 + 160 + 4);
+                const int per_cu = g_att_pf == 3 ? 3 : 2;
+                int grid = encoder_device_cus() * per_cu;
+                if (grid > nitems) grid = nitems;
+                auto attp = [&](auto kern) {
+                    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), pf_lds, stream, (const uint16_t*)qk, cu, nitems, Lp, (uint16_t*)ctx);
+                };
+#if ATLAS_TUNING
+                if (per_cu == 3) attp(attention_pf_kernel<T, 8, 3>); else
+#endif
+                attp(attention_pf_kernel<T, 8, 2>);
+            } else if (vrow) {
                 if (Lp <= 128) att(attention_kernel<T, 8, true>);
                 else if (Lp <= 256) att(attention_kernel<T, 16, true>);
                 else att(attention_kernel<T, 32, true>);
@@ -2390,12 +2656,14 @@ int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int
             else att(attention_kernel<T, 32>);
         }
         launch_gemm<T, 2>(cfg, stream, ctx, (const E*)ly.o_w, (const E*)ly.o_b, x, u, (E*)nullptr, M, cu, n, tokinfo, HID, HID, Lp);
+        if (!g_skip_ln)
         hipLaunchKernelGGL(ln_kernel<T>, dim3(tok_blocks), dim3(256), 0, stream, u, cu + n, (const E*)ly.ln1_w, (const E*)ly.ln1_b,
                            w->eps, x);
         launch_gemm<T, 1>(cfg, stream, x, (const E*)ly.ff1_w, (const E*)ly.ff1_b, (const E*)nullptr, hbuf, (E*)nullptr, M, cu, n,
                           tokinfo, 4 * HID, HID, Lp);
         launch_gemm<T, 2>(cfg, stream, hbuf, (const E*)ly.ff2_w, (const E*)ly.ff2_b, x, u, (E*)nullptr, M, cu, n, tokinfo, HID,
                           4 * HID, Lp);
+        if (!g_skip_ln)
         hipLaunchKernelGGL(ln_kernel<T>, dim3(tok_blocks), dim3(256), 0, stream, u, cu + n, (const E*)ly.ln2_w, (const E*)ly.ln2_b,
                            w->eps, x);
     }
@@ -2413,6 +2681,8 @@ void atlas_tune_set_gemm_stamps(unsigned long long* p) { g_gemm_dbg = p; g_pt_st
 void atlas_tune_set_gemm_stamps_nth(unsigned long long* p, int nth) { g_gemm_dbg = p; g_pt_stamp_nth = nth; g_pt_launches = 0; }
 void atlas_tune_set_gemm_diag(int d) { g_gemm_diag = d; }
 void atlas_tune_set_gemm_cfg(int c) { g_gemm_cfg = c; }
+void atlas_tune_set_att_pf(int v) { g_att_pf = v; }
+void atlas_tune_set_skip_ln(int v) { g_skip_ln = v; }
 #endif
 
 size_t atlas_contriever_workspace_bytes(int n, int L, int dtype) {
