@@ -88,6 +88,23 @@ class _SmiSampler:
                 "watts_max": float(np.max(pw)), "sclk_mhz_mean": float(np.mean(sc)) if sc else None, "sclk_mhz_min": float(np.min(sc)) if sc else None}
 
 
+class _StdoutToStderr:
+    """fd 1 -> fd 2 while a process group comes up: RCCL prints a version banner ("RCCL version : ...", 5 lines) straight to the process's stdout
+    when its first communicator is created; the bench's stdout carries ONE JSON line and nothing else"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def _free_port() -> int:
     import socket
 
@@ -213,10 +230,14 @@ def main():
     dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
-        else:
-            dist.init_process_group(backend)
+        with _StdoutToStderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+                t_ = torch.zeros(1, device=dev)
+                dist.all_reduce(t_)                                # (the communicator -- and RCCL's banner -- come with the first collective)
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group(backend)
 
     from atlas_amd import HipDistributedIndex, _lib
 
@@ -653,11 +674,13 @@ def main():
                     own_group = not dist.is_initialized()
                     if own_group:
                         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-                        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
                     g1 = torch.empty((B, k), dtype=torch.int64, device=dev)
-                    for _ in range(5):
-                        dist.all_gather_into_tensor(g1, packed_e)
-                    fence()
+                    with _StdoutToStderr():
+                        if own_group:
+                            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+                        for _ in range(5):
+                            dist.all_gather_into_tensor(g1, packed_e)
+                        fence()
                     ea, eb_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     n_ag = 200
                     tg = time.perf_counter()
@@ -694,7 +717,7 @@ def main():
                         "what": "world-size-1 RCCL all_gather_into_tensor of %d bytes on the bench stream (launch path only: one rank has no peer, no xGMI transfer, no protocol)" % (B * k * 8),
                         "all_gather_us_back_to_back": ag_us, "host_enqueue_us": t_enq * 1e6, "calls": n_ag, "emulated_w": W_e,
                         "ms_per_step_with_it": dtr_ * 1e3, "step_frac_with_it": n_0 * D * 2 / dtr_ / 1e9 / HBM_PEAK_GBS,
-                        "added_to_the_step_us": (dtr_ - dte) * 1e3,
+                        "added_to_the_step_us": (dtr_ - dte) * 1e6,
                         "budget_us_to_stay_at_0p70": (n_0 * D * 2 / (0.70 * HBM_PEAK_GBS * 1e9) - dte) * 1e6,
                         "projected": "W = %d step >= this (+ one xGMI hop of %d bytes per peer and RCCL's W-rank protocol, unmeasured)" % (W_e, B * k * 8)}
                 except Exception as e:                                   # noqa: BLE001  (a diagnostic leg never takes the line down)
