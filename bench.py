@@ -178,6 +178,11 @@ def main():
     ap.add_argument("--exchange", choices=("rccl", "peer"), default="rccl",
                     help="N > 1: how the ranks' packed winners meet -- one RCCL all-gather + merge (default), or the peer-mapped exchange buffers "
                          "(atlas_xchg_*: push kernel + waiting merge kernel, no collective; experimental, never run across two devices)")
+    ap.add_argument("--overlap-exchange", choices=("on", "off"), default="on",
+                    help="N > 1 (RCCL exchange): 'on' = the cross-rank exchange of step i (all-gather of the packed winners + W x k -> k merge) runs on a SECOND HIP "
+                         "stream under the scan of step i + 1 (double-buffered packed / gathered buffers, event hand-offs both ways): the steps of a search "
+                         "service are independent batches, and the collective's ~28 us launch path (measured with a world-size-1 RCCL group, scale_emulated) "
+                         "otherwise sits between two scans; 'off' = everything on one stream, step after step. detail.hops times the hops serialised either way")
     ap.add_argument("--emulate-ranks", type=str, default="2,4,8",
                     help="N=1 only: the per-GPU step of a W-GPU run of the same corpus on ONE GPU -- scan of a 1/W contiguous shard with packed winners "
                          "+ the device W x k -> k merge of all W shards' winners (scanned once, outside the timed region); labelled 'emulated, no RCCL' "
@@ -314,9 +319,43 @@ def main():
             dist.all_gather_into_tensor(hq_, q_own.cpu())
             q.copy_(hq_)
 
+    # the exchange of step i under the scan of step i + 1 (--overlap-exchange): a second stream, two sets of exchange buffers
+    overlap = world > 1 and px is None and args.overlap_exchange == "on"
+    step_no = [0]
+    mode = {"overlap": overlap}
+    if overlap:
+        side = torch.cuda.Stream(dev)
+        main_s = torch.cuda.current_stream(dev)
+        packed_b = [packed, torch.empty_like(packed)]
+        gathered_b = [gathered, torch.empty_like(gathered)]
+        ev_scanned = [torch.cuda.Event(), torch.cuda.Event()]
+        ev_exchanged = [torch.cuda.Event(), torch.cuda.Event()]
+
     def step(ev=None):
         eb = ev[0].cuda_event if ev else None
         ee = ev[1].cuda_event if ev else None
+        if mode["overlap"]:
+            slot = step_no[0] & 1
+            step_no[0] += 1
+            if distinct:
+                gather_queries()
+            main_s.wait_event(ev_exchanged[slot])                       # step i - 2's exchange has read this slot's packed winners (no-op the first two times)
+            rc = L.atlas_scan_topk_pack(q.data_ptr(), q_code, slab.data_ptr(), rows, B, D, k, pmax, out_s.data_ptr(), out_i.data_ptr(), out_st.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), stream, eb, ee, _lib.SCAN_TRUST_PMAX, world, rank, packed_b[slot].data_ptr())
+            assert rc == 0, rc
+            ev_scanned[slot].record(main_s)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_scanned[slot])
+                if backend == "nccl":
+                    dist.all_gather_into_tensor(gathered_b[slot], packed_b[slot])
+                else:                                                   # gloo logic check: staged through the host
+                    hg = torch.empty((world * B, k), dtype=torch.int64)
+                    dist.all_gather_into_tensor(hg, packed_b[slot].cpu())
+                    gathered_b[slot].copy_(hg)
+                rc = L.atlas_merge_packed(gathered_b[slot].data_ptr(), world, B, k, merged.data_ptr(), side.cuda_stream)
+                assert rc == 0, rc
+                ev_exchanged[slot].record(side)
+            return
         # the call of HipDistributedIndex._local_topk: pmax was measured by the product call above (atlas_slab_pmax) and nothing has
         # written to the slab since, so the scan takes it as certified (ATLAS_SCAN_TRUST_PMAX) instead of re-measuring every row's norm
         # (N > 1: the merge kernel emits the packed (score, global id) pairs itself -- global id = row * world + rank -- so the scan is followed
@@ -368,10 +407,27 @@ def main():
     if world > 1 and px is not None:
         assert int(px_bad.item()) == 0, "peer exchange: a rank was late in the timed region"
         dist.all_gather_into_tensor(gathered, packed)                   # (outside the timed region: what the merge must equal)
+    if overlap:                                                         # (the last step's slot holds what `merged` was formed from)
+        last = (step_no[0] - 1) & 1
+        packed, gathered = packed_b[last], gathered_b[last]
     if world > 1:
         from atlas_amd.index import merge_packed_host
         want = merge_packed_host(gathered.view(world, B, k).cpu().numpy(), k)
         assert np.array_equal(merged.cpu().numpy(), want), "device W*k merge disagrees with the host merge"
+
+    # ... and the same K steps with the exchange on the scan's stream, step after step: what the overlap is worth
+    ms_serial = None
+    if overlap:
+        mode["overlap"] = False
+        for _ in range(max(2, args.warmup)):
+            step()
+        fence()
+        ts_ = time.perf_counter()
+        for it in range(args.steps):
+            step()
+        fence()
+        ms_serial = reduce_max(time.perf_counter() - ts_) / args.steps * 1e3
+        assert np.array_equal(merged.cpu().numpy(), want), "serialised exchange disagrees with the overlapped one"
 
     # N > 1: where a step's time goes, hop by hop (hipEvents on the launch stream, a separate pass of the same steps): the scan + merge on this
     # rank's shard, the all-gather of the packed winners, the W x k -> k merge. The all-gather + merge budget that keeps an 8-GPU step at
@@ -710,6 +766,34 @@ def main():
                     fence()
                     dtr_ = (time.perf_counter() - te) / steps_e
                     assert np.array_equal(merged_e.cpu().numpy(), want_packed)
+                    # the same with the exchange of step i on a SECOND stream under the scan of step i + 1 (what --overlap-exchange does at N > 1)
+                    side_e, main_e = torch.cuda.Stream(dev), torch.cuda.current_stream(dev)
+                    pk2, ga2 = [packed_e, torch.empty_like(packed_e)], [gathered_e, gathered_e.clone()]
+                    ev_a, ev_b = [torch.cuda.Event(), torch.cuda.Event()], [torch.cuda.Event(), torch.cuda.Event()]
+
+                    def e_step_pipe(i):
+                        sl = i & 1
+                        main_e.wait_event(ev_b[sl])
+                        rc = L.atlas_scan_topk_pack(q.data_ptr(), q_code, slab.data_ptr(), n_0, B, D, k, pmax, out_s.data_ptr(), out_i.data_ptr(), out_st.data_ptr(),
+                                                    ws_0.data_ptr(), ws_0.numel(), stream, None, None, _lib.SCAN_TRUST_PMAX, 1, 0, pk2[sl].data_ptr())
+                        assert rc == 0, rc
+                        ev_a[sl].record(main_e)
+                        with torch.cuda.stream(side_e):
+                            side_e.wait_event(ev_a[sl])
+                            dist.all_gather_into_tensor(ga2[sl][:B], pk2[sl])
+                            rc = L.atlas_merge_packed(ga2[sl].data_ptr(), W_e, B, k, merged_e.data_ptr(), side_e.cuda_stream)
+                            assert rc == 0, rc
+                            ev_b[sl].record(side_e)
+
+                    for i_ in range(max(args.warmup, 6)):
+                        e_step_pipe(i_)
+                    fence()
+                    te = time.perf_counter()
+                    for i_ in range(steps_e):
+                        e_step_pipe(i_)
+                    fence()
+                    dtp_ = (time.perf_counter() - te) / steps_e
+                    assert np.array_equal(merged_e.cpu().numpy(), want_packed) and int(out_st.cpu()[_lib.ST_FLAGS]) == 0
                     if own_group:
                         dist.destroy_process_group()
                     scale_emulated["rccl_w1_all_gather_us"] = ag_us
@@ -718,6 +802,8 @@ def main():
                         "all_gather_us_back_to_back": ag_us, "host_enqueue_us": t_enq * 1e6, "calls": n_ag, "emulated_w": W_e,
                         "ms_per_step_with_it": dtr_ * 1e3, "step_frac_with_it": n_0 * D * 2 / dtr_ / 1e9 / HBM_PEAK_GBS,
                         "added_to_the_step_us": (dtr_ - dte) * 1e6,
+                        "ms_per_step_overlapped": dtp_ * 1e3, "step_frac_overlapped": n_0 * D * 2 / dtp_ / 1e9 / HBM_PEAK_GBS,
+                        "overlapped": "the all-gather + W x k -> k merge of step i on a second HIP stream under the scan of step i + 1 (bench.py --overlap-exchange on, the N > 1 default)",
                         "budget_us_to_stay_at_0p70": (n_0 * D * 2 / (0.70 * HBM_PEAK_GBS * 1e9) - dte) * 1e6,
                         "projected": "W = %d step >= this (+ one xGMI hop of %d bytes per peer and RCCL's W-rank protocol, unmeasured)" % (W_e, B * k * 8)}
                 except Exception as e:                                   # noqa: BLE001  (a diagnostic leg never takes the line down)
@@ -1008,6 +1094,8 @@ def main():
             flat_refresh["rccl_w1_all_gather_us"] = r1.get("all_gather_us_back_to_back")
             flat_refresh["emulated_w8_with_rccl_w1_ms_per_step"] = r1.get("ms_per_step_with_it")
             flat_refresh["emulated_w8_with_rccl_w1_step_frac"] = r1.get("step_frac_with_it")
+            flat_refresh["emulated_w8_with_rccl_w1_overlapped_ms_per_step"] = r1.get("ms_per_step_overlapped")
+            flat_refresh["emulated_w8_with_rccl_w1_overlapped_step_frac"] = r1.get("step_frac_overlapped")
         if shard_sweep is not None:
             for n_, v_ in shard_sweep.items():
                 flat_refresh["shard_%s_step_frac" % n_] = v_["step_frac"]
@@ -1091,6 +1179,9 @@ def main():
                 "search_knn_queries_per_s": (world * Bq / (knn_ms * 1e-3)) if knn_ms else None,
                 "search_knn_note": "synchronous product call incl. host lists; at N > 1 every rank submits its own 64 queries (N x 64 per call)", "candidates_per_search": stats0.get("candidates"),
                 "hops": hops, "plan": stats0.get("plan"),
+                "exchange_overlapped": bool(overlap), "ms_per_step_serialized": ms_serial,
+                "exchange_note": ("the all-gather + W x k -> k merge of step i run on a second HIP stream under the scan of step i + 1 (--overlap-exchange on); "
+                                  "`hops` times them serialised") if overlap else ("one stream, step after step" if world > 1 else None),
                 "rescored_per_search": stats0.get("rescored"), "max_err_over_eps": stats0.get("max_err_over_eps"),
                 "build": L.atlas_build_info().decode(),
                 "pmax": {"value": pmax, "how": "atlas_slab_pmax once per state of the slab (torch version counter); the timed scans take it as certified "
