@@ -1799,13 +1799,13 @@ unsigned long long* g_gemm_dbg = nullptr;    // atlas_tune_set_gemm_stamps
 int g_pt_stamp_nth = 0, g_pt_launches = 0;   // atlas_tune_set_gemm_stamps_nth: only the nth gemm_pt launch from now on gets the stamp buffer
 int g_gemm_diag = 0;                         // atlas_tune_set_gemm_diag
 int g_gemm_cfg = -1;                         // atlas_tune_set_gemm_cfg: -1 = by size (what the product library always does)
-int g_att_pf = 2;                            // atlas_tune_set_att_pf: 0 = attention_kernel<.., VROW> (one workgroup per item, no prefetch); 2 / 3 = attention_pf_kernel with that many workgroups per CU
+int g_att_pf = 0;                            // atlas_tune_set_att_pf: 0 = attention_kernel<.., VROW> (one workgroup per item, no prefetch); 2 / 3 = attention_pf_kernel with that many workgroups per CU
 int g_skip_ln = 0;                           // atlas_tune_set_skip_ln: 1 = the two ln_kernel launches of a layer are left out (RESULTS WRONG: the bound of any LayerNorm fusion)
 #else
 constexpr unsigned long long* g_gemm_dbg = nullptr;
 constexpr int g_gemm_diag = 0;
 constexpr int g_gemm_cfg = -1;
-constexpr int g_att_pf = 2;
+constexpr int g_att_pf = 0;
 constexpr int g_skip_ln = 0;
 #endif
 
@@ -2212,6 +2212,7 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
     }
 }
 
+#if ATLAS_TUNING   // (measured and NOT adopted: the tuning build keeps it for the A/B of tools/enc_knob_ab.py, profiles/r06/enc_knob_ab.txt)
 // ------------------------------------------------------------------------------------------
 // attention_pf_kernel (round 6): the VROW attention of the 16-bit bulk path, PERSISTENT and PREFETCHING.
 // What bounded attention_kernel<.., VROW> (96 us per layer at 512 x 128 tokens = 4.2 TB/s of its 400 MB, 12 % MFMA-busy, VALU a third of the
@@ -2446,6 +2447,8 @@ attention_pf_kernel(const uint16_t* __restrict__ qkv, const int* __restrict__ cu
     }
 }
 
+#endif
+
 // fp32 model precision (query embedding with --precision fp32, atlas.py:104): same S^T trick with v_mfma 16x16x4 f32.
 // After S^T = K.Q^T lane (lr, lg) holds query lr x keys 16kf+4lg+r; taking the contraction index of P.V step (kf, r)
 // as lane group lg <-> key 16kf+4lg+r makes those registers the A operand as they are, and the B operand
@@ -2631,6 +2634,7 @@ int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int
                 (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 hipLaunchKernelGGL(kern, dim3((unsigned)n * NHEAD), dim3(256), att_lds, stream, qk, vt, cu, LpS, ctx);
             };
+#if ATLAS_TUNING
             if (vrow && Lp <= 128 && g_att_pf) {
                 // round 6: persistent, prefetching (attention_pf_kernel) for batches of up to 128 tokens per passage; longer passages keep one
                 // workgroup per item (their prefetch does not fit the registers). g_att_pf (tuning build): 2 / 3 = workgroups per CU
@@ -2643,11 +2647,10 @@ int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int
                     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), pf_lds, stream, (const uint16_t*)qk, cu, nitems, Lp, (uint16_t*)ctx);
                 };
-#if ATLAS_TUNING
-                if (per_cu == 3) attp(attention_pf_kernel<T, 8, 3>); else
+                if (per_cu == 3) attp(attention_pf_kernel<T, 8, 3>); else attp(attention_pf_kernel<T, 8, 2>);
+            } else
 #endif
-                attp(attention_pf_kernel<T, 8, 2>);
-            } else if (vrow) {
+            if (vrow) {
                 if (Lp <= 128) att(attention_kernel<T, 8, true>);
                 else if (Lp <= 256) att(attention_kernel<T, 16, true>);
                 else att(attention_kernel<T, 32, true>);
