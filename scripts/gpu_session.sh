@@ -18,6 +18,7 @@
 #   host           tools/host_overhead.py 1M 4M
 #   refatlas       tests/test_gpu_reference_atlas.py (needs .refstage/: scripts/stage_reference.sh in the build container)
 #   gloo2          two ranks on one GPU over gloo: bench.py --gpus 2 logic check, replicated and --distinct-queries
+#   libab_enc / libab_scan   tools/lib_ab.py enc | scan on BUILDS of the library ($LIBAB, default tools/ab/r05.so vs tools/ab/r06.so: scripts/build_variant.sh)
 #   enc_knob       tools/enc_knob_ab.py: attention kernels (round 5 | persistent prefetching, 2 / 3 workgroups per CU) and the no-LayerNorm bound, ms + W + mJ per passage
 #   encpower       tools/refresh_power.py random zero random zero: the refresh batch with all-zero operands (same instructions, no toggling) beside the real one
 #   fullshard      BASELINE configs[3]'s per-GPU share: bench.py --refresh-full-shard 4000000 (one streamed refresh of 4M ragged passages, ~2 min), the
@@ -105,6 +106,10 @@ gloo2)
     ATLAS_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --passages 2000003 --refresh-batches 0 --cpu-seconds 0 $extra > $OUT/bench_w2_gloo$extra.json 2> $OUT/bench_w2_gloo$extra.err; say "gloo2 $extra rc=$?"
     grep "^{" $OUT/bench_w2_gloo$extra.json | cut -c1-900 | tee -a $OUT/summary.log
   done ;;
+libab_enc)
+  timeout 900 python tools/lib_ab.py enc ${LIBAB:-r05=tools/ab/r05.so r06=tools/ab/r06.so} 5 > $OUT/lib_ab_enc.txt 2>&1; say "libab_enc rc=$?"; cat $OUT/lib_ab_enc.txt | tee -a $OUT/summary.log ;;
+libab_scan)
+  LIB_AB_ROWS=${LIB_AB_ROWS:-4000000} timeout 900 python tools/lib_ab.py scan ${LIBAB:-r05=tools/ab/r05.so r06=tools/ab/r06.so} 5 > $OUT/lib_ab_scan.txt 2>&1; say "libab_scan rc=$?"; cat $OUT/lib_ab_scan.txt | tee -a $OUT/summary.log ;;
 enc_knob)
   timeout 900 python tools/enc_knob_ab.py ${ENC_KNOBS:-att0,att2,att3,noln} 3 3 > $OUT/enc_knob_ab.txt 2>&1; say "enc_knob rc=$?"; cat $OUT/enc_knob_ab.txt | tee -a $OUT/summary.log ;;
 encpower)
