@@ -100,6 +100,12 @@ class _StdoutToStderr:
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        try:                                                     # (RCCL printf()s into libc's buffer -- fully buffered when stdout is a file: it has to be
+            import ctypes                                        #  pushed out while fd 1 still points at stderr, or it lands behind the JSON line at exit)
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                                        # noqa: BLE001
+            pass
         os.dup2(self._saved, 1)
         os.close(self._saved)
         return False
@@ -575,38 +581,9 @@ def main():
                                        "step_frac": nbytes / dts / 1e9 / HBM_PEAK_GBS, "kernel_frac": nbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                        "steps": steps_s, "timing": "step: K launches without events; kernel: hipEvents in a second pass of K",
                                        "parity_checked": {"rows": n_sub, "queries": B, "queries_exact": B}}
-            # TWO SEARCHES IN FLIGHT (round 6, an extra figure -- `ms_per_step` above stays one search after the other): the same K steps issued
-            # alternately on two HIP streams, each with its own workspace and output buffers (the C-ABI is re-entrant for distinct (stream,
-            # workspace) pairs). A retrieval service with a queue of independent batches can do this; what it buys is the part of a search that
-            # is not the slab stream -- the query image's construction at the start, the tail of the last workgroups, the merge -- overlapped
-            # with the neighbouring search's stream. Results of both streams are held to the checked ones.
-            try:
-                st2 = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
-                ws2 = [torch.zeros(ws_s.numel(), dtype=torch.uint8, device=dev) for _ in range(2)]
-                o2 = [(torch.empty_like(out_s), torch.empty_like(out_i), torch.empty_like(out_st)) for _ in range(2)]
-                torch.cuda.synchronize()
-
-                def two_step(i):
-                    j = i & 1
-                    rc = L.atlas_scan_topk_flags(q.data_ptr(), _lib.DT_F32, slab.data_ptr(), n_sub, B, D, k, pm_s, o2[j][0].data_ptr(), o2[j][1].data_ptr(),
-                                                 o2[j][2].data_ptr(), ws2[j].data_ptr(), ws2[j].numel(), st2[j].cuda_stream, None, None, _lib.SCAN_TRUST_PMAX)
-                    assert rc == 0, rc
-
-                for i_ in range(10):
-                    two_step(i_)
-                fence()
-                ts = time.perf_counter()
-                for i_ in range(steps_s):
-                    two_step(i_)
-                fence()
-                dt2 = (time.perf_counter() - ts) / steps_s
-                for j in range(2):
-                    assert int(o2[j][2].cpu()[_lib.ST_FLAGS]) == 0 and torch.equal(o2[j][0], es_s) and torch.equal(o2[j][1], ei_s), "two searches in flight: wrong result"
-                shard_sweep[str(n_sub)].update({"two_in_flight_ms_per_step": dt2 * 1e3, "two_in_flight_step_frac": nbytes / dt2 / 1e9 / HBM_PEAK_GBS,
-                                                "two_in_flight": "the same steps issued alternately on two HIP streams with their own workspaces (independent batches of a queue)"})
-                del ws2, o2, st2
-            except Exception as e:                                       # noqa: BLE001  (an extra figure never takes the line down)
-                shard_sweep[str(n_sub)]["two_in_flight_error"] = f"{type(e).__name__}: {e}"
+            # (round 6, measured and dropped from the line: TWO searches in flight -- the same steps issued alternately on two HIP streams with their own
+            #  workspaces -- buy 0.5 % at 4M rows and LOSE 3 % at 1M rows: a scan workgroup holds its CU's whole LDS, so the neighbouring search's
+            #  workgroups start when it ends, not beside it; profiles/r06/bench_default_32m_sessionD_two_in_flight.json)
             # what a caller of the reference API sees on this shard: the synchronous product calls (host sync, one pinned D2H, status check,
             # and for search_knn the passages through a REAL dict doc_map and python lists), against the device step above
             if n_sub <= args.api_rows_max:
@@ -1131,8 +1108,6 @@ def main():
         if shard_sweep is not None:
             for n_, v_ in shard_sweep.items():
                 flat_refresh["shard_%s_step_frac" % n_] = v_["step_frac"]
-                if "two_in_flight_step_frac" in v_:
-                    flat_refresh["shard_%s_two_in_flight_step_frac" % n_] = v_["two_in_flight_step_frac"]
         if batch_sweep is not None:
             for b_, v_ in batch_sweep.items():
                 flat_refresh["batch_%s_ms_per_step_4m" % b_] = v_["ms_per_step"]

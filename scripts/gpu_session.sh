@@ -110,6 +110,8 @@ libab_enc)
   timeout 900 python tools/lib_ab.py enc ${LIBAB:-r05=tools/ab/r05.so r06=tools/ab/r06.so} 5 > $OUT/lib_ab_enc.txt 2>&1; say "libab_enc rc=$?"; cat $OUT/lib_ab_enc.txt | tee -a $OUT/summary.log ;;
 libab_scan)
   LIB_AB_ROWS=${LIB_AB_ROWS:-4000000} timeout 900 python tools/lib_ab.py scan ${LIBAB:-r05=tools/ab/r05.so r06=tools/ab/r06.so} 5 > $OUT/lib_ab_scan.txt 2>&1; say "libab_scan rc=$?"; cat $OUT/lib_ab_scan.txt | tee -a $OUT/summary.log ;;
+enc_batch)
+  timeout 900 python tools/enc_batch_size.py > $OUT/enc_batch_size.txt 2>&1; say "enc_batch rc=$?"; cat $OUT/enc_batch_size.txt | tee -a $OUT/summary.log ;;
 enc_knob)
   timeout 900 python tools/enc_knob_ab.py ${ENC_KNOBS:-att0,att2,att3,noln} 3 3 > $OUT/enc_knob_ab.txt 2>&1; say "enc_knob rc=$?"; cat $OUT/enc_knob_ab.txt | tee -a $OUT/summary.log ;;
 encpower)
