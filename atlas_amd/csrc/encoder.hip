@@ -1800,6 +1800,7 @@ int g_pt_stamp_nth = 0, g_pt_launches = 0;   // atlas_tune_set_gemm_stamps_nth: 
 int g_gemm_diag = 0;                         // atlas_tune_set_gemm_diag
 int g_gemm_cfg = -1;                         // atlas_tune_set_gemm_cfg: -1 = by size (what the product library always does)
 int g_att_pf = 0;                            // atlas_tune_set_att_pf: 0 = attention_kernel<.., VROW> (one workgroup per item, no prefetch); 2 / 3 = attention_pf_kernel with that many workgroups per CU
+int g_att_xmap = 1;                          // atlas_tune_set_att_xmap: 0 = item = blockIdx (rounds 1-5)
 int g_skip_ln = 0;                           // atlas_tune_set_skip_ln: 1 = the two ln_kernel launches of a layer are left out (RESULTS WRONG: the bound of any LayerNorm fusion)
 #else
 constexpr unsigned long long* g_gemm_dbg = nullptr;
@@ -1807,6 +1808,7 @@ constexpr int g_gemm_diag = 0;
 constexpr int g_gemm_cfg = -1;
 constexpr int g_att_pf = 0;
 constexpr int g_skip_ln = 0;
+constexpr int g_att_xmap = 1;
 #endif
 
 static int encoder_device_cus() {     // CU count of the current device, asked every time (an attribute read; no cached state)
@@ -1922,7 +1924,7 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
 template <class T, int MAXKF, bool VROW = false>
 __global__ void __launch_bounds__(256)
 attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ vt, const int* __restrict__ cu, int LpMax,
-                 uint16_t* __restrict__ ctx) {
+                 uint16_t* __restrict__ ctx, const int n_passages, const int xmap) {
     // K (this head's [Lp][64] slice) and V^T ([64][Lp]) are staged in LDS ONCE per (passage, head) with coalesced
     // loads; the query fragments then run entirely out of LDS + registers (re-reading K/V^T from L2 for each of the
     // L/16 query fragments made the kernel latency-bound: 300 us -> see profiles). K chunks are XOR-swizzled by
@@ -1932,7 +1934,13 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;
-    const int b = blockIdx.x / NHEAD, h = blockIdx.x % NHEAD;
+    // (passage, head) of this workgroup. Round 6: workgroup g runs on XCD g % 8 (the dispatcher deals workgroups round-robin), and with
+    // item = blockIdx the 12 heads of a passage -- 12 x 128 B of every 4 608-byte q | k | v row -- were fetched by 12 workgroups on 8 different
+    // XCDs at different times: scattered 128-byte requests, 4.2 TB/s. XMAP: XCD x takes the passages b = 8 j + x, its slots walk them head by
+    // head, so the 12 pieces of a row are requested from ONE XCD within a few microseconds of each other (tuning: atlas_tune_set_att_xmap)
+    int b, h;
+    if (xmap) { const int slot = blockIdx.x >> 3; b = (slot / NHEAD) * 8 + (blockIdx.x & 7); h = slot % NHEAD; if (b >= n_passages) return; }
+    else { b = blockIdx.x / NHEAD; h = blockIdx.x % NHEAD; if (b >= n_passages) return; }
     const int tb = cu[b], L = cu[b + 1] - tb;
     if (L <= 0) return;
     const int Lp = (L + 31) & ~31;
@@ -2632,7 +2640,8 @@ int run_encoder(const atlas_bert_weights* w, const int64_t* input_ids, const int
                                         : (size_t)Lp * 128 + (size_t)64 * (Lp + 8) * 2 + (size_t)Lp * 4;
             auto att = [&](auto kern) {
                 (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                hipLaunchKernelGGL(kern, dim3((unsigned)n * NHEAD), dim3(256), att_lds, stream, qk, vt, cu, LpS, ctx);
+                const unsigned grid = g_att_xmap ? (unsigned)((n + 7) / 8 * 8) * NHEAD : (unsigned)n * NHEAD;
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), att_lds, stream, qk, vt, cu, LpS, ctx, n, (int)g_att_xmap);
             };
 #if ATLAS_TUNING
             if (vrow && Lp <= 128 && g_att_pf) {
@@ -2686,6 +2695,7 @@ void atlas_tune_set_gemm_diag(int d) { g_gemm_diag = d; }
 void atlas_tune_set_gemm_cfg(int c) { g_gemm_cfg = c; }
 void atlas_tune_set_att_pf(int v) { g_att_pf = v; }
 void atlas_tune_set_skip_ln(int v) { g_skip_ln = v; }
+void atlas_tune_set_att_xmap(int v) { g_att_xmap = v; }
 #endif
 
 size_t atlas_contriever_workspace_bytes(int n, int L, int dtype) {

@@ -15,5 +15,5 @@ L = _lib.lib()
 for _name, _args in (("atlas_tune_set_scan_variant", [ctypes.c_int]), ("atlas_tune_set_scan_coop", [ctypes.c_int]), ("atlas_tune_set_scan_fused", [ctypes.c_int]), ("atlas_tune_set_scan_wide", [ctypes.c_int]), ("atlas_tune_set_scan_pair", [ctypes.c_int]), ("atlas_tune_set_scan_gemm", [ctypes.c_int]), ("atlas_tune_set_scan_pool", [ctypes.c_int, ctypes.c_int]), ("atlas_tune_set_gemm_cfg", [ctypes.c_int]),
                      ("atlas_tune_set_gemm_diag", [ctypes.c_int]), ("atlas_tune_set_gemm_stamps", [ctypes.c_void_p]), ("atlas_tune_set_gemm_stamps_nth", [ctypes.c_void_p, ctypes.c_int]),
                      ("atlas_tune_set_merge_stamps", [ctypes.c_void_p]), ("atlas_tune_set_scan_stamps", [ctypes.c_void_p]),
-                     ("atlas_tune_set_att_pf", [ctypes.c_int]), ("atlas_tune_set_skip_ln", [ctypes.c_int])):
+                     ("atlas_tune_set_att_pf", [ctypes.c_int]), ("atlas_tune_set_skip_ln", [ctypes.c_int]), ("atlas_tune_set_att_xmap", [ctypes.c_int])):
     getattr(L, _name).argtypes, getattr(L, _name).restype = _args, None

@@ -1,6 +1,7 @@
 """Same-process A/B of the refresh encoder under knobs of the TUNING build (round 6), with energy per passage beside the time:
     python tools/enc_knob_ab.py [variants, default att0,att2,att3,noln] [seconds per leg, default 3] [rounds, default 3]
-  att0 / att2 / att3   attention: round 5's one-workgroup-per-item kernel | the persistent prefetching kernel with 2 | 3 workgroups per CU
+  att0 / att2 / att3   attention: one workgroup per item (the product) | the persistent prefetching kernel with 2 | 3 workgroups per CU
+  att0x0               attention: one workgroup per item, item = blockIdx (rounds 1-5) instead of the XCD-aware mapping
   noln                 the two ln_kernel launches of every layer left out (RESULTS WRONG): the upper bound of ANY LayerNorm fusion, power effects included
 Each leg runs the batch back to back for the given seconds beside a rocm-smi sampler: ms per batch, W, J per passage (= W x ms / 512). Under the
 board's 1 400 W limit the time follows the energy, so J per passage is the quantity a schedule change has to move (VERDICT r05 next #3b).
@@ -31,6 +32,7 @@ def batch(lens, L_):
 def select(v):
     L.atlas_tune_set_att_pf({"att0": 0, "att3": 3}.get(v, 2))
     L.atlas_tune_set_skip_ln(1 if v == "noln" else 0)
+    L.atlas_tune_set_att_xmap(0 if v in ("att0x0", "att2", "att3") else 1)
 
 
 work = {"full 512x128": batch(torch.full((NB,), 128), 128)}
