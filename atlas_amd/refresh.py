@@ -43,6 +43,11 @@ class HalfMirror:
 # GEMM of the encoder (csrc/encoder.hip: gemm_pt_kernel). Batches formed by passage COUNT (512 x ~132 tokens = 264 tiles) run one round
 # more, nearly empty: 32.8k -> 34.4k passages/s, same process, slab bit-identical (profiles/r03/streamed_token_budget.txt)
 TOKEN_BUDGET = 65536
+# Round 6: a streamed refresh forms groups of BUDGET_SCALE x TOKEN_BUDGET tokens (which passages share a batch changes no embedding, and the
+# batches here are ours, not the caller's 512): 512 / 1024 / 2048 / 4096 passages x 128 tokens per launch sequence run at 12.82 / 12.80 /
+# 12.63 / 12.61 ms per 512 passages in one process (profiles/r06/enc_batch_size.txt) -- every launch's ramp, first fetch and last-tile tail
+# spread over four times the tiles. Costs workspace only (~4 GB of the 288).
+BUDGET_SCALE = 4
 
 
 class IndexRefresher:
@@ -53,12 +58,14 @@ class IndexRefresher:
         self.dev = index._slab.device
         self.copy_stream = torch.cuda.Stream(device=self.dev)
         self.depth, self.max_batch, self.max_len = depth, max_batch, max_len
-        # (staging holds max_batch x max_len token slots; a batch cut by tokens may have up to 2 x max_batch shorter passages in them)
-        mk = lambda: torch.empty((max_batch, max_len), dtype=torch.int64).pin_memory()     # noqa: E731
-        self._pin = [(mk(), mk(), torch.empty(2 * max_batch, dtype=torch.int64).pin_memory()) for _ in range(depth)]
-        self._dev = [(torch.empty((max_batch, max_len), dtype=torch.int64, device=self.dev),
-                      torch.empty((max_batch, max_len), dtype=torch.int64, device=self.dev),
-                      torch.empty(2 * max_batch, dtype=torch.int64, device=self.dev)) for _ in range(depth)]
+        # (staging holds BUDGET_SCALE x max_batch x max_len token slots; a batch cut by tokens may have up to 2 x BUDGET_SCALE x max_batch shorter
+        #  passages in them)
+        self.stage_batch = max_batch * BUDGET_SCALE
+        mk = lambda: torch.empty((self.stage_batch, max_len), dtype=torch.int64).pin_memory()     # noqa: E731
+        self._pin = [(mk(), mk(), torch.empty(2 * self.stage_batch, dtype=torch.int64).pin_memory()) for _ in range(depth)]
+        self._dev = [(torch.empty((self.stage_batch, max_len), dtype=torch.int64, device=self.dev),
+                      torch.empty((self.stage_batch, max_len), dtype=torch.int64, device=self.dev),
+                      torch.empty(2 * self.stage_batch, dtype=torch.int64, device=self.dev)) for _ in range(depth)]
         self._ready = [torch.cuda.Event() for _ in range(depth)]      # H2D of the slot finished
         self._free = [torch.cuda.Event() for _ in range(depth)]       # encoder finished reading the slot
         self._used = [False] * depth
@@ -114,6 +121,25 @@ class IndexRefresher:
         self.index._pmax = None                                        # row norms changed: re-certify on the next search
         return row - row_offset
 
+    def plan(self, store: TokenStore, batch_size: Optional[int] = None, bucket: bool = True, token_budget: Optional[int] = None):
+        """the row groups `run_store` launches for these arguments"""
+        batch_size = batch_size or self.max_batch
+        assert batch_size <= self.max_batch and store.max_length <= self.max_len and len(store) == self.index._slab.shape[0]
+        group_batch = batch_size
+        if token_budget is None and bucket and len(store) and batch_size * store.n_tokens / len(store) >= 0.75 * TOKEN_BUDGET:
+            token_budget, group_batch = TOKEN_BUDGET * BUDGET_SCALE, batch_size * BUDGET_SCALE
+        plan = store.plan(group_batch, bucket, token_budget)
+        if token_budget:                                               # every group has to fit the staging buffers as [n, L]
+            slots = self.stage_batch * self.max_len
+            out = []
+            for grp in plan:
+                parts = [grp]
+                while any(g.shape[0] > 1 and g.shape[0] * int(store.lengths[g].max()) > slots for g in parts) or any(g.shape[0] > 2 * self.stage_batch for g in parts):
+                    parts = [h for g in parts for h in (g[: g.shape[0] // 2], g[g.shape[0] // 2:])]
+                out += parts
+            plan = out
+        return plan
+
     @torch.no_grad()
     def run_store(self, store: TokenStore, batch_size: Optional[int] = None, bucket: bool = True, repeat: int = 1,
                   token_budget: Optional[int] = None) -> int:
@@ -121,15 +147,7 @@ class IndexRefresher:
         Row r of the slab receives the embedding of passage r of the store. Asynchronous like `run`.
         token_budget: batches are cut by tokens (TokenStore.plan); default: TOKEN_BUDGET when the batches are formed by length and
         batch_size passages of the store's mean length reach it, else by passage count."""
-        batch_size = batch_size or self.max_batch
-        assert batch_size <= self.max_batch and store.max_length <= self.max_len and len(store) == self.index._slab.shape[0]
-        if token_budget is None and bucket and len(store) and batch_size * store.n_tokens / len(store) >= 0.75 * TOKEN_BUDGET:
-            token_budget = TOKEN_BUDGET
-        plan = store.plan(batch_size, bucket, token_budget)
-        if token_budget:                                               # every group has to fit the staging buffers as [n, L]
-            slots = self.max_batch * self.max_len
-            plan = [g for grp in plan for g in ([grp] if grp.shape[0] * int(store.lengths[grp].max()) <= slots
-                                                else [grp[: grp.shape[0] // 2], grp[grp.shape[0] // 2:]])]
+        plan = self.plan(store, batch_size, bucket, token_budget)
         for _ in range(repeat):
             for rows in plan:
                 s = self._slot()

@@ -1002,7 +1002,7 @@ def main():
             lfs = lens_s.astype(np.float64)
             flops_s = float((169.9e6 * lfs + 36864.0 * lfs * lfs).sum()) * reps
             refresh["streamed"] = {"value": world * n_s * reps / dts, "unit": "passages/s", "seconds": dts, "passages_per_refresh": n_s,
-                                   "refreshes": reps, "lengths": "uniform 64..200, length-bucketed batches of %d tokens (atlas_amd.refresh.TOKEN_BUDGET)" % refresh_mod.TOKEN_BUDGET,
+                                   "refreshes": reps, "lengths": "uniform 64..200, length-bucketed batches of %d tokens (atlas_amd.refresh: BUDGET_SCALE x TOKEN_BUDGET)" % (refresh_mod.TOKEN_BUDGET * refresh_mod.BUDGET_SCALE),
                                    "one_refresh_with_batches_of_%d_passages_passages_per_s" % nb: world * n_s / t_cnt,
                                    "includes": "host batch assembly from the pinned token store + H2D + encoder + slab-row writes",
                                    "real_token_tflops": flops_s / dts / 1e12, "mean_len": float(lfs.mean()),
@@ -1028,7 +1028,7 @@ def main():
             sub_f._set_slab(slab[:n_f])
             rf_f = refresh_mod.IndexRefresher(sub_f, enc, max_batch=nb, max_len=200, depth=3)
             pinned = store_f.tokens.numel() * 4 + sum(t.numel() * 8 for slot in rf_f._pin for t in slot)
-            plan_f = store_f.plan(nb, True, refresh_mod.TOKEN_BUDGET)
+            plan_f = rf_f.plan(store_f, nb)
             fence()
             smi = _SmiSampler() if rank == 0 else None
             if smi:
@@ -1062,7 +1062,7 @@ def main():
             assert torch.equal(sf, esf) and torch.equal(if_, eif), "search on the refreshed shard disagrees with the exact path"
             refresh["full_shard"] = {"passages": n_f, "of_passages_per_gpu_in_configs3": 4_000_000, "label": "%d of 4000000 (BASELINE configs[3]: 32M passages over 8 GPUs)" % n_f,
                                      "value": world * n_f / dt_f, "unit": "passages/s", "seconds": dt_f, "batches": len(plan_f),
-                                     "lengths": "uniform 64..200, length-bucketed batches of %d tokens" % refresh_mod.TOKEN_BUDGET,
+                                     "lengths": "uniform 64..200, length-bucketed batches of %d tokens" % (refresh_mod.TOKEN_BUDGET * refresh_mod.BUDGET_SCALE),
                                      "real_token_tflops": flops_f / dt_f / 1e12, "frac_of_mfma_peak": flops_f / dt_f / 1e12 / MFMA_PEAK_TFLOPS,
                                      "vs_streamed_16k": ((world * n_f / dt_f) / refresh["streamed"]["value"]) if "streamed" in refresh else None,
                                      "host_seconds": host_f, "host_fill_share": host_f["fill"] / dt_f, "host_slot_wait_share": host_f["slot_wait"] / dt_f,

@@ -74,3 +74,32 @@ def test_fill_matches_a_per_passage_loop():
     for j, r in enumerate(rows):
         assert got_ids[j, : len(lists[r])].tolist() == lists[r] and not got_ids[j, len(lists[r]):].any()
         assert got_mask[j].tolist() == [1] * len(lists[r]) + [0] * (L - len(lists[r]))
+
+
+def test_refresher_plan_scales_the_token_budget_and_fits_the_staging_buffers():
+    """round 6: a streamed refresh forms groups of BUDGET_SCALE x TOKEN_BUDGET tokens (refresh.IndexRefresher.plan, pure host arithmetic): every row
+    once, every group within the budget and inside the staging buffers as [n, Lmax] -- also when a few long passages share a group with many
+    short ones -- and a shard too small for token groups keeps the caller's passage batches"""
+    import types
+
+    from atlas_amd import refresh
+    from atlas_amd.token_store import TokenStore
+
+    rs = np.random.default_rng(3)
+    for lens in (rs.integers(64, 201, size=40_000), np.concatenate([np.full(30_000, 9), np.full(50, 200)]), rs.integers(5, 30, size=700)):
+        off = np.zeros(lens.shape[0] + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        store = TokenStore(torch.zeros(int(off[-1]), dtype=torch.int32), off, 200)
+        fake = types.SimpleNamespace(max_batch=512, max_len=200, stage_batch=512 * refresh.BUDGET_SCALE,
+                                     index=types.SimpleNamespace(_slab=torch.empty((len(store), 1))))
+        plan = refresh.IndexRefresher.plan(fake, store, 512)
+        rows = np.concatenate(plan)
+        assert np.array_equal(np.sort(rows), np.arange(len(store)))
+        slots = fake.stage_batch * fake.max_len
+        for g in plan:
+            assert g.shape[0] <= 2 * fake.stage_batch and g.shape[0] * int(store.lengths[g].max()) <= slots
+        if 512 * store.n_tokens / len(store) >= 0.75 * refresh.TOKEN_BUDGET:
+            assert max(int(store.lengths[g].sum()) for g in plan) <= refresh.TOKEN_BUDGET * refresh.BUDGET_SCALE
+            assert len(plan) <= -(-store.n_tokens // (refresh.TOKEN_BUDGET * refresh.BUDGET_SCALE)) * 2 + 2
+        else:                                                        # short passages: batches of 512 PASSAGES, by length
+            assert all(g.shape[0] <= 512 for g in plan)
