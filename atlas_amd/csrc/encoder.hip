@@ -1904,6 +1904,24 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
     else go(gemm_bt_kernel<T, EPI, 128, 128, 2, 2>, 128, 128, 256);
 }
 
+// Reductions over the four 16-lane rows of a wave (lane ^ 16, lane ^ 32) with gfx950's row swaps: `v_permlane16_swap` exchanges the odd rows of
+// its first operand with the even rows of its second, `v_permlane32_swap` the upper half of the first with the lower half of the second -- with
+// both operands = x the two results hold, on every lane, the two values of the pair, so one VALU op finishes the step. __shfl_xor compiles to
+// ds_bpermute_b32 for these distances: an LDS round trip of ~120 cycles, and a softmax row needs FOUR of them in one dependent chain (max over
+// rows, then the sum) per query fragment. Same operands, commutative operation: bit-identical results.
+static __device__ __forceinline__ float rows4_max(float x) {
+    auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+    x = fmaxf(__builtin_bit_cast(float, a[0]), __builtin_bit_cast(float, a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+    return fmaxf(__builtin_bit_cast(float, b[0]), __builtin_bit_cast(float, b[1]));
+}
+static __device__ __forceinline__ float rows4_sum(float x) {
+    auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+    x = __builtin_bit_cast(float, a[0]) + __builtin_bit_cast(float, a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+    return __builtin_bit_cast(float, b[0]) + __builtin_bit_cast(float, b[1]);
+}
+
 // ------------------------------------------------------------------------------------------
 // attention: one block (4 waves) per (passage, head). QK is [M][1536] (q | k), VT is [n][768][Lp] (V transposed).
 //   scores = fp16(q.k^T) ; / 8 (exact) ; + fp16 mask (0 / -10000) ; softmax in fp32 ; P = fp16 ; ctx = fp16(P.v)
@@ -2066,8 +2084,7 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
                     }
                 }
             float mx = fmaxf((float)mx2.x, (float)mx2.y);
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = rows4_max(mx);
             const float nmx = -mx * 1.4426950408889634f;
             f2 ex[NKF][2];
             f2 sum2 = {0.f, 0.f};
@@ -2083,8 +2100,7 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
                     }
                 }
             float sum = sum2.x + sum2.y;
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
+            sum = rows4_sum(sum);
             const float inv = 1.0f / sum;
 #pragma unroll
             for (int kf = 0; kf < NKF; ++kf)
@@ -2111,8 +2127,7 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
                         mx = fmaxf(mx, v);
                     }
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = rows4_max(mx);
             float sum = 0.f;
 #pragma unroll
             for (int kf = 0; kf < NKF; ++kf)
@@ -2124,8 +2139,7 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
                         sum += e;
                     }
                 }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
+            sum = rows4_sum(sum);
             const float inv = 1.0f / sum;
 #pragma unroll
             for (int kf = 0; kf < NKF; ++kf)
@@ -2139,28 +2153,46 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
         f4 o[4];
 #pragma unroll
         for (int df = 0; df < 4; ++df) o[df] = (f4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (VROW) {
+            // keys 32 ks + 4 lg .. + 3 (first read of a pair) and + 16 (second) of dim 16 df + lr, out of the row-major tile: the lane's address selects
+            // key 4 lg + (lr >> 2) and dims 4 (lr & 3) .. + 3, the instruction transposes inside the 16-lane group (header note).
+            // Round 6: the eight reads of key step ks + 1 are issued BEFORE the MFMAs of step ks and waited for with a counted lgkmcnt (LDS
+            // operations return in order): rounds 1-5 issued a step's reads, drained lgkmcnt and only then multiplied -- an LDS latency of
+            // ~120 cycles exposed NKF / 2 times per query fragment. The wait statements name the registers they release ("+v"), so the
+            // MFMAs that read them cannot be scheduled above them.
+            const uint32_t va0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)sVt + (uint32_t)((4 * lg + (lr >> 2)) * VPITCH + 8 * (lr & 3));
+            unsigned long long tq[2][8];
+            auto issue = [&](const int ks, unsigned long long (&t)[8]) {
+                const uint32_t va = va0 + (uint32_t)(32 * ks * VPITCH);
+                asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:2560\n\t"
+                             "ds_read_b64_tr_b16 %2, %8 offset:32\n\tds_read_b64_tr_b16 %3, %8 offset:2592\n\t"
+                             "ds_read_b64_tr_b16 %4, %8 offset:64\n\tds_read_b64_tr_b16 %5, %8 offset:2624\n\t"
+                             "ds_read_b64_tr_b16 %6, %8 offset:96\n\tds_read_b64_tr_b16 %7, %8 offset:2656"
+                             : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]) : "v"(va) : "memory");
+            };
+            issue(0, tq[0]);
 #pragma unroll
-        for (int ks = 0; ks < NKF / 2; ++ks)
-            if (!GUARD || FULL || 2 * ks < nkf) {
-                const uint4 pa = make_uint4(pk[2 * ks][0], pk[2 * ks][1], pk[2 * ks + 1][0], pk[2 * ks + 1][1]);
-                if constexpr (VROW) {
-                    // keys 32 ks + 4 lg .. + 3 (v0) and + 16 (v1) of dim 16 df + lr, out of the row-major tile: the lane's address selects key
-                    // 4 lg + (lr >> 2) and dims 4 (lr & 3) .. + 3, the instruction transposes inside the 16-lane group (header note)
-                    const uint32_t va = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)sVt +
-                                        (uint32_t)((32 * ks + 4 * lg + (lr >> 2)) * VPITCH + 8 * (lr & 3));
-                    unsigned long long t0, t1, t2, t3, t4, t5, t6, t7;
-                    asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:2560\n\t"
-                                 "ds_read_b64_tr_b16 %2, %8 offset:32\n\tds_read_b64_tr_b16 %3, %8 offset:2592\n\t"
-                                 "ds_read_b64_tr_b16 %4, %8 offset:64\n\tds_read_b64_tr_b16 %5, %8 offset:2624\n\t"
-                                 "ds_read_b64_tr_b16 %6, %8 offset:96\n\tds_read_b64_tr_b16 %7, %8 offset:2656\n\t"
-                                 "s_waitcnt lgkmcnt(0)"
-                                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7) : "v"(va) : "memory");
-                    const unsigned long long tv[4][2] = {{t0, t1}, {t2, t3}, {t4, t5}, {t6, t7}};
+            for (int ks = 0; ks < NKF / 2; ++ks)
+                if (!GUARD || FULL || 2 * ks < nkf) {
+                    unsigned long long (&t)[8] = tq[ks & 1];
+                    const bool more = (ks + 1 < NKF / 2) && (!GUARD || FULL || 2 * (ks + 1) < nkf);
+                    if (more) {
+                        issue(ks + 1, tq[(ks + 1) & 1]);
+                        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]) :: "memory");
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]) :: "memory");
+                    }
+                    const uint4 pa = make_uint4(pk[2 * ks][0], pk[2 * ks][1], pk[2 * ks + 1][0], pk[2 * ks + 1][1]);
 #pragma unroll
                     for (int df = 0; df < 4; ++df)
                         // (round 6: operands swapped -- ctx^T = V^T . P^T, the same products over the same keys -- so that o[df][r] = ctx[query 16 qf + lr][dim 16 df + 4 lg + r])
-                        o[df] = T::mma(make_uint4((uint32_t)tv[df][0], (uint32_t)(tv[df][0] >> 32), (uint32_t)tv[df][1], (uint32_t)(tv[df][1] >> 32)), pa, o[df]);
-                } else {
+                        o[df] = T::mma(make_uint4((uint32_t)t[2 * df], (uint32_t)(t[2 * df] >> 32), (uint32_t)t[2 * df + 1], (uint32_t)(t[2 * df + 1] >> 32)), pa, o[df]);
+                }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < NKF / 2; ++ks)
+                if (!GUARD || FULL || 2 * ks < nkf) {
+                    const uint4 pa = make_uint4(pk[2 * ks][0], pk[2 * ks][1], pk[2 * ks + 1][0], pk[2 * ks + 1][1]);
 #pragma unroll
                     for (int df = 0; df < 4; ++df) {
                         const uint16_t* vrow = sVt + (df * 16 + lr) * vstride + ks * 32 + lg * 4;
@@ -2168,7 +2200,7 @@ attention_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v
                         o[df] = T::mma(pa, make_uint4(v0.x, v0.y, v1.x, v1.y), o[df]);
                     }
                 }
-            }
+        }
         // context_layer.permute(0,2,1,3).view(.., 768): [token][h*64 + dim]
         if constexpr (VROW) {                                      // four consecutive dims of one query row per lane: 4 stores of 8 bytes
             const int row = qf * 16 + lr;
@@ -2336,8 +2368,7 @@ attention_pf_kernel(const uint16_t* __restrict__ qkv, const int* __restrict__ cu
                         mx2 = __builtin_elementwise_max(mx2, x);
                     }
                 float mx = fmaxf((float)mx2.x, (float)mx2.y);
-                mx = fmaxf(mx, __shfl_xor(mx, 16));
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                mx = rows4_max(mx);
                 const float nmx = -mx * 1.4426950408889634f;
                 f2 ex[NKF][2];
                 f2 sum2 = {0.f, 0.f};
@@ -2351,8 +2382,7 @@ attention_pf_kernel(const uint16_t* __restrict__ qkv, const int* __restrict__ cu
                         sum2 += ee;
                     }
                 float sum = sum2.x + sum2.y;
-                sum += __shfl_xor(sum, 16);
-                sum += __shfl_xor(sum, 32);
+                sum = rows4_sum(sum);
                 const float inv = 1.0f / sum;
 #pragma unroll
                 for (int kf = 0; kf < NKF; ++kf)
@@ -2375,8 +2405,7 @@ attention_pf_kernel(const uint16_t* __restrict__ qkv, const int* __restrict__ cu
                         mx = fmaxf(mx, vv_);
                     }
                 }
-                mx = fmaxf(mx, __shfl_xor(mx, 16));
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                mx = rows4_max(mx);
                 float sum = 0.f;
 #pragma unroll
                 for (int kf = 0; kf < NKF; ++kf)
@@ -2386,8 +2415,7 @@ attention_pf_kernel(const uint16_t* __restrict__ qkv, const int* __restrict__ cu
                         s[kf][r] = e;
                         sum += e;
                     }
-                sum += __shfl_xor(sum, 16);
-                sum += __shfl_xor(sum, 32);
+                sum = rows4_sum(sum);
                 const float inv = 1.0f / sum;
 #pragma unroll
                 for (int kf = 0; kf < NKF; ++kf)
