@@ -1909,17 +1909,26 @@ static void launch_gemm(int cfg, hipStream_t stream, const typename T::elem* A, 
 // both operands = x the two results hold, on every lane, the two values of the pair, so one VALU op finishes the step. __shfl_xor compiles to
 // ds_bpermute_b32 for these distances: an LDS round trip of ~120 cycles, and a softmax row needs FOUR of them in one dependent chain (max over
 // rows, then the sum) per query fragment. Same operands, commutative operation: bit-identical results.
+// Inline asm, not __builtin_amdgcn_permlane16/32_swap: with this hipcc (ROCm 7.2.0) the builtin's SECOND result reads the register of the first
+// (r[0] + r[1] compiles to `v_add v1, v1, v1` whatever the operands are: tools/permlane_probe.hip; every encoder test caught it). The two
+// v_nop are the wait states the swap needs behind a VALU write of either operand (LLVM's gfx950 hazard rule; hipcc does not look inside asm).
+static __device__ __forceinline__ void rows_swap16(unsigned& a, unsigned& b) { asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+static __device__ __forceinline__ void rows_swap32(unsigned& a, unsigned& b) { asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 static __device__ __forceinline__ float rows4_max(float x) {
-    auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
-    x = fmaxf(__builtin_bit_cast(float, a[0]), __builtin_bit_cast(float, a[1]));
-    auto b = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
-    return fmaxf(__builtin_bit_cast(float, b[0]), __builtin_bit_cast(float, b[1]));
+    unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+    rows_swap16(a, b);
+    x = fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+    a = b = __builtin_bit_cast(unsigned, x);
+    rows_swap32(a, b);
+    return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
 }
 static __device__ __forceinline__ float rows4_sum(float x) {
-    auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
-    x = __builtin_bit_cast(float, a[0]) + __builtin_bit_cast(float, a[1]);
-    auto b = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
-    return __builtin_bit_cast(float, b[0]) + __builtin_bit_cast(float, b[1]);
+    unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+    rows_swap16(a, b);
+    x = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+    a = b = __builtin_bit_cast(unsigned, x);
+    rows_swap32(a, b);
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
 }
 
 // ------------------------------------------------------------------------------------------
