@@ -98,15 +98,30 @@ def test_fp16_reference_self_jitter_and_fixture_reproducibility(tmp_path):
     here = os.path.dirname(os.path.abspath(__file__))
     z = np.load(os.path.join(here, "golden", "enc_l12_ragged.npz"))
     runs = {}
-    for tag, env in (("native", {}), ("avx2", {"ATEN_CPU_CAPABILITY": "avx2"})):
+    for tag, env in (("native", {}), ("native_again", {}), ("avx2", {"ATEN_CPU_CAPABILITY": "avx2"})):
         dst = str(tmp_path / f"{tag}.npz")
         subprocess.run([sys.executable, "-c", _JITTER_CHILD, here, dst], check=True, env={**os.environ, **env}, capture_output=True, timeout=600)
         runs[tag] = np.load(dst)
     cap = bytes(runs["native"]["cap"]).decode()
+    # (1) one machine, two processes: the same bits
+    for pooling in ("average", "cls"):
+        assert np.array_equal(runs["native"][pooling], runs["native_again"][pooling]), "the reference's fp16 CPU forward is not reproducible on ONE machine"
+    # ... and against the committed fixture: the same bits on the machine class it was made on. ATen's capability string is coarser than that
+    # class (round 6: the build container moved to a host with AVX512-FP16 / AMX, same "AVX512" string, and 75 % of the fp16 outputs moved by
+    # 0.9e-3 of max|e| -- the very cross-machine noise (2) is about), so a mismatch under an equal string is held to the tolerance, not to equality
     if bytes(z["torch_version"]).decode() == torch.__version__ and "cpu_capability" in z.files and bytes(z["cpu_capability"]).decode() == cap:
-        assert np.array_equal(runs["native"]["average"], z["emb_fp16"].astype(np.float32)), "the fixture is not reproducible on its own machine class"
-        assert np.array_equal(runs["native"]["cls"], z["emb_fp16_cls"].astype(np.float32))
-        print(f"fixture enc_l12_ragged (torch {torch.__version__}, {cap}): emb_fp16 and emb_fp16_cls re-derived bit for bit")
+        same = (np.array_equal(runs["native"]["average"], z["emb_fp16"].astype(np.float32)) and
+                np.array_equal(runs["native"]["cls"], z["emb_fp16_cls"].astype(np.float32)))
+        if same:
+            print(f"fixture enc_l12_ragged (torch {torch.__version__}, {cap}): emb_fp16 and emb_fp16_cls re-derived bit for bit")
+        else:
+            flags = sorted({f for f in open("/proc/cpuinfo").read().split() if f in ("avx512_fp16", "amx_tile", "avx512_bf16")}) if os.path.exists("/proc/cpuinfo") else []
+            for key, pooling, tol in (("emb_fp16", "average", 2e-3), ("emb_fp16_cls", "cls", 3e-3)):
+                want = z[key].astype(np.float32)
+                d = float(np.abs(runs["native"][pooling] - want).max() / np.abs(want).max())
+                print(f"fixture enc_l12_ragged was made on another machine class than this host ({cap}; {', '.join(flags) or 'no fp16 / AMX extensions'}): "
+                      f"pooling={pooling} max|d|/max|e| = {d:.2e} (tolerance {tol:.0e})")
+                assert d <= tol
     if bytes(runs["avx2"]["cap"]).decode() == cap:
         pytest.skip("this host has no second ATen CPU capability to compare with")
     for pooling, tol in (("average", 2e-3), ("cls", 3e-3)):
