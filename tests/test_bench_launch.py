@@ -72,9 +72,14 @@ def _check_two_rank_line(p):
 @pytest.mark.gpu
 def test_plain_two_rank_command_prints_one_line_on_one_gpu_over_gloo():
     """the command the driver types, with the two ranks sharing this box's GPU (gloo: a logic check of the N > 1 path, not a measurement)"""
-    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "5", "--warmup", "2", "--passages", "1000003", "--refresh-batches", "0",
-                        "--cpu-seconds", "0"], capture_output=True, text=True, timeout=900, env=_env(ATLAS_BENCH_BACKEND="gloo"), cwd=ROOT)
-    _check_two_rank_line(p)
+    cmd = [sys.executable, BENCH, "--gpus", "2", "--steps", "5", "--warmup", "2", "--passages", "1000003", "--refresh-batches", "0", "--cpu-seconds", "0"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=_env(ATLAS_BENCH_BACKEND="gloo"), cwd=ROOT)
+    d = _check_two_rank_line(p)
+    # the N > 1 default: the exchange of step i on a second stream under the scan of step i + 1, with its serialised twin timed beside it
+    assert d["detail"]["exchange_overlapped"] is True and d["detail"]["ms_per_step_serialized"] > 0
+    p = subprocess.run(cmd + ["--overlap-exchange", "off"], capture_output=True, text=True, timeout=900, env=_env(ATLAS_BENCH_BACKEND="gloo"), cwd=ROOT)
+    d = _check_two_rank_line(p)
+    assert d["detail"]["exchange_overlapped"] is False and d["detail"]["ms_per_step_serialized"] is None
 
 
 @pytest.mark.gpu
