@@ -372,3 +372,49 @@ def test_row_major_v_attention_agrees_with_the_transposed_path_at_every_length(n
     finally:
         T.atlas_tune_set_gemm_cfg(-1)
         mine._library = None
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
+def test_query_embedding_replays_a_captured_graph_with_identical_bits(dtype, gpu_index_cls):
+    """round 6: small batches (the query embedding of atlas.py:104) replay a hipGraph of the launch sequence from the second consecutive call with the
+    same (weights, n, L) on. The replayed call gives the eager call's bits for the inputs it captured AND for new inputs of the same shape; another
+    shape goes eager (then captures its own graph); a weight changed in place is never served by a graph captured before the change; a deep copy
+    starts without graphs; ATLAS_QUERY_GRAPHS / `query_graphs = False` keeps plain launches."""
+    import copy
+
+    _, mine = _models(4, seed=21)
+    mine = mine.to(dtype)
+    a_ids, a_mask = (t.cuda() for t in _batch(64, 24, seed=1))
+    b_ids, b_mask = (t.cuda() for t in _batch(64, 24, seed=2))
+    c_ids, c_mask = (t.cuda() for t in _batch(17, 40, seed=3))
+    mine.query_graphs = False
+    want = {k: mine(i, m).clone() for k, (i, m) in {"a": (a_ids, a_mask), "b": (b_ids, b_mask), "c": (c_ids, c_mask)}.items()}
+    assert not mine._graphs
+    mine.query_graphs = True
+    assert torch.equal(mine(a_ids, a_mask), want["a"]) and len(mine._graphs) == 0          # first sight of the shape: eager
+    assert torch.equal(mine(a_ids, a_mask), want["a"]) and len(mine._graphs) == 1          # second: captured + replayed
+    assert torch.equal(mine(b_ids, b_mask), want["b"]) and len(mine._graphs) == 1          # other inputs, same shape: replayed
+    assert torch.equal(mine(c_ids, c_mask), want["c"]) and len(mine._graphs) == 1          # another shape: eager
+    assert torch.equal(mine(c_ids, c_mask), want["c"]) and len(mine._graphs) == 2
+    assert torch.equal(mine(a_ids, a_mask), want["a"])                                      # the first graph is still good
+    out = torch.empty((64, 768), dtype=mine._out_dtype(), device="cuda")
+    v0 = out._version
+    mine.embed_into(out, a_ids, a_mask)
+    assert torch.equal(out, want["a"]) and out._version > v0                               # (the slab's pmax cache watches this counter)
+    # a weight changed in place: the packed key changes, the old graphs are not used
+    with torch.no_grad():
+        mine.encoder.layer[0].output.LayerNorm.bias.add_(0.25)
+    mine.query_graphs = False
+    changed = mine(a_ids, a_mask).clone()
+    mine.query_graphs = True
+    assert not torch.equal(changed, want["a"])
+    n_before = len(mine._graphs)
+    assert torch.equal(mine(a_ids, a_mask), changed) and len(mine._graphs) == n_before     # new key: first sight, eager
+    assert torch.equal(mine(a_ids, a_mask), changed) and len(mine._graphs) == n_before + 1
+    twin = copy.deepcopy(mine)
+    assert len(twin._graphs) == 0 and torch.equal(twin(a_ids, a_mask), changed)
+    # bulk batches and row-mapped writes never take a graph
+    big_ids, big_mask = (t.cuda() for t in _batch(300, 128, seed=4))
+    n_graphs = len(mine._graphs)
+    mine(big_ids, big_mask); mine(big_ids, big_mask)
+    assert len(mine._graphs) == n_graphs
