@@ -17,11 +17,14 @@ for name, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16), ("fp16", 
         mask = (torch.arange(width)[None, :] < lens[:, None]).long()
         ids, mask = (ids * mask).cuda(), mask.cuda()
         for trim in (False, True):
-            with torch.no_grad():
-                for _ in range(5):
-                    e = m(ids, mask, trim_padding=trim)
-                torch.cuda.synchronize()
-                ts = []
-                for _ in range(30):
-                    t = time.perf_counter(); e = m(ids, mask, trim_padding=trim); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
-            print(f"{name} 64 queries x {float(lens.float().mean()):.0f} real tokens padded to {width:3d}, trim_padding={trim!s:5}: {np.median(ts) * 1e3:7.3f} ms per call (min {min(ts) * 1e3:7.3f})", flush=True)
+            for graphs in (False, True):
+                m.query_graphs = graphs
+                with torch.no_grad():
+                    for _ in range(5):
+                        e = m(ids, mask, trim_padding=trim)
+                    torch.cuda.synchronize()
+                    ts = []
+                    for _ in range(30):
+                        t = time.perf_counter(); e = m(ids, mask, trim_padding=trim); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
+                print(f"{name} 64 queries x {float(lens.float().mean()):.0f} real tokens padded to {width:3d}, trim_padding={trim!s:5}, hipGraph replay={graphs!s:5}: "
+                      f"{np.median(ts) * 1e3:7.3f} ms per call (min {min(ts) * 1e3:7.3f})", flush=True)
