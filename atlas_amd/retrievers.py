@@ -315,8 +315,10 @@ class Contriever(nn.Module):
     def _embed_graphed(self, L, w, out, ids, mask, tt, n, seq) -> bool:
         """Small batches -- the query embedding of src/atlas.py:104: 64 queries x ~20 tokens -- are 87 launches of 3-19 us each: launch-bound.
         The second consecutive call with the same (weights, n, L) captures the launch sequence of the C-ABI call into a hipGraph over static
-        input / output / workspace buffers; from then on a call is: two small copies in, one graph launch, one copy out (bf16: 1.40 -> 0.92 ms,
-        fp32: 4.04 -> 3.57 ms per 64-query batch, outputs identical: profiles/r06/enc_query_graph_probe.txt). The key holds the packed weights'
+        input / output / workspace buffers; from then on a call is: two small copies in, one graph launch, one copy out. What it buys, measured
+        (profiles/r06/enc_query_time.txt, 64 queries x 23 tokens): against the plain launches of the SAME build 0-5 % (fp16 1.16 -> 1.11 ms with
+        trim_padding, 1.01 -> 1.00 without; fp32 none) -- the 0.3-0.5 ms the first probe credited to the graph (enc_query_graph_probe.txt) was the
+        python side of the call, which `_params()` removed for both paths. Outputs identical. The key holds the packed weights'
         identity (pointers + torch version counters), so a graph is never replayed over weights that have changed (a training loop, whose
         weights change every step, never sees the same key twice and stays eager). Single-threaded like everything behind this boundary
         (SURVEY §8b): the static buffers belong to the module. Returns False when the call should take the eager path (first sight of a
@@ -337,7 +339,9 @@ class Contriever(nn.Module):
                 if tt is not None:
                     st_tt.copy_(tt)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                # (thread-local capture mode: a process-group watchdog thread polling its events -- a multi-rank job -- must neither be
+                #  failed by this capture nor invalidate it; unsafe calls from THIS thread still abort the capture and land in `except`)
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     self._launch(L, w, st_out, st_ids, st_mask, st_tt, n, seq, None, ws)
                 ent = (graph, st_ids, st_mask, st_tt, st_out, ws, self._packed[2])       # (the packed weight tensors stay alive with the graph)
             except Exception as e:                                   # noqa: BLE001  (capture is an optimisation: the eager HIP path serves the call)
