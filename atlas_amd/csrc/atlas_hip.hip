@@ -31,6 +31,7 @@
 #include "common.h"
 #include "scan_kernel.h"
 #include "gscan_kernel.h"
+#include "dscan_kernel.h"
 #include "../../include/atlas_hip.h"
 #include "../../include/atlas_hip_experimental.h"   // atlas_xchg_*: exported, outside the product interface
 
@@ -510,6 +511,8 @@ int g_scan_fused = 0;                        // atlas_tune_set_scan_fused: 1 = t
 bool scan_fused_enabled() { return g_scan_fused != 0; }
 int g_scan_gemm = 1;                         // atlas_tune_set_scan_gemm: 0 = no GEMM-shaped passes for big batches (A/B)
 bool scan_gemm_enabled() { return g_scan_gemm != 0; }
+int g_scan_dma = 1;                          // atlas_tune_set_scan_dma: 0 = 64-query passes on scan_kernel.h (round 5's kernel; A/B), 2 = the DMA kernel with the default cache policy
+int scan_dma_mode() { return g_scan_dma; }
 #else
 constexpr unsigned long long* g_merge_dbg = nullptr;
 constexpr unsigned long long* g_scan_dbg = nullptr;
@@ -518,6 +521,14 @@ constexpr bool scan_coop_enabled() { return true; }
 constexpr bool scan_wide_enabled() { return true; }
 constexpr bool scan_pair_enabled() { return true; }
 constexpr bool scan_gemm_enabled() { return true; }
+constexpr int scan_dma_mode() { return 1; }
+#endif
+// The 64-query pass with the slab staged through LDS-DMA (dscan_kernel.h, round 6): what every coop, unpaired pass of up to 64 queries runs.
+// [0] measures every row norm (the C-ABI's default contract), [1] takes the caller's pmax as certified (ATLAS_SCAN_TRUST_PMAX)
+struct DmaVariant { void (*kern)(const ScanParams); const char* name; };
+const DmaVariant kDma[2] = {{dscan_kernel<2>, "dscan_kernel<nt>"}, {dscan_kernel<2 | 64>, "dscan_kernel<nt> (trusted pmax)"}};
+#if ATLAS_TUNING
+const DmaVariant kDmaDefaultPolicy[2] = {{dscan_kernel<0>, "dscan_kernel<default policy>"}, {dscan_kernel<64>, "dscan_kernel<default policy> (trusted pmax)"}};
 #endif
 // run-time tile pool at the end of the slab: share of a workgroup's tiles that is NOT pre-assigned, and its cap
 #if ATLAS_TUNING
@@ -854,6 +865,7 @@ int atlas_dbg_f64_to_f16(const double* in, uint16_t* out, int n, void* stream) {
 // tuning build only (not in include/atlas_hip.h): scan variant, device buffers for cycle stamps
 void atlas_tune_set_scan_variant(int v) { g_scan_variant = v; }
 void atlas_tune_set_scan_coop(int c) { g_scan_coop = c; }
+void atlas_tune_set_scan_dma(int m) { g_scan_dma = m; }
 void atlas_tune_set_scan_fused(int f) { g_scan_fused = f; }
 void atlas_tune_set_scan_wide(int f) { g_scan_wide = f; }
 void atlas_tune_set_scan_pair(int f) { g_scan_pair = f; }
@@ -884,7 +896,7 @@ const char* atlas_build_info(void) {
     snprintf(buf, sizeof(buf), "atlas_hip gfx950 %s " __DATE__ " " __TIME__ " tuning", kVariants[scan_variant_index()].name);
     return buf;
 #else
-    return "atlas_hip gfx950 scan_kernel<16,1,8> " __DATE__ " " __TIME__;
+    return "atlas_hip gfx950 dscan_kernel<nt> (64-query passes) + scan_kernel<16,1,8> " __DATE__ " " __TIME__;
 #endif
 }
 
@@ -963,6 +975,11 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
     if (wide_ok) allow_lds(wide.kern);
     allow_lds(merge);
     allow_lds(sample_scores_kernel);
+    const DmaVariant& dma = kDma[trusted ? 1 : 0];
+    allow_lds(dma.kern);
+#if ATLAS_TUNING
+    allow_lds(kDmaDefaultPolicy[trusted ? 1 : 0].kern);
+#endif
 
     hipError_t e = hipSuccess;
     const ScanPlan single = pl;
@@ -1076,7 +1093,20 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
         constexpr bool fused = false;
 #endif
         const dim3 sgrid(pl.G, paired ? 2 : 1);
-        if (is_wide) hipLaunchKernelGGL(wide.kern, sgrid, dim3(wide.nw * 64), pl.scan_lds_wide, stream, sp);
+        // coop, unpaired, 64-query passes of the production shape: the DMA-staged kernel (dscan_kernel.h). Its tiles are 256 rows, pool tiles
+        // included (all eight waves take rows: the ticket is one lane's returning atomic, not a wave's job), and its candidate buffer is what
+        // four 32 KiB stages leave of the LDS
+        const bool use_dma = coop && !paired && !is_wide && !fused && scan_variant_index() == 0 && scan_dma_mode() != 0 && pl.tile == DS_TILE;
+        if (use_dma) {
+            sp.pool_tiles = (pl.pool_rows + DS_TILE - 1) / DS_TILE;
+            sp.buf_cap = DS_BUF_CAP; sp.flush_at = DS_BUF_CAP * 3 / 4;
+#if ATLAS_TUNING
+            const DmaVariant& dk = scan_dma_mode() == 2 ? kDmaDefaultPolicy[trusted ? 1 : 0] : dma;
+#else
+            const DmaVariant& dk = dma;
+#endif
+            hipLaunchKernelGGL(dk.kern, dim3(pl.G), dim3(DS_NW * 64), (size_t)DScanSmem::total, stream, sp);
+        } else if (is_wide) hipLaunchKernelGGL(wide.kern, sgrid, dim3(wide.nw * 64), pl.scan_lds_wide, stream, sp);
         else hipLaunchKernelGGL(var.kern, sgrid, dim3(var.nw * 64), pl.scan_lds, stream, sp);
         if (q0 == 0 && ev_scan_end) (void)hipEventRecord((hipEvent_t)ev_scan_end, stream);
         if (!fused) hipLaunchKernelGGL(merge, dim3(nq, paired ? 2 : 1), dim3(MERGE_NT), pl.merge_lds, stream, mp);

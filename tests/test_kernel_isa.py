@@ -78,6 +78,28 @@ def test_scan_has_no_scratch_and_a_clean_loop():
         assert _scratch_bytes(body) == 0 and "scratch_" not in body, (name, _scratch_bytes(body))
 
 
+def test_dma_staged_scan_has_no_scratch_and_counted_waits_only():
+    """dscan_kernel (round 6: the 64-query pass, slab through LDS-DMA, queries in 96 VGPRs): both twins without a private segment; a tile's
+    twelve stages are 192 MFMAs (+ 48 Gram MFMAs in the certifying twin) and 48 nt LDS-DMA pieces; between the FIRST and the LAST MFMA of a
+    tile nothing waits for vmcnt(0) -- the pipeline of three stages in flight is only ever waited on by count (vmcnt(8) in front of a stage's
+    barrier) -- and no LDS-DMA descriptor lives in VGPRs (no readfirstlane loop around a piece)."""
+    fns = {k: v for k, v in _functions(_asm("atlas_hip")).items() if "dscan_kernelILi" in k}
+    assert len(fns) == 2, sorted(fns)
+    for name, body in fns.items():
+        cert = "ILi2E" in name
+        assert _scratch_bytes(body) == 0 and "scratch_" not in body, (name, _scratch_bytes(body))
+        lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith((";", "."))]
+        mf = [i for i, l in enumerate(lines) if l.startswith("v_mfma")]
+        assert len(mf) == 192 + (48 if cert else 0), (name, len(mf))
+        loop = lines[mf[0]:mf[-1] + 1]
+        dma = [l for l in lines if l.startswith("buffer_load_dwordx4") and " lds" in l]
+        assert len(dma) == 48 + 12 and all(l.endswith(" nt lds") for l in dma), (name, len(dma))       # a tile's stages + the prologue's three
+        assert 11 <= sum(l == "s_waitcnt vmcnt(8)" for l in loop) <= 13, name                        # one per stage (+ the pool ticket's, by count as well)
+        # (the returning atomic of the tile pool is waited for by count too: hipcc knows the eight pieces issued behind it)
+        assert not any(re.match(r"s_waitcnt.*vmcnt\(0\)", l) for l in loop), f"{name}: the DMA pipeline is drained inside a tile"
+        assert body.count("v_readfirstlane_b32") <= 12, (name, body.count("v_readfirstlane_b32"))
+
+
 def test_gemm_shaped_scan_has_a_clean_k_loop():
     """gscan_kernel (batches above 96 queries): at the 256-register cap of its 8-wave workgroup (128 accumulators + 96 fragment registers); no
     instantiation carries a private segment (the fragment registers are filled ASYNCHRONOUSLY by single ds_reads between the LDS-DMA pieces: a
