@@ -163,7 +163,7 @@ def torch_dtype_code(dtype):
 
 
 def scan_sources_sha256() -> str:
-    """sha256 of the CODE of csrc/scan_kernel.h + merge_kernel.h + atlas_hip.hip (the 64-query scan AND its launch plan), comments and blank lines
+    """sha256 of the CODE of csrc/dscan_kernel.h + scan_kernel.h + merge_kernel.h + atlas_hip.hip (the 64-query scan AND its launch plan), comments and blank lines
     stripped: what profiles/pmc_traffic.json is keyed on -- bench.py quotes its PMC traffic only for exactly this code, and an edited comment
     does not invalidate a measurement"""
     import hashlib
@@ -171,7 +171,7 @@ def scan_sources_sha256() -> str:
 
     h = hashlib.sha256()
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-    for f in ("scan_kernel.h", "merge_kernel.h", "atlas_hip.hip"):
+    for f in ("dscan_kernel.h", "scan_kernel.h", "merge_kernel.h", "atlas_hip.hip"):
         text = open(os.path.join(here, f), encoding="utf-8").read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)                 # block comments
         text = re.sub(r"//[^\n]*", "", text)                             # line comments (no string literal of these files holds //)

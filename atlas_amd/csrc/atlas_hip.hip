@@ -511,6 +511,8 @@ int g_scan_fused = 0;                        // atlas_tune_set_scan_fused: 1 = t
 bool scan_fused_enabled() { return g_scan_fused != 0; }
 int g_scan_gemm = 1;                         // atlas_tune_set_scan_gemm: 0 = no GEMM-shaped passes for big batches (A/B)
 bool scan_gemm_enabled() { return g_scan_gemm != 0; }
+int g_gscan_nt = 1;                          // atlas_tune_set_gscan_nt: 0 = the GEMM-shaped passes' slab DMA with the default cache policy (A/B)
+bool gscan_nt_enabled() { return g_gscan_nt != 0; }
 int g_scan_dma = 1;                          // atlas_tune_set_scan_dma: 0 = 64-query passes on scan_kernel.h (round 5's kernel; A/B), 2 = the DMA kernel with the default cache policy
 int scan_dma_mode() { return g_scan_dma; }
 #else
@@ -522,6 +524,7 @@ constexpr bool scan_wide_enabled() { return true; }
 constexpr bool scan_pair_enabled() { return true; }
 constexpr bool scan_gemm_enabled() { return true; }
 constexpr int scan_dma_mode() { return 1; }
+constexpr bool gscan_nt_enabled() { return true; }
 #endif
 // The 64-query pass with the slab staged through LDS-DMA (dscan_kernel.h, round 6): what every coop, unpaired pass of up to 64 queries runs.
 // [0] measures every row norm (the C-ABI's default contract), [1] takes the caller's pmax as certified (ATLAS_SCAN_TRUST_PMAX)
@@ -866,6 +869,7 @@ int atlas_dbg_f64_to_f16(const double* in, uint16_t* out, int n, void* stream) {
 void atlas_tune_set_scan_variant(int v) { g_scan_variant = v; }
 void atlas_tune_set_scan_coop(int c) { g_scan_coop = c; }
 void atlas_tune_set_scan_dma(int m) { g_scan_dma = m; }
+void atlas_tune_set_gscan_nt(int m) { g_gscan_nt = m; }
 void atlas_tune_set_scan_fused(int f) { g_scan_fused = f; }
 void atlas_tune_set_scan_wide(int f) { g_scan_wide = f; }
 void atlas_tune_set_scan_pair(int f) { g_scan_pair = f; }
@@ -994,6 +998,10 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
             auto gscan = g.cw == 256 ? (trusted ? gscan_kernel<0, 4> : gscan_kernel<2, 4>)          // <2, .>: the twin that measures every row norm
                        : g.cw == 192 ? (trusted ? gscan_kernel<0, 3> : gscan_kernel<2, 3>)
                                      : (trusted ? gscan_kernel<0, 2> : gscan_kernel<2, 2>);
+            if (g.ncol == 1 && gscan_nt_enabled())        // one column tile: every slab line is read once -> nt on the slab DMA (gscan_kernel.h: NT)
+                gscan = g.cw == 256 ? (trusted ? gscan_kernel<0, 4, 1> : gscan_kernel<2, 4, 1>)
+                      : g.cw == 192 ? (trusted ? gscan_kernel<0, 3, 1> : gscan_kernel<2, 3, 1>)
+                                    : (trusted ? gscan_kernel<0, 2, 1> : gscan_kernel<2, 2, 1>);
             const size_t g_lds = GS_LDS_BYTES;
             allow_lds(gsample); allow_lds(gscan); allow_lds(gtheta_kernel);
             uint16_t* q16 = (uint16_t*)(w + g.off_q16);

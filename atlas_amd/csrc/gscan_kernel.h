@@ -113,7 +113,10 @@ static __device__ __forceinline__ void gs_ds_read(gs_u4& dst, const uint32_t add
 // FB = 16-query fragments per wave: 4 -> the column tile is 256 queries wide (a wave owns 128 rows x 64 queries); 3 -> 192 wide; 2 -> 128 wide
 // (128 x 32: half the MFMAs per k-tile and 48 instead of 64 LDS-DMA pieces). The narrower tiles serve the pass widths a 256-wide tile would
 // leave part empty at the full cost: 97..128 and 129..192 queries, and -- two or four column tiles of 192 -- 257..384 and 513..768.
-template <int MODE, int FB = 4>
+// NT = 1 (round 6): the slab pieces carry the `nt` cache policy -- for passes of ONE column tile (<= 256 queries: every slab line is read once, by one
+// CU; tools/read_ceiling.hip: a full-line LDS-DMA stream gains 4-7 % with it). With two or four column tiles the neighbouring workgroups of an XCD
+// re-read the tile from its L2, and nt lines are the first to leave it: those passes keep the default policy. Query pieces: always default.
+template <int MODE, int FB = 4, int NT = 0>
 __global__ void __launch_bounds__(512)
 gscan_kernel(const GScanParams p) {
     constexpr int QW = 16 * FB;                        // queries per wave
@@ -205,7 +208,7 @@ gscan_kernel(const GScanParams p) {
             constexpr bool isq = GB ? (i >= 4) : (i < QP);
             constexpr int j = GB ? (i >= 4 ? i - 4 : i) : (i < QP ? i : i - QP);          // the j-th query / slab piece of the phase
             if constexpr (isq) __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_ptr)(lq + j * 1024), 16, (int)(vq + (uint32_t)(j * 8 * ROWB)), kb, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(ls + j * 4096), 16, (int)(vs + (uint32_t)(j * 32 * ROWB)), kb, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(ls + j * 4096), 16, (int)(vs + (uint32_t)(j * 32 * ROWB)), kb, 0, NT ? 2 : 0);
             between(ic);
         });
     };

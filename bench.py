@@ -6,7 +6,7 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" = one pass of the hot path over one batch of 64 synthetic queries with everything resident in HBM:
-  C-ABI atlas_scan_topk (fused MFMA scan/top-k + merge/exact-rescore kernels) on this rank's shard,
+  C-ABI atlas_scan_topk (fused MFMA scan/top-k -- dscan_kernel: slab through LDS-DMA, queries in registers -- + merge/exact-rescore kernels) on this rank's shard,
   and for N > 1 the cross-rank step: ONE RCCL all-gather of the packed (score,id) pairs the merge emitted -> W*k->k merge kernel.
 Workload: a fixed corpus of --passages (default 32M = enwiki-dec2018, BASELINE.json north_star target; fits one
 GPU: 49.2 GB) rows x 768 fp16, round-robin sharded over the N ranks (strong scaling: total work fixed),
@@ -478,7 +478,7 @@ def main():
         fence()
         assert int(out_st.cpu()[_lib.ST_FLAGS]) == 0 and torch.equal(out_s, s0) and torch.equal(out_i, i0), "certifying scan disagrees with the trusting one"
         c_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-        certifying = {"kernel": "scan_kernel<16,1,8,0> (measures every row norm: atlas_scan_topk)", "kernel_ms_mean": c_ms,
+        certifying = {"kernel": "dscan_kernel<nt> (measures every row norm: atlas_scan_topk)", "kernel_ms_mean": c_ms,
                       "frac": rows * D * 2 / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "steps": args.steps}
 
     # synchronous latency of the full product call (host sync + D2H of results + status check), for DESIGN.md
@@ -1158,11 +1158,14 @@ def main():
                 "parallelism": f"shard{world}" + (("+peer-exchange" if args.exchange == "peer" and backend == "nccl" else "+rccl-allgather") if world > 1 else ""),
             },
             "roofline": ({
-                "kernel": "scan_kernel<16,1,8,64> (the twin that takes pmax as certified: ATLAS_SCAN_TRUST_PMAX, what HipDistributedIndex runs "
+                "kernel": "dscan_kernel<nt, trusted pmax> (csrc/dscan_kernel.h: slab through LDS-DMA, queries in registers; the twin that takes pmax as certified: ATLAS_SCAN_TRUST_PMAX, what HipDistributedIndex runs "
                           "between certifying searches)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch (PMC FETCH_SIZE, calibrated; from the committed pass of these sources, profiles/pmc_traffic.json)",
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_mean": scan_ms, "kernel_ms_min": scan_ms_min,
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+                # (a float4 COPY pays read / write turnarounds; what a read-only, full-line, nt stream reaches on this pool: tools/read_ceiling.hip,
+                #  profiles/r06/read_ceiling_32m.txt -- LDS-DMA nt 6.6-6.9 TB/s, the scan's former 16 rows x 64 B fragment loads 6.0-6.5)
+                "frac_of_measured_read_only_stream_6850": achieved / 6850.0,
                 "certifying": certifying, "certifying_frac": certifying["frac"] if certifying else None,
             } if not (stats0.get("plan") or {}).get("gemm_passes") else {
                 # more than 96 queries per step (--distinct-queries at N > 1, or --queries): the GEMM-shaped pass, bounded by the matrix pipe

@@ -599,6 +599,63 @@ def test_duplicated_passages_at_1m_stay_bounded(big, gpu_index_cls):
     assert dt < 0.25, f"{dt:.3f} s for a search with {st['fallback_queries']} flagged queries"
 
 
+def test_dma_staged_pass_random_cases_equal_the_exact_path_and_the_register_fed_kernel(gpu_index_cls):
+    """dscan_kernel.h (round 6: the 64-query pass with the slab through LDS-DMA and the queries in registers) against scan_kernel.h (what rounds 1-5
+    ran) and against the MFMA-free exact path: random shard sizes from the 65 536-row minimum of the coop exchange up (ragged last tiles, shards
+    whose last workgroups have no rows, pooled and unpooled splits), 1..64 queries, k, score scales, duplicated rows, the three query dtypes, both
+    twins, two calls per workspace -- ids and score bits equal, no flags, and the DMA kernel really ran (the tuning build's switch selects it)."""
+    import ctypes
+    from atlas_amd import _lib
+
+    T = _lib.lib(tuning=True)
+    T.atlas_tune_set_scan_dma.argtypes, T.atlas_tune_set_scan_dma.restype = [ctypes.c_int], None
+    rng = np.random.default_rng(2026)
+    g = torch.Generator(device="cuda").manual_seed(2027)
+    dts = [(torch.float32, _lib.DT_F32), (torch.float16, _lib.DT_F16), (torch.bfloat16, _lib.DT_BF16)]
+    try:
+        for c in range(18):
+            N = int([65536, 65536 + int(rng.integers(1, 256)), int(rng.integers(66000, 140000)), int(rng.integers(140000, 524288)), 524288 + int(rng.integers(0, 300)),
+                     int(rng.integers(524288, 1500000))][c % 6])
+            B = int(rng.choice([1, 7, 16, 17, 40, 63, 64, 64]))
+            k = int(rng.choice([1, 5, 40, 40, 100, 256]))
+            scale = float(rng.choice([1.0, 1.0, 0.05, 4.0]))
+            slab = torch.empty((N, 768), dtype=torch.float16, device="cuda")
+            for r0 in range(0, N, 200_000):
+                n = min(200_000, N - r0)
+                x = torch.randn((n, 768), generator=g, device="cuda")
+                slab[r0 : r0 + n] = (x / x.norm(dim=1, keepdim=True) * scale).half()
+            if c % 3 == 0:
+                slab[N // 2 : N // 2 + 1000] = slab[:1000]
+            tdt, code = dts[c % 3]
+            q = (torch.randn((B, 768), generator=g, device="cuda") * float(rng.choice([1.0, 0.3, 3.0]))).to(tdt)
+            flags = _lib.SCAN_TRUST_PMAX if c % 2 == 0 else 0
+            pmax = float(slab.float().norm(dim=1).max()) * 1.001
+            ref = _index_of(gpu_index_cls, slab)
+            es, ei = ref._exact_topk(q, k)
+            ws = torch.zeros(int(T.atlas_scan_topk_workspace_bytes(N, B, 768, k)), dtype=torch.uint8, device="cuda")
+            got = {}
+            for mode in (1, 0):
+                T.atlas_tune_set_scan_dma(mode)
+                for rep in range(2):
+                    out_s = torch.zeros((B, k), dtype=torch.float16, device="cuda")
+                    out_i = torch.zeros((B, k), dtype=torch.int64, device="cuda")
+                    out_st = torch.zeros(_lib.STATUS_HEADER + B, dtype=torch.int32, device="cuda")
+                    rc = T.atlas_scan_topk_flags(q.data_ptr(), code, slab.data_ptr(), N, B, 768, k, pmax, out_s.data_ptr(), out_i.data_ptr(), out_st.data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), None, None, None, flags)
+                    assert rc == 0, (c, mode, rc)
+                    torch.cuda.synchronize()
+                    st = out_st.cpu().numpy()
+                    assert int(st[_lib.ST_FLAGS]) == 0 and int(st[_lib.ST_N_FALLBACK]) == 0, (c, N, B, k, mode, rep, st[:8])
+                    assert torch.equal(out_s, es) and torch.equal(out_i, ei), (c, N, B, k, scale, str(tdt), mode, rep)
+                got[mode] = int(st[_lib.ST_N_CANDIDATES])
+            # (same rows, same fp32 accumulation order per score: the two kernels hand the merge candidate sets of the same order of magnitude)
+            assert 0.3 * got[0] <= got[1] <= 3.0 * got[0] + 64 * k, (c, N, B, k, got)
+            del slab, ref, ws
+    finally:
+        T.atlas_tune_set_scan_dma(1)
+
+
+
 def test_gemm_shaped_passes_random_cases_equal_the_exact_path(gpu_index_cls):
     """random shard sizes (incl. the 65 536-row minimum and ragged last tiles), batch sizes through every column-tile width and into a second
     pass, k, score scales, duplicated rows, both twins -- against the MFMA-free exact path on the device (tools/gscan_fuzz.py runs more of them:

@@ -32,6 +32,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 #ifndef DMA_AUX
 #define DMA_AUX 2
 #endif
+#ifndef ISSUE4
+#define ISSUE4 0
+#endif
 
 struct Params { const uint16_t* slab; int64_t N; const uint16_t* q16; float theta; unsigned* qmax; unsigned long long* npass; int64_t rows_per_wg; };
 
@@ -63,12 +66,23 @@ __global__ void __launch_bounds__(512) dscan_proto(const Params p) {
         const int64_t r0 = begin + (int64_t)ti * TILE;
         int64_t rem = end - r0; if (rem > TILE) rem = TILE; if (rem < 0 || ti >= ntl) rem = 0;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.slab + (size_t)(rem > 0 ? r0 : 0) * D), 0, (int)rem * ROWB, 0x00020000);
+#if ISSUE4
+        // variant: only waves 4..7 issue, 8 pieces each (tools/read_ceiling.hip: fewer issuing waves stream faster)
+        if (wave < 4) return;
+        unsigned char* const ls = smem + buf * STG + (wave - 4) * 8192;
+        uint32_t vs = vbase + (uint32_t)((wave - 4) * 64 * ROWB);
+        asm volatile("" : "+v"(vs));
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(ls + i * 1024), 16, (int)(vs + (uint32_t)(i * 8 * ROWB)), kt * 128, 0, DMA_AUX);
+#else
         unsigned char* const ls = smem + buf * STG + wave * 4096;
         uint32_t vs = vbase + (uint32_t)(wave * 32 * ROWB);
         asm volatile("" : "+v"(vs));
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(ls + i * 1024), 16, (int)(vs + (uint32_t)(i * 8 * ROWB)), kt * 128, 0, DMA_AUX);
+#endif
     };
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const uint32_t as0 = lds0 + (half * 128 + lr) * 128 + ((0 + lg) ^ (lr & 7)) * 16;
@@ -89,7 +103,8 @@ __global__ void __launch_bounds__(512) dscan_proto(const Params p) {
             constexpr int dummy = 0; (void)dummy;
             const int buf = kt % NSTAGE;                              // (NKT % NSTAGE == 0: the stage of a k-tile is a compile-time constant)
             // this wave's pieces of the stage about to be read have landed: everything but the (NSTAGE - 2) x 4 younger pieces
-            if constexpr (NSTAGE == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if constexpr (NSTAGE == 4 && ISSUE4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if constexpr (NSTAGE == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if constexpr (NSTAGE == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // ... and its reads of the stage about to be overwritten have returned
@@ -207,7 +222,7 @@ int main(int argc, char** argv) {
         float ms; hipEventElapsedTime(&ms, e0, e1); sum += ms; if (ms < best) best = ms;
     }
     const double bytes = (double)N * ROWB;
-    printf("dscan_proto NSTAGE=%d aux=%d  %lld rows x 64 queries: mean %.4f ms (min %.4f)  %.3f TB/s = %.3f of 8 TB/s\n", NSTAGE, DMA_AUX, (long long)N,
+    printf("dscan_proto NSTAGE=%d aux=%d issue4=%d  %lld rows x 64 queries: mean %.4f ms (min %.4f)  %.3f TB/s = %.3f of 8 TB/s\n", NSTAGE, DMA_AUX, ISSUE4, (long long)N,
            sum / iters, best, bytes / (sum / iters * 1e-3) / 1e12, bytes / (sum / iters * 1e-3) / 8e12);
     return 0;
 }

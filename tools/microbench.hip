@@ -62,6 +62,41 @@ __global__ void __launch_bounds__(512) stream_kernel(const unsigned char* slab, 
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[blockIdx.x] = 1;
 }
 
+// pattern 3: dscan_kernel.h's stream by itself -- LDS-DMA `nt`, one wave instruction = 8 rows x 128 B (swizzled on the source address), a
+// 256-row tile staged k-tile by k-tile into four 32 KiB stages by eight waves, three stages in flight; nobody reads the LDS. Exactly rows x 1536
+// bytes: the calibration stream of the PMC pass for that kernel (tools/pmc_run.py)
+__global__ void __launch_bounds__(512) stream_dma_kernel(const unsigned char* slab, int64_t N, int64_t rows_per_wg, unsigned* out) {
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem_dma[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t begin = (int64_t)blockIdx.x * rows_per_wg;
+    int64_t end = begin + rows_per_wg; if (end > N) end = N;
+    const int ntl = end > begin ? (int)((end - begin + 255) / 256) : 0;
+    const uint32_t vbase = (uint32_t)(lane >> 3) * 1536u + (uint32_t)(((lane & 7) ^ (lane >> 3)) * 16) + (uint32_t)(wave * 32 * 1536);
+    auto issue = [&](const int ti, const int kt, const int buf) __attribute__((always_inline)) {
+        const int64_t r0 = begin + (int64_t)ti * 256;
+        int64_t rem = end - r0; if (rem > 256) rem = 256; if (rem < 0 || ti >= ntl) rem = 0;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(slab + (rem > 0 ? r0 : 0) * 1536), 0, (int)rem * 1536, 0x00020000);
+        unsigned char* const ls = smem_dma + buf * 32768 + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(ls + i * 1024), 16, (int)(vbase + (uint32_t)(i * 8 * 1536)), kt * 128, 0, 2);
+    };
+    if (ntl == 0) return;
+    for (int s = 0; s < 3; ++s) issue(0, s, s);
+    for (int ti = 0; ti < ntl; ++ti) {
+#pragma unroll
+        for (int kt = 0; kt < 12; ++kt) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int k2 = kt + 3;
+            issue(ti + (k2 >= 12 ? 1 : 0), k2 % 12, k2 % 4);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (smem_dma[threadIdx.x] == 0x5a && smem_dma[threadIdx.x + 512] == 0xa5 && N == 1) out[blockIdx.x] = 1;
+}
+
 template <typename F>
 static float time_ms(F launch, int iters) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -78,6 +113,11 @@ extern "C" float mb_stream(int pattern, int ring, const void* slab, int64_t N, u
     int64_t frags = (N + 15) / 16, G = 256;
     int64_t rows_per_wg = ((frags + G - 1) / G) * 16;
     auto go = [&](auto kern) { return time_ms([&] { hipLaunchKernelGGL(kern, dim3(G), dim3(512), 0, 0, (const unsigned char*)slab, N, rows_per_wg, out); }, iters); };
+    if (pattern == 3) {
+        const int64_t tiles = (N + 255) / 256, rpw = ((tiles + G - 1) / G) * 256;
+        (void)hipFuncSetAttribute((const void*)stream_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        return time_ms([&] { hipLaunchKernelGGL(stream_dma_kernel, dim3(G), dim3(512), 131072, 0, (const unsigned char*)slab, N, rpw, out); }, iters);
+    }
     if (pattern == 0) return go(stream_kernel<0, 4, 8>);
     if (pattern == 1 && ring == 4) return go(stream_kernel<1, 4, 4>);
     if (pattern == 1 && ring == 8) return go(stream_kernel<1, 4, 8>);

@@ -15,6 +15,8 @@ for r0 in range(0, N, 250_000):
 out = torch.zeros(1024, dtype=torch.int32, device="cuda")
 print("stream p1 ms", mb.mb_stream(1, 8, slab.data_ptr(), N, out.data_ptr(), 3), "bytes", N * 1536)
 print("stream p0 ms", mb.mb_stream(0, 8, slab.data_ptr(), N, out.data_ptr(), 3))
+# (round 6) the calibration stream of dscan_kernel.h: LDS-DMA nt, 8 rows x 128 B per wave instruction, exactly rows x 1536 bytes as well
+print("stream dma nt ms", mb.mb_stream(3, 8, slab.data_ptr(), N, out.data_ptr(), 3))
 q = torch.randn((64, 768), device="cuda")
 idx = HipDistributedIndex(); idx._set_slab(slab)
 for _ in range(4):
