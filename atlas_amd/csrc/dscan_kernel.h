@@ -110,11 +110,14 @@ dscan_kernel(const ScanParams p) {
         if (rem > DS_TILE) rem = DS_TILE;
         return Tile{r0, (int)(rem > 0 ? rem : 0), (uint32_t)c * DS_TILE};
     };
+    // (pool tiles are SHORTER than static ones -- p.pool_tile_rows of the 256 rows: the rows past a tile's end are not fetched, so it costs its share
+    //  of a tile's HBM time, and the workgroups' finishing times differ by a short tile, not a whole one)
     auto pool_tile = [&](const uint32_t pt) -> Tile {
         if (pt >= (uint32_t)p.pool_tiles) return Tile{0, 0, 0u};
-        int rem = p.pool_rows - (int)(pt * DS_TILE);
-        if (rem > DS_TILE) rem = DS_TILE;
-        return Tile{p.pool_begin + (int64_t)pt * DS_TILE, rem > 0 ? rem : 0, vpool + pt * DS_TILE};
+        const uint32_t ptr = (uint32_t)p.pool_tile_rows;
+        int rem = p.pool_rows - (int)(pt * ptr);
+        if (rem > (int)ptr) rem = (int)ptr;
+        return Tile{p.pool_begin + (int64_t)pt * ptr, rem > 0 ? rem : 0, vpool + pt * ptr};
     };
     auto seq_tile = [&](const int c) -> Tile { return c < ntiles ? static_tile(c) : pool_tile(blockIdx.x); };     // (c <= ntiles)
 

@@ -2,7 +2,7 @@
 registers), same process, alternated round by round (boxes differ by several per cent; tuning build: atlas_tune_set_scan_dma 0 | 1 | 2 = default cache
 policy on the DMA). Per mode and twin (trusting / certifying): hipEvents around the scan kernel and the whole search step; results must be bit-identical.
 
-    python tools/scan_dma_ab.py 1000000 4000000 32000000 [--pool 60,32 --pool 30,16 ...] [--modes 0,1,2]
+    python tools/scan_dma_ab.py 1000000 4000000 32000000 [--pool 60,32 --pool 200,32,128 ... = permille, cap[, rows of a pool tile of the DMA kernel]] [--modes 0,1,2]
 """
 import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
 from _tune import L  # noqa: E402  (tuning build of the library, hooks bound)
@@ -20,6 +20,7 @@ from atlas_amd import HipDistributedIndex, _lib  # noqa: E402
 from scan_policy_common import shard  # noqa: E402
 
 L.atlas_tune_set_scan_dma.argtypes, L.atlas_tune_set_scan_dma.restype = [ctypes.c_int], None
+L.atlas_tune_set_dma_pool_tile.argtypes, L.atlas_tune_set_dma_pool_tile.restype = [ctypes.c_int], None
 argv = sys.argv[1:]
 pools, modes, sizes = [], [0, 1], []
 while argv:
@@ -56,7 +57,8 @@ for N in sizes:
     acc = {}
     for rnd in range(rounds):
         for pool in pools:
-            L.atlas_tune_set_scan_pool(*pool)
+            L.atlas_tune_set_scan_pool(*pool[:2])
+            L.atlas_tune_set_dma_pool_tile(pool[2] if len(pool) > 2 else 256)
             for flags in (_lib.SCAN_TRUST_PMAX, 0):
                 for m in modes:
                     L.atlas_tune_set_scan_dma(m)
@@ -77,8 +79,10 @@ for N in sizes:
     for key, v in acc.items():
         pool, flags, m = key
         a = np.array([(x[0], x[1], x[2]) for x in v])
-        print(f"N={N:9d} pool={pool[0]:3d},{pool[1]:2d} {'trusting  ' if flags else 'certifying'} {names[m]:22s} kernel mean {a[:, 0].mean():.4f} (min {a[:, 1].min():.4f}) ms = "
+        pool_s = ",".join(str(x) for x in pool)
+        print(f"N={N:9d} pool={pool_s:>10s} {'trusting  ' if flags else 'certifying'} {names[m]:22s} kernel mean {a[:, 0].mean():.4f} (min {a[:, 1].min():.4f}) ms = "
               f"{N * 1536 / a[:, 0].mean() / 1e9 / 8:.3f} of 8 TB/s   step {a[:, 2].mean():.4f} ms = {N * 1536 / a[:, 2].mean() / 1e9 / 8:.3f}   candidates {v[-1][4]}   "
               f"identical={all(x[3] for x in v)}", flush=True)
+    L.atlas_tune_set_dma_pool_tile(256)
     del slab, idx, ws
     torch.cuda.empty_cache()
