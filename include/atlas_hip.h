@@ -118,9 +118,12 @@ const char* atlas_build_info(void);          /* "gfx950 <compile date> ..." */
  * from its own first tiles -- the workgroups exchange 8-byte granules inside the kernel; every wait is bounded, a value
  * that does not arrive in time only loosens a threshold -- and leaves per-workgroup candidate lists) and the merge
  * (exact rescoring of the candidate band, canonical order). Shards below 65 536 rows start without thresholds.
- * The last ~6 % of a large shard's rows are handed out to the scan's workgroups at run time (one ticket per 240-row tile
+ * The last ~6 % of a large shard's rows are handed out to the scan's workgroups at run time (one ticket per 256-row tile
  * from a counter in the workspace state, put back by the merge): which workgroup scans which of those rows differs from
  * call to call, the result -- canonical order, exact scores -- does not.
+ * Round 6: the scan of a pass of up to 64 queries on a shard of >= 65 536 rows is csrc/dscan_kernel.h -- the slab staged through LDS-DMA
+ * (full 128-byte lines, nt policy), the queries in registers: 0.85-0.88 of the 8 TB/s HBM peak at 32M rows where the register-fed
+ * scan_kernel.h (which remains for 96-query and paired passes and smaller shards) reached 0.77. Same workspace, same results bit for bit.
  */
 size_t atlas_scan_topk_workspace_bytes(int64_t N, int B, int d, int k);
 int atlas_scan_topk(const void* q, int q_dtype, const void* slab_f16, int64_t N, int B, int d,
