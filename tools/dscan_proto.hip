@@ -35,6 +35,11 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 #ifndef ISSUE4
 #define ISSUE4 0
 #endif
+#ifndef Q128
+#define Q128 0        // 1: 128 queries per pass -- a wave = one of EIGHT query fragments x all 256 rows of the tile (16 accumulator fragments)
+#endif
+#define NQ (Q128 ? 128 : 64)
+#define NA (Q128 ? 16 : 8)
 
 struct Params { const uint16_t* slab; int64_t N; const uint16_t* q16; float theta; unsigned* qmax; unsigned long long* npass; int64_t rows_per_wg; };
 
@@ -47,7 +52,7 @@ __global__ void __launch_bounds__(512) dscan_proto(const Params p) {
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qf = wave & 3, half = wave >> 2;
+    const int qf = Q128 ? wave : (wave & 3), half = Q128 ? 0 : (wave >> 2);
     const int lr = lane & 15, lg = lane >> 4;
     const int64_t begin = (int64_t)blockIdx.x * p.rows_per_wg;
     int64_t end = begin + p.rows_per_wg; if (end > p.N) end = p.N;
@@ -87,7 +92,7 @@ __global__ void __launch_bounds__(512) dscan_proto(const Params p) {
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const uint32_t as0 = lds0 + (half * 128 + lr) * 128 + ((0 + lg) ^ (lr & 7)) * 16;
 
-    f32x4 acc[8];
+    f32x4 acc[NA];
     const float th = p.theta;
     float qm = -INFINITY;
     unsigned npass = 0;
@@ -114,27 +119,28 @@ __global__ void __launch_bounds__(512) dscan_proto(const Params p) {
                 issue(ti + (k2 >= NKT ? 1 : 0), k2 % NKT, k2 % NSTAGE);
             }
             const uint32_t s0 = as0 + buf * STG, s1 = s0 ^ 64u;
-            u32x4 f0[8], f1[8];
-            ds_read<0 * 2048>(f0[0], s0); ds_read<1 * 2048>(f0[1], s0); ds_read<2 * 2048>(f0[2], s0); ds_read<3 * 2048>(f0[3], s0);
-            ds_read<4 * 2048>(f0[4], s0); ds_read<5 * 2048>(f0[5], s0); ds_read<6 * 2048>(f0[6], s0); ds_read<7 * 2048>(f0[7], s0);
-            ds_read<0 * 2048>(f1[0], s1); ds_read<1 * 2048>(f1[1], s1); ds_read<2 * 2048>(f1[2], s1); ds_read<3 * 2048>(f1[3], s1);
-            ds_read<4 * 2048>(f1[4], s1); ds_read<5 * 2048>(f1[5], s1); ds_read<6 * 2048>(f1[6], s1); ds_read<7 * 2048>(f1[7], s1);
-            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f0[0]), "+v"(f0[1]), "+v"(f0[2]), "+v"(f0[3]), "+v"(f0[4]), "+v"(f0[5]), "+v"(f0[6]), "+v"(f0[7]) :: "memory");
 #pragma unroll
-            for (int a = 0; a < 8; ++a)
-                acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, f0[a]), __builtin_bit_cast(f16x8, bq[2 * kt]),
-                                                               kt == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[a], 0, 0, 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f1[0]), "+v"(f1[1]), "+v"(f1[2]), "+v"(f1[3]), "+v"(f1[4]), "+v"(f1[5]), "+v"(f1[6]), "+v"(f1[7]) :: "memory");
+            for (int h = 0; h < 2; ++h) {
 #pragma unroll
-            for (int a = 0; a < 8; ++a)
-                acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, f1[a]), __builtin_bit_cast(f16x8, bq[2 * kt + 1]), acc[a], 0, 0, 0);
+                for (int g8 = 0; g8 < NA / 8; ++g8) {
+                    const uint32_t sa = (h ? s1 : s0) + g8 * 16384;
+                    u32x4 f[8];
+                    ds_read<0 * 2048>(f[0], sa); ds_read<1 * 2048>(f[1], sa); ds_read<2 * 2048>(f[2], sa); ds_read<3 * 2048>(f[3], sa);
+                    ds_read<4 * 2048>(f[4], sa); ds_read<5 * 2048>(f[5], sa); ds_read<6 * 2048>(f[6], sa); ds_read<7 * 2048>(f[7], sa);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) :: "memory");
+#pragma unroll
+                    for (int a = 0; a < 8; ++a)
+                        acc[g8 * 8 + a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, f[a]), __builtin_bit_cast(f16x8, bq[2 * kt + h]),
+                                                                               (kt == 0 && h == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[g8 * 8 + a], 0, 0, 0);
+                }
+            }
         }
         // end of the tile: the lane owns query 16 qf + lr; rows half * 128 + 16 a + 4 lg + r
         const int nrows = (int)((end - begin) - (int64_t)ti * TILE);
         bool any = false;
         float m = -INFINITY;
 #pragma unroll
-        for (int a = 0; a < 8; ++a)
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool valid = half * 128 + 16 * a + 4 * lg + r < nrows;
@@ -145,7 +151,7 @@ __global__ void __launch_bounds__(512) dscan_proto(const Params p) {
         qm = fmaxf(qm, m);
         if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
 #pragma unroll
-            for (int a = 0; a < 8; ++a)
+            for (int a = 0; a < NA; ++a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) npass += (half * 128 + 16 * a + 4 * lg + r < nrows && acc[a][r] > th) ? 1u : 0u;
         }
@@ -158,7 +164,7 @@ __global__ void __launch_bounds__(512) dscan_proto(const Params p) {
 // reference: per-query maximum of plain fp32 dot products (one wave per row)
 __global__ void ref_kernel(const uint16_t* slab, int64_t N, const uint16_t* q16, unsigned* qmax, float theta, unsigned long long* npass) {
     __shared__ _Float16 sq[64 * D];
-    for (int i = threadIdx.x; i < 64 * D; i += blockDim.x) sq[i] = ((const _Float16*)q16)[i];
+    for (int i = threadIdx.x; i < 64 * D; i += blockDim.x) sq[i] = ((const _Float16*)q16)[i];   // (q16 points at the 64 queries of this launch)
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     float best = -INFINITY; unsigned np = 0;           // lane = query
@@ -187,9 +193,9 @@ int main(int argc, char** argv) {
     const int64_t check_rows = argc > 3 ? atoll(argv[3]) : 1000000ll;
     uint16_t *slab, *q16; unsigned *qmax, *qmax_ref; unsigned long long *np, *np_ref;
     if (hipMalloc(&slab, (size_t)N * ROWB) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
-    hipMalloc(&q16, 64 * ROWB); hipMalloc(&qmax, 256); hipMalloc(&qmax_ref, 256); hipMalloc(&np, 8); hipMalloc(&np_ref, 8);
+    hipMalloc(&q16, NQ * ROWB); hipMalloc(&qmax, NQ * 4); hipMalloc(&qmax_ref, NQ * 4); hipMalloc(&np, 8); hipMalloc(&np_ref, 8);
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, slab, N * D, 1ull);
-    hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, 0, q16, (int64_t)64 * D, 0x1234567ull);
+    hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, 0, q16, (int64_t)NQ * D, 0x1234567ull);
     hipDeviceSynchronize();
     const int G = 256;
     const int64_t tiles = (N + TILE - 1) / TILE, rows_per_wg = ((tiles + G - 1) / G) * TILE;
@@ -200,16 +206,16 @@ int main(int argc, char** argv) {
     {
         const int64_t n = check_rows < N ? check_rows : N;
         const int64_t t = (n + TILE - 1) / TILE, rpw = ((t + G - 1) / G) * TILE;
-        hipMemset(qmax, 0, 256); hipMemset(qmax_ref, 0, 256); hipMemset(np, 0, 8); hipMemset(np_ref, 0, 8);
+        hipMemset(qmax, 0, NQ * 4); hipMemset(qmax_ref, 0, NQ * 4); hipMemset(np, 0, 8); hipMemset(np_ref, 0, 8);
         Params p = {slab, n, q16, theta, qmax, np, rpw};
         hipLaunchKernelGGL(dscan_proto, dim3(G), dim3(512), lds, 0, p);
-        hipLaunchKernelGGL(ref_kernel, dim3(1024), dim3(256), 0, 0, slab, n, q16, qmax_ref, theta, np_ref);
+        for (int c = 0; c < NQ / 64; ++c) hipLaunchKernelGGL(ref_kernel, dim3(1024), dim3(256), 0, 0, slab, n, q16 + (size_t)c * 64 * D, qmax_ref + c * 64, theta, np_ref);
         if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
-        unsigned a[64], b[64]; unsigned long long na, nb;
-        hipMemcpy(a, qmax, 256, hipMemcpyDeviceToHost); hipMemcpy(b, qmax_ref, 256, hipMemcpyDeviceToHost);
+        unsigned a[NQ], b[NQ]; unsigned long long na, nb;
+        hipMemcpy(a, qmax, NQ * 4, hipMemcpyDeviceToHost); hipMemcpy(b, qmax_ref, NQ * 4, hipMemcpyDeviceToHost);
         hipMemcpy(&na, np, 8, hipMemcpyDeviceToHost); hipMemcpy(&nb, np_ref, 8, hipMemcpyDeviceToHost);
         auto unkey = [](unsigned k) { unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; union { unsigned u; float f; } x; x.u = u; return x.f; };
-        double worst = 0; for (int i = 0; i < 64; ++i) worst = fmax(worst, fabs((double)unkey(a[i]) - (double)unkey(b[i])));
+        double worst = 0; for (int i = 0; i < NQ; ++i) worst = fmax(worst, fabs((double)unkey(a[i]) - (double)unkey(b[i])));
         printf("# check on %lld rows: per-query maxima agree within %.3g (q0: %.6f vs %.6f), scores above %.2f: %llu vs %llu (fp32 reference)\n",
                (long long)n, worst, unkey(a[0]), unkey(b[0]), theta, na, nb);
     }
@@ -222,7 +228,7 @@ int main(int argc, char** argv) {
         float ms; hipEventElapsedTime(&ms, e0, e1); sum += ms; if (ms < best) best = ms;
     }
     const double bytes = (double)N * ROWB;
-    printf("dscan_proto NSTAGE=%d aux=%d issue4=%d  %lld rows x 64 queries: mean %.4f ms (min %.4f)  %.3f TB/s = %.3f of 8 TB/s\n", NSTAGE, DMA_AUX, ISSUE4, (long long)N,
+    printf("dscan_proto NSTAGE=%d aux=%d issue4=%d  %lld rows x %d queries: mean %.4f ms (min %.4f)  %.3f TB/s = %.3f of 8 TB/s\n", NSTAGE, DMA_AUX, ISSUE4, (long long)N, NQ,
            sum / iters, best, bytes / (sum / iters * 1e-3) / 1e12, bytes / (sum / iters * 1e-3) / 8e12);
     return 0;
 }
