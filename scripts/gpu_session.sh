@@ -10,6 +10,7 @@
 #   stats          rocprofv3 --kernel-trace --stats of the driver-shaped command (all legs)
 #   pmc_fetch      PMC FETCH_SIZE passes (own runs) of the 64-query scan at 1M / 4M / 32M rows -> profiles/pmc_traffic.json
 #   gscan_ab       tools/batch_gemm_ab.py at 4M and 32M rows (streaming passes vs GEMM-shaped passes, same process)
+#   dscan_prof     MFMA-busy and LDS bank-conflict PMC passes of the DMA-staged 64-query scan at 32M rows
 #   gscan_prof     per-kernel durations + MFMA-busy + FETCH_SIZE counters of the GEMM-shaped pass (4M rows x 512 / 256 queries), phase stamps
 #   enc_pmc        MFMA-busy PMC passes of the refresh encoder (two layers) + per-layer GEMM report
 #   gemm_alias     per-layer GEMM times with diag bits: 1 = no epilogue, 16 / 32 = activation / weight loads aliased to the first tile (always L2 hits)
@@ -61,6 +62,15 @@ pmc_fetch)
   cp profiles/pmc_traffic.json $OUT/pmc_traffic.json; rm -rf $OUT/pmc_1000000 $OUT/pmc_4000000 $OUT/pmc_32000000 ;;
 gscan_ab)
   for n in 4000000 32000000; do timeout 900 python tools/batch_gemm_ab.py $n > $OUT/batch_gemm_pass_ab_$n.txt 2>&1; say "gscan_ab $n rc=$?"; cut -c1-330 $OUT/batch_gemm_pass_ab_$n.txt | grep rows | tee -a $OUT/summary.log; done ;;
+dscan_prof)
+  # MFMA-pipe busy and LDS bank conflicts of the DMA-staged 64-query scan (own PMC passes, --kernel-trace only): tools/pmc_run.py = calibration streams + 4 searches
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -w tools/microbench.hip -o tools/libatlas_mb.so 2>&1 | tail -2
+  (cd /tmp && timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $R/$OUT/dpmc_mfma -o t -- python $R/tools/pmc_run.py 32000000 > $R/$OUT/dpmc_mfma.log 2>&1); say "dscan pmc mfma rc=$?"
+  python tools/pmc_mfma_summarize.py $OUT/dpmc_mfma | tee $OUT/mfma_util_dscan.txt | tee -a $OUT/summary.log
+  (cd /tmp && timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $R/$OUT/dpmc_lds -o t -- python $R/tools/pmc_run.py 32000000 > $R/$OUT/dpmc_lds.log 2>&1); say "dscan pmc lds rc=$?"
+  python tools/pmc_lds_summarize.py $OUT/dpmc_lds | tee $OUT/lds_conflicts_dscan.txt | tee -a $OUT/summary.log
+  cp $(find $OUT/dpmc_mfma -name "*counter_collection.csv" | head -1) $OUT/dscan_pmc_mfma_counter_collection.csv; cp $(find $OUT/dpmc_lds -name "*counter_collection.csv" | head -1) $OUT/dscan_pmc_lds_counter_collection.csv
+  rm -rf $OUT/dpmc_mfma $OUT/dpmc_lds ;;
 gscan_prof)
   for B in 256 512; do
     (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/kt_$B -o t -- python $R/tools/gscan_run.py 4000000 $B 10 > $R/$OUT/kt_$B.log 2>&1)
