@@ -3,10 +3,13 @@
 // Kernels (DESIGN.md §4 has the roofline of each):
 //   prep_queries_kernel   queries -> fp16 (== `.half()`, src/index.py:117), MFMA B-fragment
 //                         order for LDS, row-major copy for rescoring, per-query eps
-//   scan_kernel           the hot one: streams the (N,768) fp16 slab once, 16x16x32 f16 MFMA
-//                         against 64 LDS-resident queries, per-lane threshold filter,
-//                         per-workgroup candidate lists with certified pruning margins.
-//                         Scores never reach HBM (replaces matmul+topk, index.py:117-118)
+//   dscan_kernel          the hot one (round 6, dscan_kernel.h): streams the (N,768) fp16 slab once through LDS-DMA
+//                         (full 128-byte lines, nt), 16x16x32 f16 MFMA against 64 queries held in REGISTERS,
+//                         per-lane threshold filter, per-workgroup candidate lists with certified pruning
+//                         margins. Scores never reach HBM (replaces matmul+topk, index.py:117-118)
+//   scan_kernel           the same pass with the slab HBM -> VGPR and the queries in an LDS image (rounds 1-5:
+//                         every pass; now 96-query and paired passes, shards below 65 536 rows)
+//   gscan_kernel          the slab pass of 97..1024 queries, shaped like a GEMM (gscan_kernel.h)
 //   merge_rescore_kernel  per query: k-th of all surviving candidates, exact (canonical
 //                         double-order) rescoring of the candidate band, canonical sort
 //   exact_* kernels       MFMA-free exact path for any (d,k): fallback + on-device cross-check
