@@ -62,3 +62,42 @@ def test_plan_invariants_over_sizes(plan):
         p = f(N)
         assert p["supported"] == 1 and p["pool_tiles"] > 0 and p["pool_rows"] <= 33 * 256 * 256 + 65536
     assert f(100_000)["pool_tiles"] == 0 and f(524_287)["pool_tiles"] == 0 and f(524_288)["pool_tiles"] > 0
+
+
+def test_dma_staged_scan_tiles_cover_every_row_exactly_once(plan):
+    """csrc/dscan_kernel.h walks the SAME plan with its own tile shapes: static tiles of 256 rows inside every workgroup's range (the last one of a range
+    may be partial), then the pool in tiles of `pool_tile_rows` rows (256 in the product; 128 / 64 through the tuning knob) -- pool tile g pre-assigned to
+    workgroup g, tiles G + t by ticket t, a ticket past the last tile ends a workgroup's sequence (atlas_hip.hip sets ScanParams::pool_tiles =
+    ceil(pool_rows / pool_tile_rows) for it). Simulated here over the plan hook: every slab row lies in exactly one tile, every virtual candidate row
+    (26 bits: static rows below rows_per_wg, pool rows from it on) maps back to its slab row, and wherever the pool exists every workgroup has static rows
+    (a workgroup without rows never reaches its pre-assigned pool tile)."""
+    f, T = plan
+    rng = np.random.default_rng(11)
+    sizes = [65536, 65537, 70_001, 524_287, 524_288, 524_527, 700_001, 1_000_000, 4_000_000, 32_000_000, 128_000_000] + [int(x) for x in rng.integers(65536, 40_000_000, size=60)]
+    for N in sizes:
+        p = f(N)
+        G, R = p["G"], p["rows_per_wg"]
+        if not (p["supported"] and 64 <= G <= 256):
+            continue                                              # (not a coop shape: scan_kernel.h takes it)
+        for ptr in (256, 128, 64):
+            covered = np.zeros(N, dtype=np.uint8)
+            for g in range(G):
+                r_begin, r_end = g * R, min(g * R + R, N)
+                ntiles = max(0, -(-(r_end - r_begin) // 256))
+                if p["pool_tiles"] > 0:
+                    assert ntiles >= 1, (N, g)
+                for c in range(ntiles):
+                    r0 = r_begin + c * 256
+                    rem = min(256, r_end - r0)
+                    assert rem > 0 and c * 256 + rem <= R < (1 << 26)
+                    covered[r0: r0 + rem] += 1
+            pool_tiles = -(-p["pool_rows"] // ptr) if p["pool_rows"] > 0 else 0
+            if p["pool_tiles"] > 0:
+                assert pool_tiles >= G
+            for pt in range(pool_tiles):                          # (whoever draws it: pre-assigned or by ticket, each tile index is handed out once)
+                rem = min(ptr, p["pool_rows"] - pt * ptr)
+                r0 = p["pool_begin"] + pt * ptr
+                vrow0 = R + pt * ptr
+                assert rem > 0 and vrow0 + rem < (1 << 26) and (vrow0 - R) + p["pool_begin"] == r0
+                covered[r0: r0 + rem] += 1
+            assert covered.min() == 1 and covered.max() == 1, (N, ptr, int(np.argmin(covered)), int(np.argmax(covered)))
