@@ -57,6 +57,68 @@ if "contiguous" in sys.argv[1:]:
         for name, r0, n in parts[:3]:
             t = float(np.mean(acc[label + ": " + name]))
             print(f"  {label}: {name:18s}: scan kernel {t:.4f} ms = {n * 1536 / t / 1e9 / 8:.3f} of 8 TB/s")
+if "vmm" in sys.argv[1:]:
+    # the same slab in ONE virtual range stitched from separately created physical chunks (hipMemAddressReserve + hipMemCreate + hipMemMap): does the
+    # slow upper half follow the position inside an ALLOCATION (then chunks of a few GB each should all be of the fast kind)?
+    import ctypes, glob
+    hip = ctypes.CDLL(glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so*"))[0])
+
+    class Loc(ctypes.Structure):
+        _fields_ = [("type", ctypes.c_int), ("id", ctypes.c_int)]
+
+    class Flags(ctypes.Structure):
+        _fields_ = [("compressionType", ctypes.c_ubyte), ("gpuDirectRDMACapable", ctypes.c_ubyte), ("usage", ctypes.c_ushort)]
+
+    class Prop(ctypes.Structure):
+        _fields_ = [("type", ctypes.c_int), ("requestedHandleType", ctypes.c_int), ("location", Loc), ("win32HandleMetaData", ctypes.c_void_p), ("allocFlags", Flags)]
+
+    class Access(ctypes.Structure):
+        _fields_ = [("location", Loc), ("flags", ctypes.c_int)]
+
+    hip.hipMemAddressReserve.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_ulonglong]
+    hip.hipMemCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.POINTER(Prop), ctypes.c_ulonglong]
+    hip.hipMemMap.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_ulonglong]
+    hip.hipMemSetAccess.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(Access), ctypes.c_size_t]
+    hip.hipMemGetAllocationGranularity.argtypes = [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(Prop), ctypes.c_int]
+    hip.hipMemcpy.argtypes, hip.hipMemcpy.restype = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int], ctypes.c_int
+    dev = torch.cuda.current_device()
+    prop = Prop(1, 0, Loc(1, dev), None, Flags(0, 0, 0))
+    gran = ctypes.c_size_t()
+    print("granularity rc", hip.hipMemGetAllocationGranularity(ctypes.byref(gran), ctypes.byref(prop), 1), gran.value, flush=True)
+    for chunk_gb in (4, 16):
+        chunk = chunk_gb << 30
+        total = -(-(N * D * 2) // chunk) * chunk
+        base = ctypes.c_void_p()
+        rc = hip.hipMemAddressReserve(ctypes.byref(base), total, 0, None, 0)
+        print(f"chunks of {chunk_gb} GB: reserve rc {rc} base {base.value}", flush=True)
+        if rc != 0:
+            continue
+        ok = True
+        for off in range(0, total, chunk):
+            h = ctypes.c_void_p()
+            rc1 = hip.hipMemCreate(ctypes.byref(h), chunk, ctypes.byref(prop), 0)
+            rc2 = hip.hipMemMap(base.value + off, chunk, 0, h, 0) if rc1 == 0 else -1
+            ok = ok and rc1 == 0 and rc2 == 0
+        acc_d = Access(Loc(1, dev), 3)
+        rc3 = hip.hipMemSetAccess(base, total, ctypes.byref(acc_d), 1)
+        print(f"  create / map ok {ok}, set access rc {rc3}", flush=True)
+        if not ok or rc3 != 0:
+            continue
+        assert hip.hipMemcpy(base, slab.data_ptr(), N * D * 2, 3) == 0
+        torch.cuda.synchronize()
+        label = f"one virtual range of {chunk_gb} GB physical chunks"
+        for rnd in range(3):
+            for name, r0, n in parts[:3]:
+                ptr = base.value + r0 * D * 2
+                for it in range(2 + reps):
+                    ev = evs[it - 2] if it >= 2 else (None, None)
+                    assert L.atlas_scan_topk_flags(q.data_ptr(), _lib.DT_F32, ptr, n, B, D, k, 1.002, out_s.data_ptr(), out_i.data_ptr(), out_st.data_ptr(), ws.data_ptr(), ws.numel(), stream,
+                                                   ev[0].cuda_event if ev[0] else None, ev[1].cuda_event if ev[1] else None, _lib.SCAN_TRUST_PMAX) == 0
+                torch.cuda.synchronize()
+                acc.setdefault(label + ": " + name, []).append(np.mean([a.elapsed_time(b) for a, b in evs]))
+        for name, r0, n in parts[:3]:
+            t = float(np.mean(acc[label + ": " + name]))
+            print(f"  {label}: {name:18s}: scan kernel {t:.4f} ms = {n * 1536 / t / 1e9 / 8:.3f} of 8 TB/s", flush=True)
 for name, r0, n in parts:
     t = float(np.mean(acc[name]))
     print(f"{name:18s}: scan kernel {t:.4f} ms = {n * 1536 / t / 1e9 / 8:.3f} of 8 TB/s   (rounds: {' '.join('%.4f' % x for x in acc[name])})")
