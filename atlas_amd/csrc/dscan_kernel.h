@@ -12,6 +12,9 @@
 // 256-row tile: per 32 KiB stage (one 64-wide k-tile of 256 rows) a wave issues 4 DMA pieces, 16 ds_read_b128 and 16 MFMAs, and not one VALU
 // instruction. tools/dscan_proto.hip (the bare k-loop + filter): 6.88 ms at 32M rows against 8.08 ms of scan_kernel<16,1,8,64> on the same box.
 //
+// The static part of the slab is DEALT to the workgroups tile by tile (workgroup g: tiles g, g + G, ...): all of them stream one ~100 MB window that
+// moves through the slab -- on boxes whose large allocations stream slower past their first ~24 GB this is worth 3-7 % at 32M rows (see `static_end` below).
+//
 // Everything around the k-loop is scan_kernel.h's, restated for 8 waves: ScanParams, the candidate entries and per-(query, workgroup) lists
 // the merge gathers, the coop threshold exchange on the first tiles, flush + compaction, the run-time tile pool at the end of the slab, the
 // hand-over without global atomics, the certifying twin (Gram MFMAs, two of a tile half's eight fragments per wave). The host runs it for the
@@ -90,23 +93,30 @@ dscan_kernel(const ScanParams p) {
     const int lr = lane & 15, lg = lane >> 4;
     const uint32_t G = gridDim.x;
 
-    const int64_t r_begin = (int64_t)blockIdx.x * p.rows_per_wg;
-    int64_t r_end = r_begin + p.rows_per_wg;
-    if (r_end > p.N) r_end = p.N;
-    const int ntiles = (r_end > r_begin) ? (int)((r_end - r_begin + DS_TILE - 1) / DS_TILE) : 0;       // workgroup-uniform
+    // The static part of the slab, [0, pool_begin) (pool_begin == N without a pool), is DEALT to the workgroups tile by tile: workgroup g takes the tiles
+    // g, g + G, g + 2 G, ... -- at any moment the G workgroups stream ONE window of G x 384 KiB = ~100 MB that moves through the slab, instead of G
+    // streams ~190 MB apart (scan_kernel.h's contiguous ranges). Measured on the bare k-loop (tools/dscan_proto.hip -DDEAL=1, profiles/r06/
+    // dscan_proto_dealt_tiles.txt): 32M rows 7.40 -> 6.87, 7.63 -> 7.07, 7.48 -> 7.23 ms on a box whose large allocations stream slower past their first
+    // ~24 GB (scan_halves.txt: the translation reach, not the DRAM); nothing lost at 4M and 1M rows. The sample of the coop exchange -- every workgroup's
+    // first tile -- is therefore the slab's first G tiles, not G tiles spread over it: any k real scores give a valid threshold.
+    const int64_t static_end = p.pool_begin;
+    const int n_static = (int)((static_end + DS_TILE - 1) / DS_TILE);
+    const int ntiles = n_static > (int)blockIdx.x ? (n_static - (int)blockIdx.x + (int)G - 1) / (int)G : 0;       // workgroup-uniform
     const size_t qstride = (size_t)gridDim.x * p.cap;
     uint2* my_lists = p.lists + (size_t)blockIdx.x * p.cap;
-    // candidate entries carry a 26-bit VIRTUAL row: [0, rows_per_wg) = the static range, from vpool on = pool rows (scan_kernel.h)
-    const uint32_t vpool = (uint32_t)p.rows_per_wg;
-    const uint32_t gbase = (uint32_t)r_begin;
+    // candidate entries carry a 26-bit VIRTUAL row: 256 c + r = row r of the workgroup's c-th static tile (below rows_per_wg: with a pool every workgroup
+    // has exactly rows_per_wg / 256 of them), from vpool on = pool rows (scan_kernel.h); without a pool nothing reaches vpool
+    const uint32_t vpool = p.pool_tiles > 0 ? (uint32_t)p.rows_per_wg : (1u << QSHIFT);
     const uint32_t pbase = (uint32_t)p.pool_begin - vpool;
-    auto global_row = [&](const uint32_t v) -> uint32_t { return v + (v >= vpool ? pbase : gbase); };
+    auto global_row = [&](const uint32_t v) -> uint32_t {
+        return v >= vpool ? v + pbase : ((((v >> 8) * G + blockIdx.x) << 8) | (v & 255u));
+    };
 
-    // ---- the tile sequence: static tiles 0 .. ntiles - 1, pool tile blockIdx.x, then pool tiles G + ticket (one returning atomic per tile) ----
+    // ---- the tile sequence: the workgroup's dealt static tiles 0 .. ntiles - 1, pool tile blockIdx.x, then pool tiles G + ticket (one returning atomic per tile) ----
     struct Tile { int64_t row0; int rem; uint32_t vrow0; };          // first slab row, rows (0: no tile), first virtual row
     auto static_tile = [&](const int c) -> Tile {
-        const int64_t r0 = r_begin + (int64_t)c * DS_TILE;
-        int64_t rem = r_end - r0;
+        const int64_t r0 = ((int64_t)c * G + blockIdx.x) * DS_TILE;
+        int64_t rem = static_end - r0;
         if (rem > DS_TILE) rem = DS_TILE;
         return Tile{r0, (int)(rem > 0 ? rem : 0), (uint32_t)c * DS_TILE};
     };

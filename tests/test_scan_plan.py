@@ -65,12 +65,13 @@ def test_plan_invariants_over_sizes(plan):
 
 
 def test_dma_staged_scan_tiles_cover_every_row_exactly_once(plan):
-    """csrc/dscan_kernel.h walks the SAME plan with its own tile shapes: static tiles of 256 rows inside every workgroup's range (the last one of a range
-    may be partial), then the pool in tiles of `pool_tile_rows` rows (256 in the product; 128 / 64 through the tuning knob) -- pool tile g pre-assigned to
-    workgroup g, tiles G + t by ticket t, a ticket past the last tile ends a workgroup's sequence (atlas_hip.hip sets ScanParams::pool_tiles =
-    ceil(pool_rows / pool_tile_rows) for it). Simulated here over the plan hook: every slab row lies in exactly one tile, every virtual candidate row
-    (26 bits: static rows below rows_per_wg, pool rows from it on) maps back to its slab row, and wherever the pool exists every workgroup has static rows
-    (a workgroup without rows never reaches its pre-assigned pool tile)."""
+    """csrc/dscan_kernel.h walks the SAME plan with its own tile shapes: the static part of the slab, [0, pool_begin), in tiles of 256 rows DEALT to the
+    workgroups (workgroup g: tiles g, g + G, ...; the last tile of the part may be partial), then the pool in tiles of `pool_tile_rows` rows (256 in the
+    product; 128 / 64 through the tuning knob) -- pool tile g pre-assigned to workgroup g, tiles G + t by ticket t, a ticket past the last tile ends a
+    workgroup's sequence (atlas_hip.hip sets ScanParams::pool_tiles = ceil(pool_rows / pool_tile_rows) for it). Simulated here over the plan hook: every
+    slab row lies in exactly one tile; every virtual candidate row (26 bits: 256 c + r for row r of a workgroup's c-th static tile, pool rows from
+    rows_per_wg on) maps back to its slab row the way the kernel's global_row() does; with a pool every workgroup has the same number of static tiles,
+    rows_per_wg / 256 of them, so static virtual rows stay below the pool's."""
     f, T = plan
     rng = np.random.default_rng(11)
     sizes = [65536, 65537, 70_001, 524_287, 524_288, 524_527, 700_001, 1_000_000, 4_000_000, 32_000_000, 128_000_000] + [int(x) for x in rng.integers(65536, 40_000_000, size=60)]
@@ -79,17 +80,23 @@ def test_dma_staged_scan_tiles_cover_every_row_exactly_once(plan):
         G, R = p["G"], p["rows_per_wg"]
         if not (p["supported"] and 64 <= G <= 256):
             continue                                              # (not a coop shape: scan_kernel.h takes it)
+        static_end = p["pool_begin"]
+        assert static_end == (G * R if p["pool_tiles"] > 0 else N)
+        n_static = -(-static_end // 256)
+        vpool = R if p["pool_tiles"] > 0 else 1 << 26
         for ptr in (256, 128, 64):
             covered = np.zeros(N, dtype=np.uint8)
             for g in range(G):
-                r_begin, r_end = g * R, min(g * R + R, N)
-                ntiles = max(0, -(-(r_end - r_begin) // 256))
+                ntiles = (n_static - g + G - 1) // G if n_static > g else 0
                 if p["pool_tiles"] > 0:
-                    assert ntiles >= 1, (N, g)
+                    assert ntiles == R // 256 >= 1, (N, g)
                 for c in range(ntiles):
-                    r0 = r_begin + c * 256
-                    rem = min(256, r_end - r0)
-                    assert rem > 0 and c * 256 + rem <= R < (1 << 26)
+                    r0 = (c * G + g) * 256
+                    rem = min(256, static_end - r0)
+                    assert rem > 0
+                    for r in (0, rem - 1):                        # global_row() of the tile's first and last virtual row
+                        v = c * 256 + r
+                        assert v < vpool and v < (1 << 26) and (((v >> 8) * G + g) << 8 | (v & 255)) == r0 + r
                     covered[r0: r0 + rem] += 1
             pool_tiles = -(-p["pool_rows"] // ptr) if p["pool_rows"] > 0 else 0
             if p["pool_tiles"] > 0:
@@ -98,6 +105,6 @@ def test_dma_staged_scan_tiles_cover_every_row_exactly_once(plan):
                 rem = min(ptr, p["pool_rows"] - pt * ptr)
                 r0 = p["pool_begin"] + pt * ptr
                 vrow0 = R + pt * ptr
-                assert rem > 0 and vrow0 + rem < (1 << 26) and (vrow0 - R) + p["pool_begin"] == r0
+                assert rem > 0 and vrow0 >= vpool and vrow0 + rem < (1 << 26) and vrow0 + (p["pool_begin"] - vpool) == r0
                 covered[r0: r0 + rem] += 1
             assert covered.min() == 1 and covered.max() == 1, (N, ptr, int(np.argmin(covered)), int(np.argmax(covered)))

@@ -35,6 +35,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 #ifndef ISSUE4
 #define ISSUE4 0
 #endif
+#ifndef DEAL
+#define DEAL 0        // 1: the workgroup's tiles are dealt round-robin (tile = blockIdx + i * gridDim) instead of one contiguous range
+#endif
 #ifndef Q128
 #define Q128 0        // 1: 128 queries per pass -- a wave = one of EIGHT query fragments x all 256 rows of the tile (16 accumulator fragments)
 #endif
@@ -54,10 +57,19 @@ __global__ void __launch_bounds__(512) dscan_proto(const Params p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qf = Q128 ? wave : (wave & 3), half = Q128 ? 0 : (wave >> 2);
     const int lr = lane & 15, lg = lane >> 4;
+#if DEAL
+    const int64_t tiles_all = (p.N + TILE - 1) / TILE;
+    const int ntl = (int)((tiles_all - (int64_t)blockIdx.x + gridDim.x - 1) / gridDim.x);
+    const int64_t begin = 0, end = p.N;
+    if (ntl <= 0) return;
+#define TILE_ROW0(ti) (((int64_t)(ti) * gridDim.x + blockIdx.x) * TILE)
+#else
     const int64_t begin = (int64_t)blockIdx.x * p.rows_per_wg;
     int64_t end = begin + p.rows_per_wg; if (end > p.N) end = p.N;
     const int ntl = end > begin ? (int)((end - begin + TILE - 1) / TILE) : 0;
     if (ntl == 0) return;
+#define TILE_ROW0(ti) (begin + (int64_t)(ti) * TILE)
+#endif
 
     // the wave's 16 queries, MFMA B layout: lane (query 16 qf + lr, k-group lg), k-step s = elements 32 s + 8 lg .. + 8
     u32x4 bq[24];
@@ -68,7 +80,7 @@ __global__ void __launch_bounds__(512) dscan_proto(const Params p) {
     const uint32_t vbase = (uint32_t)(lane >> 3) * ROWB + chb;
     // this wave's 4 pieces of stage `it` (k-tile kt of tile ti) -> buffer buf: LDS rows 32 wave + 8 i + (lane >> 3)
     auto issue = [&](const int ti, const int kt, const int buf) __attribute__((always_inline)) {
-        const int64_t r0 = begin + (int64_t)ti * TILE;
+        const int64_t r0 = TILE_ROW0(ti);
         int64_t rem = end - r0; if (rem > TILE) rem = TILE; if (rem < 0 || ti >= ntl) rem = 0;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.slab + (size_t)(rem > 0 ? r0 : 0) * D), 0, (int)rem * ROWB, 0x00020000);
 #if ISSUE4
@@ -136,7 +148,7 @@ __global__ void __launch_bounds__(512) dscan_proto(const Params p) {
             }
         }
         // end of the tile: the lane owns query 16 qf + lr; rows half * 128 + 16 a + 4 lg + r
-        const int nrows = (int)((end - begin) - (int64_t)ti * TILE);
+        const int nrows = (int)(end - TILE_ROW0(ti));
         bool any = false;
         float m = -INFINITY;
 #pragma unroll
@@ -228,7 +240,7 @@ int main(int argc, char** argv) {
         float ms; hipEventElapsedTime(&ms, e0, e1); sum += ms; if (ms < best) best = ms;
     }
     const double bytes = (double)N * ROWB;
-    printf("dscan_proto NSTAGE=%d aux=%d issue4=%d  %lld rows x %d queries: mean %.4f ms (min %.4f)  %.3f TB/s = %.3f of 8 TB/s\n", NSTAGE, DMA_AUX, ISSUE4, (long long)N, NQ,
+    printf("dscan_proto NSTAGE=%d aux=%d issue4=%d deal=%d  %lld rows x %d queries: mean %.4f ms (min %.4f)  %.3f TB/s = %.3f of 8 TB/s\n", NSTAGE, DMA_AUX, ISSUE4, DEAL, (long long)N, NQ,
            sum / iters, best, bytes / (sum / iters * 1e-3) / 1e12, bytes / (sum / iters * 1e-3) / 8e12);
     return 0;
 }
