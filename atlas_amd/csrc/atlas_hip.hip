@@ -518,6 +518,8 @@ int g_gscan_nt = 1;                          // atlas_tune_set_gscan_nt: 0 = the
 bool gscan_nt_enabled() { return g_gscan_nt != 0; }
 int g_dma_pool_tile = 256;                   // atlas_tune_set_dma_pool_tile: rows of a pool tile of the DMA-staged scan (64 | 128 | 256)
 int dma_pool_tile_rows() { return g_dma_pool_tile; }
+int g_dma_deal = 1;                          // atlas_tune_set_dma_deal: 0 = the DMA-staged scan with one contiguous range per workgroup (A/B)
+int dma_deal() { return g_dma_deal; }
 int g_scan_dma = 1;                          // atlas_tune_set_scan_dma: 0 = 64-query passes on scan_kernel.h (round 5's kernel; A/B), 2 = the DMA kernel with the default cache policy
 int scan_dma_mode() { return g_scan_dma; }
 #else
@@ -529,6 +531,7 @@ constexpr bool scan_wide_enabled() { return true; }
 constexpr bool scan_pair_enabled() { return true; }
 constexpr bool scan_gemm_enabled() { return true; }
 constexpr int scan_dma_mode() { return 1; }
+constexpr int dma_deal() { return 1; }
 constexpr int dma_pool_tile_rows() { return 256; }
 constexpr bool gscan_nt_enabled() { return true; }
 #endif
@@ -875,6 +878,7 @@ int atlas_dbg_f64_to_f16(const double* in, uint16_t* out, int n, void* stream) {
 void atlas_tune_set_scan_variant(int v) { g_scan_variant = v; }
 void atlas_tune_set_scan_coop(int c) { g_scan_coop = c; }
 void atlas_tune_set_scan_dma(int m) { g_scan_dma = m; }
+void atlas_tune_set_dma_deal(int d) { g_dma_deal = d; }
 void atlas_tune_set_dma_pool_tile(int rows) { g_dma_pool_tile = (rows == 64 || rows == 128) ? rows : 256; }
 void atlas_tune_set_gscan_nt(int m) { g_gscan_nt = m; }
 void atlas_tune_set_scan_fused(int f) { g_scan_fused = f; }
@@ -1113,6 +1117,7 @@ int atlas_scan_topk_pack(const void* q, int q_dtype, const void* slab_f16, int64
         // four 32 KiB stages leave of the LDS
         const bool use_dma = coop && !paired && !is_wide && !fused && scan_variant_index() == 0 && scan_dma_mode() != 0 && pl.tile == DS_TILE;
         if (use_dma) {
+            sp.deal = dma_deal();
             sp.pool_tile_rows = dma_pool_tile_rows();
             sp.pool_tiles = (pl.pool_rows + sp.pool_tile_rows - 1) / sp.pool_tile_rows;
             sp.buf_cap = DS_BUF_CAP; sp.flush_at = DS_BUF_CAP * 3 / 4;

@@ -99,23 +99,27 @@ dscan_kernel(const ScanParams p) {
     // dscan_proto_dealt_tiles.txt): 32M rows 7.40 -> 6.87, 7.63 -> 7.07, 7.48 -> 7.23 ms on a box whose large allocations stream slower past their first
     // ~24 GB (scan_halves.txt: the translation reach, not the DRAM); nothing lost at 4M and 1M rows. The sample of the coop exchange -- every workgroup's
     // first tile -- is therefore the slab's first G tiles, not G tiles spread over it: any k real scores give a valid threshold.
-    const int64_t static_end = p.pool_begin;
-    const int n_static = (int)((static_end + DS_TILE - 1) / DS_TILE);
-    const int ntiles = n_static > (int)blockIdx.x ? (n_static - (int)blockIdx.x + (int)G - 1) / (int)G : 0;       // workgroup-uniform
+    // (p.deal == 0, the tuning build's A/B: scan_kernel.h's split -- workgroup g owns rows [g * rows_per_wg, + rows_per_wg) of the static part)
+    const bool deal = p.deal != 0;
+    const int64_t r_begin = deal ? 0 : (int64_t)blockIdx.x * p.rows_per_wg;
+    const int64_t static_end = deal ? p.pool_begin : (r_begin + p.rows_per_wg < p.pool_begin ? r_begin + p.rows_per_wg : p.pool_begin);
+    const int n_static = static_end > r_begin ? (int)((static_end - r_begin + DS_TILE - 1) / DS_TILE) : 0;
+    const int ntiles = !deal ? n_static : n_static > (int)blockIdx.x ? (n_static - (int)blockIdx.x + (int)G - 1) / (int)G : 0;       // workgroup-uniform
     const size_t qstride = (size_t)gridDim.x * p.cap;
     uint2* my_lists = p.lists + (size_t)blockIdx.x * p.cap;
     // candidate entries carry a 26-bit VIRTUAL row: 256 c + r = row r of the workgroup's c-th static tile (below rows_per_wg: with a pool every workgroup
     // has exactly rows_per_wg / 256 of them), from vpool on = pool rows (scan_kernel.h); without a pool nothing reaches vpool
     const uint32_t vpool = p.pool_tiles > 0 ? (uint32_t)p.rows_per_wg : (1u << QSHIFT);
     const uint32_t pbase = (uint32_t)p.pool_begin - vpool;
+    const uint32_t gbase = (uint32_t)r_begin;
     auto global_row = [&](const uint32_t v) -> uint32_t {
-        return v >= vpool ? v + pbase : ((((v >> 8) * G + blockIdx.x) << 8) | (v & 255u));
+        return v >= vpool ? v + pbase : deal ? ((((v >> 8) * G + blockIdx.x) << 8) | (v & 255u)) : v + gbase;
     };
 
     // ---- the tile sequence: the workgroup's dealt static tiles 0 .. ntiles - 1, pool tile blockIdx.x, then pool tiles G + ticket (one returning atomic per tile) ----
     struct Tile { int64_t row0; int rem; uint32_t vrow0; };          // first slab row, rows (0: no tile), first virtual row
     auto static_tile = [&](const int c) -> Tile {
-        const int64_t r0 = ((int64_t)c * G + blockIdx.x) * DS_TILE;
+        const int64_t r0 = deal ? ((int64_t)c * G + blockIdx.x) * DS_TILE : r_begin + (int64_t)c * DS_TILE;
         int64_t rem = static_end - r0;
         if (rem > DS_TILE) rem = DS_TILE;
         return Tile{r0, (int)(rem > 0 ? rem : 0), (uint32_t)c * DS_TILE};

@@ -237,6 +237,7 @@ struct ScanParams {
     // Pool tile g is workgroup g's first one; further tiles come from the ticket counter (tile = G + ticket), see the main loop.
     int64_t pool_begin;
     int pool_rows, pool_tiles;
+    int deal;                 // dscan_kernel.h only: 1 = the static part of the slab is dealt to the workgroups tile by tile (the product), 0 = one contiguous range per workgroup (A/B)
     int pool_tile_rows;       // dscan_kernel.h only: rows of a pool tile (<= 256; rows past it are not fetched: a short tile is short in HBM time)
     uint32_t* ticket;         // per-workspace counter, zero at launch (the merge kernel puts it back)
     int nq, k, cap, keep_max;

@@ -91,12 +91,23 @@ def test_dma_staged_scan_has_no_scratch_and_counted_waits_only():
         lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith((";", "."))]
         mf = [i for i, l in enumerate(lines) if l.startswith("v_mfma")]
         assert len(mf) == 192 + (48 if cert else 0), (name, len(mf))
-        loop = lines[mf[0]:mf[-1] + 1]
         dma = [l for l in lines if l.startswith("buffer_load_dwordx4") and " lds" in l]
         assert len(dma) == 48 + 12 and all(l.endswith(" nt lds") for l in dma), (name, len(dma))       # a tile's stages + the prologue's three
-        assert 11 <= sum(l == "s_waitcnt vmcnt(8)" for l in loop) <= 13, name                        # one per stage (+ the pool ticket's, by count as well)
-        # (the returning atomic of the tile pool is waited for by count too: hipcc knows the eight pieces issued behind it)
-        assert not any(re.match(r"s_waitcnt.*vmcnt\(0\)", l) for l in loop), f"{name}: the DMA pipeline is drained inside a tile"
+        # the steady-state STAGES: the code between two consecutive barriers that holds a stage's four DMA pieces, its sixteen fragment reads and
+        # (hipcc pipelines the second k-step across the barrier) sixteen slab MFMAs. None of them waits for vmcnt(0) -- the pipeline of three stages in
+        # flight is only ever waited on by count -- nor touches scratch or writes a scalar into a VGPR lane. (The flush / exchange paths, which do drain
+        # the pipeline, sit between other barriers; where hipcc lays them out in the text is its business.)
+        bars = [i for i, l in enumerate(lines) if l == "s_barrier"]
+        segs = [lines[a + 1:b] for a, b in zip(bars, bars[1:])]
+        stages = [g for g in segs if sum(l.startswith("buffer_load_dwordx4") and " lds" in l for l in g) == 4 and sum(l.startswith("ds_read_b128") for l in g) >= 16
+                  and sum(l.startswith("v_mfma") for l in g) >= 16 and len(g) < 140]
+        assert len(stages) >= 8, (name, len(stages))
+        for g in stages:
+            assert sum(l == "s_waitcnt vmcnt(8)" for l in g) == 1, (name, g)
+            assert not any(re.match(r"s_waitcnt.*vmcnt\(0\)", l) for l in g), f"{name}: the DMA pipeline is drained inside a stage"
+            assert not any(l.startswith(("scratch_", "v_writelane", "global_", "flat_")) for l in g), (name, g)
+        # (hipcc parks ~100 scalars of the tile-boundary code in VGPR lanes; a stage may fetch one or two of them back -- a v_readlane is one VALU slot)
+        assert sum(l.startswith("v_readlane") for g in stages for l in g) <= 12, name
         assert body.count("v_readfirstlane_b32") <= 12, (name, body.count("v_readfirstlane_b32"))
 
 

@@ -21,6 +21,7 @@ from scan_policy_common import shard  # noqa: E402
 
 L.atlas_tune_set_scan_dma.argtypes, L.atlas_tune_set_scan_dma.restype = [ctypes.c_int], None
 L.atlas_tune_set_dma_pool_tile.argtypes, L.atlas_tune_set_dma_pool_tile.restype = [ctypes.c_int], None
+L.atlas_tune_set_dma_deal.argtypes, L.atlas_tune_set_dma_deal.restype = [ctypes.c_int], None
 argv = sys.argv[1:]
 pools, modes, sizes = [], [0, 1], []
 while argv:
@@ -36,7 +37,7 @@ pools = pools or [(60, 32)]
 reps = int(os.environ.get("REPS", "20"))
 rounds = int(os.environ.get("ROUNDS", "3"))
 B, k, D = 64, 40, 768
-names = {0: "scan_kernel<16,1,8>", 1: "dscan_kernel<nt>", 2: "dscan_kernel<default>"}
+names = {0: "scan_kernel<16,1,8>", 1: "dscan_kernel<nt>", 2: "dscan_kernel<default>", 3: "dscan<nt> contiguous"}      # 3: one contiguous range per workgroup instead of dealt tiles
 for N in sizes:
     slab = shard(N)
     q = torch.randn((B, D), generator=torch.Generator(device="cuda").manual_seed(99), device="cuda")
@@ -61,7 +62,8 @@ for N in sizes:
             L.atlas_tune_set_dma_pool_tile(pool[2] if len(pool) > 2 else 256)
             for flags in (_lib.SCAN_TRUST_PMAX, 0):
                 for m in modes:
-                    L.atlas_tune_set_scan_dma(m)
+                    L.atlas_tune_set_scan_dma(1 if m == 3 else m)
+                    L.atlas_tune_set_dma_deal(0 if m == 3 else 1)
                     for it in range(3):
                         assert L.atlas_scan_topk_flags(q.data_ptr(), _lib.DT_F32, slab.data_ptr(), N, B, D, k, pmax, out_s.data_ptr(), out_i.data_ptr(), out_st.data_ptr(),
                                                        ws.data_ptr(), ws.numel(), stream, None, None, flags) == 0
@@ -83,6 +85,6 @@ for N in sizes:
         print(f"N={N:9d} pool={pool_s:>10s} {'trusting  ' if flags else 'certifying'} {names[m]:22s} kernel mean {a[:, 0].mean():.4f} (min {a[:, 1].min():.4f}) ms = "
               f"{N * 1536 / a[:, 0].mean() / 1e9 / 8:.3f} of 8 TB/s   step {a[:, 2].mean():.4f} ms = {N * 1536 / a[:, 2].mean() / 1e9 / 8:.3f}   candidates {v[-1][4]}   "
               f"identical={all(x[3] for x in v)}", flush=True)
-    L.atlas_tune_set_dma_pool_tile(256)
+    L.atlas_tune_set_dma_pool_tile(256); L.atlas_tune_set_dma_deal(1)
     del slab, idx, ws
     torch.cuda.empty_cache()
