@@ -123,7 +123,9 @@ const char* atlas_build_info(void);          /* "gfx950 <compile date> ..." */
  * call to call, the result -- canonical order, exact scores -- does not.
  * Round 6: the scan of a pass of up to 64 queries on a shard of >= 65 536 rows is csrc/dscan_kernel.h -- the slab staged through LDS-DMA
  * (full 128-byte lines, nt policy), the queries in registers: 0.85-0.88 of the 8 TB/s HBM peak at 32M rows where the register-fed
- * scan_kernel.h (which remains for 96-query and paired passes and smaller shards) reached 0.77. Same workspace, same results bit for bit.
+ * scan_kernel.h (which remains for 96-query and paired passes and smaller shards) reached 0.77. Its workgroups take the slab's 256-row tiles in turn
+ * (workgroup g: tiles g, g + G, ...: one ~100 MB window moves through the slab), so a shard of 128M rows (197 GB) streams at the same 0.88 as one of
+ * 16M. Same workspace, same results bit for bit.
  */
 size_t atlas_scan_topk_workspace_bytes(int64_t N, int B, int d, int k);
 int atlas_scan_topk(const void* q, int q_dtype, const void* slab_f16, int64_t N, int B, int d,
