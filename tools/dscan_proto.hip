@@ -62,7 +62,11 @@ __global__ void __launch_bounds__(512) dscan_proto(const Params p) {
     const int ntl = (int)((tiles_all - (int64_t)blockIdx.x + gridDim.x - 1) / gridDim.x);
     const int64_t begin = 0, end = p.N;
     if (ntl <= 0) return;
+#if DEAL == 2     // ... and within the window every XCD (workgroup g runs on XCD g & 7) takes one contiguous eighth: 32 adjacent tiles = 12.5 MB per XCD
+#define TILE_ROW0(ti) (((int64_t)(ti) * gridDim.x + (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * TILE)
+#else
 #define TILE_ROW0(ti) (((int64_t)(ti) * gridDim.x + blockIdx.x) * TILE)
+#endif
 #else
     const int64_t begin = (int64_t)blockIdx.x * p.rows_per_wg;
     int64_t end = begin + p.rows_per_wg; if (end > p.N) end = p.N;

@@ -9,7 +9,7 @@ from atlas_amd import _lib
 from scan_policy_common import shard
 
 L = _lib.lib()
-N, B, k, D = 32_000_000, 64, 40, 768
+N, B, k, D = 32_000_000, int(os.environ.get("QUERIES", "64")), 40, 768      # QUERIES=128: the GEMM-shaped pass (hipEvents bracket its launches)
 slab = shard(N)
 q = torch.randn((B, D), generator=torch.Generator(device="cuda").manual_seed(99), device="cuda")
 out_s = torch.empty((B, k), dtype=torch.float16, device="cuda"); out_i = torch.empty((B, k), dtype=torch.int64, device="cuda")
