@@ -603,12 +603,13 @@ def test_dma_staged_pass_random_cases_equal_the_exact_path_and_the_register_fed_
     """dscan_kernel.h (round 6: the 64-query pass with the slab through LDS-DMA and the queries in registers) against scan_kernel.h (what rounds 1-5
     ran) and against the MFMA-free exact path: random shard sizes from the 65 536-row minimum of the coop exchange up (ragged last tiles, shards
     whose last workgroups have no rows, pooled and unpooled splits), 1..64 queries, k, score scales, duplicated rows, the three query dtypes, both
-    twins, two calls per workspace -- ids and score bits equal, no flags, and the DMA kernel really ran (the tuning build's switch selects it)."""
+    twins, two calls per workspace, the DMA kernel with its static tiles dealt (the product) and in contiguous ranges -- ids and score bits equal, no flags."""
     import ctypes
     from atlas_amd import _lib
 
     T = _lib.lib(tuning=True)
     T.atlas_tune_set_scan_dma.argtypes, T.atlas_tune_set_scan_dma.restype = [ctypes.c_int], None
+    T.atlas_tune_set_dma_deal.argtypes, T.atlas_tune_set_dma_deal.restype = [ctypes.c_int], None
     rng = np.random.default_rng(2026)
     g = torch.Generator(device="cuda").manual_seed(2027)
     dts = [(torch.float32, _lib.DT_F32), (torch.float16, _lib.DT_F16), (torch.bfloat16, _lib.DT_BF16)]
@@ -634,8 +635,9 @@ def test_dma_staged_pass_random_cases_equal_the_exact_path_and_the_register_fed_
             es, ei = ref._exact_topk(q, k)
             ws = torch.zeros(int(T.atlas_scan_topk_workspace_bytes(N, B, 768, k)), dtype=torch.uint8, device="cuda")
             got = {}
-            for mode in (1, 0):
-                T.atlas_tune_set_scan_dma(mode)
+            for mode in (1, 0, 3):                  # 1 = dscan_kernel, its static tiles dealt (the product); 0 = scan_kernel; 3 = dscan_kernel with one contiguous range per workgroup
+                T.atlas_tune_set_scan_dma(1 if mode == 3 else mode)
+                T.atlas_tune_set_dma_deal(0 if mode == 3 else 1)
                 for rep in range(2):
                     out_s = torch.zeros((B, k), dtype=torch.float16, device="cuda")
                     out_i = torch.zeros((B, k), dtype=torch.int64, device="cuda")
@@ -653,6 +655,7 @@ def test_dma_staged_pass_random_cases_equal_the_exact_path_and_the_register_fed_
             del slab, ref, ws
     finally:
         T.atlas_tune_set_scan_dma(1)
+        T.atlas_tune_set_dma_deal(1)
 
 
 
