@@ -69,6 +69,17 @@ static __device__ __forceinline__ void ds_rd128(u32x4& dst, const uint32_t addr)
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
 
+// Certified first threshold of one query (one wave): the k-th largest of n <= 64 * KPL sample scores of DISTINCT rows, pushed through prune_threshold
+// (scan_kernel.h: initial_theta, which takes one maximum per workgroup; here every workgroup brings TWO scores per query, see first_tile_exchange)
+template <int KPL>
+static __device__ __forceinline__ float sample_theta(const uint32_t (&key)[KPL], const int k, const float eps) {      // key = f32_order_key(score); 0 = no score (padding, below every real key)
+    uint32_t valid = 0;
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) valid += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(key[u] != 0u));
+    const uint32_t kth = wave_kth_key<KPL>(key, (uint32_t)k, 14);
+    return (valid >= (uint32_t)k) ? prune_threshold(f32_from_order_key(kth), eps) : neg_inf();
+}
+
 // AUX & 31 = cache-policy bits of the slab DMA (2 = nt: every line is read once, by one CU); AUX & 64 = the caller's pmax is certified
 // (ATLAS_SCAN_TRUST_PMAX): no row norms are measured
 template <int AUX>
@@ -275,40 +286,49 @@ dscan_kernel(const ScanParams p) {
         wg_barrier_lds();
     };
 
-    // ---- coop: the scan's own first tiles are the sample (scan_kernel.h: first_tile_exchange). tm = the best first-tile score of the lane's
-    // query among this wave's 128 rows ----
-    auto first_tile_exchange = [&](const float tm) {
-        float* s_tmax = (float*)s_buf;                     // [2 halves][64]: the candidate buffer is still empty
+    // ---- coop: the scan's own first tiles are the sample (scan_kernel.h: first_tile_exchange) -- with TWO scores per (workgroup, query) instead of one: the
+    // best and the runner-up of the tile (t1 >= t2 come in per wave: the two best of the lane's query among the wave's 128 rows). scan_kernel.h publishes the
+    // tile's maximum only, and the k-th largest of G = 256 maxima is a weak bound when k is large -- for k = 256 it is the SMALLEST tile maximum: 4.4M
+    // candidates per search at 4M rows (1.7 % of all scores), 1.49 ms instead of 0.96; the k-th largest of 2 G = 512 scores of distinct rows sits near the
+    // sample's own k-th best up to k = 256 (profiles/r06/dscan_k_sweep.txt). Granules: gran_max[q][2 G] (inside the [96][1024] the workspace holds) ----
+    auto first_tile_exchange = [&](const float t1, const float t2) {
+        float* s_tmax = (float*)s_buf;                     // [2 halves][2][64]: the candidate buffer is still empty
         gu64* gmax = (gu64*)p.gran_max;
-        if (lg == 0) s_tmax[half * NQ + 16 * qf + lr] = tm;
+        const uint32_t G2 = 2u * G;
+        if (lg == 0) { s_tmax[(half * 2 + 0) * NQ + 16 * qf + lr] = t1; s_tmax[(half * 2 + 1) * NQ + 16 * qf + lr] = t2; }
         wg_barrier_lds();
-        if (tid < p.nq) {
-            const float m = fmaxf(s_tmax[tid], s_tmax[NQ + tid]);
-            __hip_atomic_store(gmax + (size_t)tid * G + blockIdx.x, ((unsigned long long)tag << 32) | (unsigned long long)f32_bits(m),
+        if (tid < 2 * p.nq) {
+            const int qq = tid >> 1, j = tid & 1;
+            const float a1 = s_tmax[0 * NQ + qq], a2 = s_tmax[1 * NQ + qq], b1 = s_tmax[2 * NQ + qq], b2 = s_tmax[3 * NQ + qq];
+            const float m = j == 0 ? fmaxf(a1, b1) : fmaxf(fminf(a1, b1), fmaxf(a2, b2));      // the tile's best | its runner-up
+            __hip_atomic_store(gmax + (size_t)qq * G2 + 2u * blockIdx.x + (uint32_t)j, ((unsigned long long)tag << 32) | (unsigned long long)f32_bits(m),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (wave == NW - 1) {
             if ((int)blockIdx.x < p.nq) {                  // this workgroup derives the threshold of query blockIdx.x
                 const int qq = blockIdx.x;
-                unsigned long long g[4] = {0ull, 0ull, 0ull, 0ull};
+                constexpr int KPL = 8;                     // 2 x 256 granules over 64 lanes; a granule becomes its 32-bit order key as it arrives (the
+                uint32_t key[KPL];                         //  wave holds its tile's 32 accumulators and 96 query registers meanwhile)
+                uint32_t have = 0u;                        // bit u: granule u has arrived, or lies past the 2 G of this launch
+#pragma unroll
+                for (int u = 0; u < KPL; ++u) { key[u] = 0u; if ((uint32_t)lane + 64u * u >= G2) have |= 1u << u; }
                 for (const unsigned long long spin_end = wall_clock64() + ATLAS_SPIN_TICKS; ; ) {
                     bool missing = false;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const uint32_t i = (uint32_t)lane + 64u * u;
-                        if (i < G && (uint32_t)(g[u] >> 32) != tag) {
-                            g[u] = __hip_atomic_load(gmax + (size_t)qq * G + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            missing |= (uint32_t)(g[u] >> 32) != tag;
-                        }
+                    for (int u = 0; u < KPL; ++u) {
+                        if ((have >> u) & 1u) continue;
+                        const unsigned long long g = __hip_atomic_load(gmax + (size_t)qq * G2 + ((uint32_t)lane + 64u * u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((uint32_t)(g >> 32) == tag) {
+                            have |= 1u << u;
+                            const float val = bits_f32((uint32_t)g);
+                            key[u] = val > neg_inf() ? f32_order_key(val) : 0u;
+                        } else missing = true;
                     }
                     if (__builtin_amdgcn_ballot_w64(missing) == 0ull) break;
-                    if (wall_clock64() >= spin_end) break;
+                    if (wall_clock64() >= spin_end) break;          // (what has not arrived in time stays 0: a looser bound, never a wrong one)
                     __builtin_amdgcn_s_sleep(2);
                 }
-                float v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = ((uint32_t)(g[u] >> 32) == tag) ? bits_f32((uint32_t)g[u]) : neg_inf();
-                const float th = initial_theta(v, (int)G, p.k, s_eps[qq], lane);
+                const float th = sample_theta<KPL>(key, p.k, s_eps[qq]);
                 if (lane == 0) __hip_atomic_store(gran + qq, ((unsigned long long)tag << 32) | (unsigned long long)f32_bits(th), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             unsigned long long g = 0ull;
@@ -326,7 +346,7 @@ dscan_kernel(const ScanParams p) {
         }
         wg_barrier_lds();
     };
-    if (ntiles == 0) first_tile_exchange(neg_inf());       // a workgroup without rows still owes the others its (empty) maxima
+    if (ntiles == 0) first_tile_exchange(neg_inf(), neg_inf());       // a workgroup without rows still owes the others its (empty) scores
 
     // the lane's fragment address in stage 0: slab row half * 128 + 16 a + lr, chunk lg of k-step 0 (k-step 1: ^ 64)
     const uint32_t as0 = lds0 + (uint32_t)((half * 128 + lr) * 128 + ((lg ^ (lr & 7)) * 16));
@@ -434,9 +454,23 @@ dscan_kernel(const ScanParams p) {
                 for (int r = 0; r < 4; ++r) m = fmaxf(m, rbase + 16 * a + r < cur.rem ? acc[a][r] : neg_inf());
         }
         if (c_seq == 0) {                                  // workgroup-uniform: the first tile is the sample
-            float mm = fmaxf(m, __shfl_xor(m, 16));
-            mm = fmaxf(mm, __shfl_xor(mm, 32));
-            first_tile_exchange(mm);
+            // the best and the runner-up of the lane's query among the wave's 128 rows: over the lane's 32 elements, then over the four lanes of the query
+            float t1 = neg_inf(), t2 = neg_inf();
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x = rbase + 16 * a + r < cur.rem ? acc[a][r] : neg_inf();
+                    t2 = fmaxf(t2, fminf(t1, x));
+                    t1 = fmaxf(t1, x);
+                }
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float b1 = __shfl_xor(t1, o), b2 = __shfl_xor(t2, o);
+                t2 = fmaxf(fminf(t1, b1), fmaxf(t2, b2));
+                t1 = fmaxf(t1, b1);
+            }
+            first_tile_exchange(t1, t2);
         }
         {
             const float th = bits_f32(ds_ld32(a_theta));   // the lane OWNS its query: one threshold

@@ -36,7 +36,7 @@ sizes = sizes or [4_000_000]
 pools = pools or [(60, 32)]
 reps = int(os.environ.get("REPS", "20"))
 rounds = int(os.environ.get("ROUNDS", "3"))
-B, k, D = 64, 40, 768
+B, k, D = int(os.environ.get("QUERIES", "64")), int(os.environ.get("K", "40")), 768      # (K=128: the over-retrieval of retrieve_with_rerank)
 names = {0: "scan_kernel<16,1,8>", 1: "dscan_kernel<nt>", 2: "dscan_kernel<default>", 3: "dscan<nt> contiguous"}      # 3: one contiguous range per workgroup instead of dealt tiles
 for N in sizes:
     slab = shard(N)
